@@ -1,0 +1,80 @@
+"""ctypes binding of include/camo_fusion.h.
+
+There is no CPU fallback: if the shared library is missing or the tensors are
+not on a HIP device the callers raise.  Build with
+``python -m camouflage_multimodal_amd.build`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcamo_fusion.so")
+
+ABI_VERSION = 1
+FUSION_CROSS_ATTENTION, FUSION_LATE = 0, 1
+PREC_F32, PREC_BF16 = 0, 1
+NPARAMS_CROSS, NPARAMS_LATE = 44, 22
+
+# every symbol include/camo_fusion.h declares
+SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_forward", "camo_backward",
+           "camo_loss", "camo_grad_sumsq", "camo_clip_adamw")
+
+
+class CamoDims(C.Structure):
+    _fields_ = [("rg_dim", C.c_int32), ("kg_dim", C.c_int32), ("hidden_dim", C.c_int32), ("num_heads", C.c_int32),
+                ("num_classes", C.c_int32), ("fusion_type", C.c_int32), ("dropout", C.c_float)]
+
+
+class CamoError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CamoError(f"{LIB_PATH} is missing: the HIP extension has not been built and there is no CPU "
+                        "fallback. Run `python -m camouflage_multimodal_amd.build` (needs hipcc).")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u64, f32, sz = C.c_void_p, C.c_int32, C.c_uint64, C.c_float, C.c_size_t
+    L.camo_abi_version.restype = C.c_int
+    L.camo_abi_version.argtypes = []
+    L.camo_last_error.restype = C.c_char_p
+    L.camo_last_error.argtypes = []
+    L.camo_workspace_bytes.restype = sz
+    L.camo_workspace_bytes.argtypes = [C.POINTER(CamoDims), i32, i32, i32]
+    L.camo_forward.restype = C.c_int
+    L.camo_forward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, vp, vp, i32, u64, i32, vp]
+    L.camo_backward.restype = C.c_int
+    L.camo_backward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, vp, i32, u64, i32, vp]
+    L.camo_loss.restype = C.c_int
+    L.camo_loss.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.camo_grad_sumsq.restype = C.c_int
+    L.camo_grad_sumsq.argtypes = [vp, sz, vp, vp]
+    L.camo_clip_adamw.restype = C.c_int
+    L.camo_clip_adamw.argtypes = [vp, vp, vp, vp, sz, vp, f32, f32, f32, f32, f32, f32, i32, vp]
+    v = L.camo_abi_version()
+    if v != ABI_VERSION:
+        raise CamoError(f"libcamo_fusion.so has ABI version {v}, this package expects {ABI_VERSION}: rebuild it")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().camo_last_error().decode("utf-8", "replace")
+        raise CamoError(f"{what or 'camo call'} failed (code {rc}): {msg}")
+
+
+def require_device(t, name):
+    """The product path runs on a HIP device only."""
+    if not t.is_cuda:
+        raise CamoError(f"{name} is on {t.device}: the fusion path runs as HIP kernels on an MI355X and has no CPU "
+                        "fallback (move the model and its inputs to 'cuda').")

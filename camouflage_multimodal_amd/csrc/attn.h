@@ -1,0 +1,17 @@
+// Launchers of the cross-attention cores (attn.hip).  All return hipError_t as int.
+#pragma once
+#include "common.h"
+
+int attn_supported(int H, int nh, int Nk);
+
+int launch_attn_rg2kg_fwd(const float* Q, const float* KV, const int* offs, float* P, float* O, float* attn_avg,
+                          int B, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream);
+int launch_attn_rg2kg_bwd(const float* Q, const float* KV, const float* P, const float* dO, const int* offs,
+                          float* dQ, float* dKV, int B, int max_nr, int H, int nh, int Nk, DropCfg drop,
+                          hipStream_t stream);
+int launch_attn_kg2rg_fwd(const float* Q2, const float* KV2, const int* offs, float* P2, float* O2,
+                          int B, int H, int nh, int Nk, DropCfg drop, hipStream_t stream);
+int launch_attn_kg2rg_bwd(const float* Q2, const float* KV2, const float* P2, const float* dO2, const int* offs,
+                          float* dQ2, float* dKV2, float* dS2, int B, int H, int nh, int Nk, DropCfg drop,
+                          hipStream_t stream);
+int launch_attn_avg(const float* P2, float* out, int T, int nh, int Nk, DropCfg drop, hipStream_t stream);

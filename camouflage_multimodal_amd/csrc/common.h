@@ -1,0 +1,55 @@
+// Shared device/host helpers for the fusion kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CAMO_WAVE 64
+
+// dropout sites: one independent mask stream per place the reference has an
+// nn.Dropout / MHA dropout (fusion_model.py:36,44,56,63,71,211,218,225,232; :157,160)
+enum : uint32_t {
+  SITE_ATTN_RG2KG = 1, SITE_ATTN_KG2RG = 2, SITE_FFN_RG = 3, SITE_FFN_KG = 4, SITE_FUSE = 5,
+  SITE_HEAD0 = 6, /* +0 mask, +1 instance, +2 edge, +3 score */
+  SITE_LATE0 = 10 /* +0, +1 */
+};
+
+struct DropCfg {
+  uint32_t seed_lo, seed_hi;
+  float p;       // drop probability; 0 => disabled
+  float scale;   // 1/(1-p)
+};
+
+__host__ __device__ inline DropCfg make_drop(int training, float p, uint64_t seed) {
+  DropCfg d;
+  d.seed_lo = (uint32_t)(seed & 0xFFFFFFFFull);
+  d.seed_hi = (uint32_t)(seed >> 32);
+  d.p = (training && p > 0.f) ? p : 0.f;
+  d.scale = d.p > 0.f ? 1.0f / (1.0f - d.p) : 1.0f;
+  return d;
+}
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+
+// keep-multiplier (0 or 1/(1-p)) of element `idx` at `site`.  Same arithmetic as
+// oracle/fusion_oracle.py::dropout_keep, so masks agree element for element.
+__device__ __forceinline__ float drop_mult(const DropCfg& d, uint32_t site, uint32_t idx) {
+  uint32_t x = idx * 0x9E3779B1u + site * 0x85EBCA77u + d.seed_lo;
+  x = fmix32(x);
+  x = fmix32(x ^ d.seed_hi);
+  float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+  return u >= d.p ? d.scale : 0.0f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

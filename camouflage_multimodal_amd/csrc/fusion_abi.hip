@@ -1,0 +1,426 @@
+// C ABI (include/camo_fusion.h): workspace carving and the launch schedules of the fused
+// forward / backward of the fusion model.  No device code here.
+//
+// Algebra used (results equal to the reference up to fp32 re-association):
+//   * mean-pool linearity.  The reference computes Z = Y + FFN(Y) for every node and then only
+//     uses mean_t Z (fusion_model.py:120,134).  Since the second FFN layer is linear,
+//       mean_t Z = mean_t Y + (mean_t H1d) . W2^T + b2,   H1d = dropout(relu(Y.W1^T + b1)),
+//     so the [Nr,512]x[512,256] GEMM per sample (22 % of the forward FLOPs) becomes a
+//     [B,512]x[512,256] one, and in the backward d(H1d) is one row per sample broadcast
+//     through the ReLU/dropout mask, dW2 = d(pool)^T . mean(H1d)  (two more full-size GEMMs gone).
+//   * K|V projections share their input, so they run as one N=2H GEMM on the contiguous rows
+//     H..3H of in_proj_weight; their input gradients as one K=2H GEMM.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/camo_fusion.h"
+#include "attn.h"
+#include "gemm.h"
+#include "misc.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+int fail_hip(int e, const char* where) {
+  g_err = std::string(where) + ": " + hipGetErrorString((hipError_t)e);
+  return CAMO_E_HIP;
+}
+#define CK(x, where)                         \
+  do {                                       \
+    int e_ = (x);                            \
+    if (e_ != 0) return fail_hip(e_, where); \
+  } while (0)
+
+struct Carver {
+  char* base; size_t off;
+  explicit Carver(void* b) : base(static_cast<char*>(b)), off(0) {}
+  template <typename T> T* take(size_t n) {
+    off = (off + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct Ws {
+  // maps
+  int* row_sample; float* inv_nr;
+  // forward (saved for backward)
+  float *R, *G, *Q, *KV2, *KV, *Q2, *P, *P2, *O, *O2, *U, *U2, *st1, *st2, *Y, *Y2, *H1, *H2;
+  float *means, *Ymean, *H1mean, *Y2mean, *H2mean; size_t means_n;
+  float *comb, *F1, *fused, *hid, *a2;
+  // backward scratch
+  float *dlog, *dhid, *dfused, *dF1, *dcomb, *dHm1, *dHm2, *da2;
+  float *dH1, *dH2, *dY, *dY2, *dU, *dU2, *dO, *dO2, *dQ, *dKV, *dQ2, *dKV2, *dS2, *dR, *dG;
+  size_t bytes;
+};
+
+Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
+  Ws w{};
+  Carver c(base);
+  const size_t H = d.hidden_dim, TK = (size_t)B * Nk, nh = d.num_heads, Wd = 2 * d.num_classes + 2;
+  if (d.fusion_type == CAMO_FUSION_CROSS_ATTENTION) {
+    const size_t Fh = H / 2;
+    w.row_sample = c.take<int>(T); w.inv_nr = c.take<float>(B);
+    w.R = c.take<float>(T * H); w.G = c.take<float>(TK * H);
+    w.Q = c.take<float>(T * H); w.KV2 = c.take<float>(T * 2 * H);
+    w.KV = c.take<float>(TK * 2 * H); w.Q2 = c.take<float>(TK * H);
+    w.P = c.take<float>(T * nh * Nk); w.P2 = c.take<float>(T * nh * Nk);
+    w.O = c.take<float>(T * H); w.O2 = c.take<float>(TK * H);
+    w.U = c.take<float>(T * H); w.U2 = c.take<float>(TK * H);
+    w.st1 = c.take<float>(T * 2); w.st2 = c.take<float>(TK * 2);
+    w.Y = c.take<float>(T * H); w.Y2 = c.take<float>(TK * H);
+    w.H1 = c.take<float>(T * 2 * H); w.H2 = c.take<float>(TK * 2 * H);
+    w.means_n = (size_t)B * 6 * H;
+    w.means = c.take<float>(w.means_n);
+    if (w.means) { w.Ymean = w.means; w.H1mean = w.Ymean + B * H; w.Y2mean = w.H1mean + B * 2 * H; w.H2mean = w.Y2mean + B * H; }
+    w.comb = c.take<float>(B * 2 * H); w.F1 = c.take<float>(B * H); w.fused = c.take<float>(B * H);
+    w.hid = c.take<float>(B * 4 * Fh);
+    w.dlog = c.take<float>(B * Wd); w.dhid = c.take<float>(B * 4 * Fh); w.dfused = c.take<float>(B * H);
+    w.dF1 = c.take<float>(B * H); w.dcomb = c.take<float>(B * 2 * H);
+    w.dHm1 = c.take<float>(B * 2 * H); w.dHm2 = c.take<float>(B * 2 * H);
+    w.dH1 = c.take<float>(T * 2 * H); w.dH2 = c.take<float>(TK * 2 * H);
+    w.dY = c.take<float>(T * H); w.dY2 = c.take<float>(TK * H);
+    w.dU = c.take<float>(T * H); w.dU2 = c.take<float>(TK * H);
+    w.dO = c.take<float>(T * H); w.dO2 = c.take<float>(TK * H);
+    w.dQ = c.take<float>(T * H); w.dKV = c.take<float>(TK * 2 * H);
+    w.dQ2 = c.take<float>(TK * H); w.dKV2 = c.take<float>(T * 2 * H);
+    w.dS2 = c.take<float>(T * nh * Nk);
+    w.dR = c.take<float>(T * H); w.dG = c.take<float>(TK * H);
+  } else {
+    const size_t F = H / 2, Fh = F / 2, Dc = (size_t)d.rg_dim + d.kg_dim;
+    w.means_n = (size_t)B * Dc;
+    w.comb = c.take<float>(w.means_n);         // [B, rg_dim+kg_dim] = the two means, zeroed then accumulated
+    w.means = w.comb;
+    w.F1 = c.take<float>(B * H);               // a1
+    w.a2 = c.take<float>(B * F);
+    w.fused = c.take<float>(B * F);
+    w.hid = c.take<float>(B * 4 * Fh);
+    w.dlog = c.take<float>(B * Wd); w.dhid = c.take<float>(B * 4 * Fh); w.dfused = c.take<float>(B * F);
+    w.da2 = c.take<float>(B * F); w.dF1 = c.take<float>(B * H);
+  }
+  c.off = (c.off + 255) & ~size_t(255);
+  w.bytes = c.off;
+  return w;
+}
+
+int check_dims(const camo_dims_t* d, int B, int T, int Nk) {
+  if (!d) return fail(CAMO_E_ARG, "dims is null");
+  if (B < 1 || T < B || Nk < 1) return fail(CAMO_E_ARG, "need B >= 1, T >= B (every sample has >= 1 RG row), Nk >= 1");
+  if (d->rg_dim < 1 || d->kg_dim < 1 || d->hidden_dim < 4 || d->num_classes < 1 || d->num_classes > 64)
+    return fail(CAMO_E_ARG, "bad model dimensions");
+  if (!(d->dropout >= 0.f && d->dropout < 1.f)) return fail(CAMO_E_ARG, "dropout must be in [0,1)");
+  if (d->fusion_type == CAMO_FUSION_CROSS_ATTENTION) {
+    if (d->num_heads < 1 || d->hidden_dim % d->num_heads) return fail(CAMO_E_ARG, "hidden_dim must be divisible by num_heads");
+    if (d->hidden_dim % 2) return fail(CAMO_E_UNSUPPORTED, "hidden_dim must be even");
+    if (!attn_supported(d->hidden_dim, d->num_heads, Nk))
+      return fail(CAMO_E_UNSUPPORTED, "attention kernels support num_heads <= 256, head_dim <= 256, Nk <= 64 within 160 KB of LDS");
+    if (!ln_supported(d->hidden_dim)) return fail(CAMO_E_UNSUPPORTED, "LayerNorm kernels support hidden_dim <= 1024");
+  } else if (d->fusion_type == CAMO_FUSION_LATE) {
+    if (d->hidden_dim % 4) return fail(CAMO_E_UNSUPPORTED, "late fusion needs hidden_dim divisible by 4");
+  } else {
+    return fail(CAMO_E_ARG, "unknown fusion_type");
+  }
+  if ((double)T * d->hidden_dim * 2 > 2.0e9 || (double)T * d->num_heads * Nk > 4.0e9)
+    return fail(CAMO_E_UNSUPPORTED, "batch too large for 32-bit element indices");
+  return 0;
+}
+
+struct GB {
+  GemmBatch b;
+  int prec; hipStream_t st;
+  GB(const DropCfg& d, int prec_, hipStream_t st_) : prec(prec_), st(st_) { std::memset(&b, 0, sizeof(b)); b.drop = d; }
+  GemmProb& add(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K, int flags) {
+    GemmProb& p = b.p[b.n++];
+    p.A = A; p.lda = lda; p.B = Bm; p.ldb = ldb; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.flags = flags;
+    p.aux_scale = 1.f;
+    return p;
+  }
+  // y = x.W^T (+bias): x [M,K], W [N,K]
+  GemmProb& nt(const float* x, int ldx, const float* W, int ldw, const float* bias, float* y, int ldy, int M, int N, int K, int flags = 0) {
+    GemmProb& p = add(x, ldx, W, ldw, y, ldy, M, N, K, flags);
+    p.bias = bias;
+    return p;
+  }
+  // dx = dy.W : dy [M,K=Nout], W [Nout, N=in]
+  GemmProb& nn(const float* dy, int lddy, const float* W, int ldw, float* dx, int lddx, int M, int N, int K, int flags = 0) {
+    return add(dy, lddy, W, ldw, dx, lddx, M, N, K, flags | GF_B_KMAJOR);
+  }
+  // dW [Nout, Nin] += dy^T.x : dy [rows, Nout], x [rows, Nin]; db [Nout] += colsum(dy)
+  GemmProb& tn(const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, float* db, int Nout, int Nin, int rows) {
+    GemmProb& p = add(dy, lddy, x, ldx, dW, lddw, Nout, Nin, rows, GF_A_KMAJOR | GF_B_KMAJOR | GF_ATOMIC);
+    p.bias_grad = db;
+    return p;
+  }
+  int run() {
+    if (b.n == 0) return 0;
+    int e = launch_gemm_batch(b, prec, st);
+    b.n = 0;
+    return e;
+  }
+};
+
+void set_res(GemmProb& p, const float* res, int ldr) { p.res = res; p.ldr = ldr; }
+void set_drop(GemmProb& p, uint32_t site) { p.flags |= GF_DROPOUT; p.drop_site = site; }
+void set_relu_bwd(GemmProb& p, const float* act, int ldr, float scale) {
+  p.flags |= GF_RELU_BWD; p.res = act; p.ldr = ldr; p.aux_scale = scale;
+}
+void set_bcast(GemmProb& p, const float* v, int ldv, const int* row_sample, const float* inv_nr, int uniform_n) {
+  p.flags |= GF_RES_BCAST; p.res = v; p.ldr = ldv; p.row_sample = row_sample; p.inv_nr = inv_nr; p.uniform_n = uniform_n;
+}
+
+// ---- the four heads (fusion_model.py:208-235), shared by both fusion types -------------------
+int heads_forward(const camo_dims_t& d, const float* const* hp /*16 pointers*/, const Ws& w, int B, int F,
+                  float* outs, const DropCfg& drop, int prec, hipStream_t st) {
+  const int Fh = F / 2, C = d.num_classes, Wd = 2 * C + 2;
+  const int nout[4] = {C, C, 1, 1}, coff[4] = {0, C, 2 * C, 2 * C + 1};
+  GB g(drop, prec, st);
+  for (int x = 0; x < 4; ++x) {
+    GemmProb& p = g.nt(w.fused, F, hp[4 * x], F, hp[4 * x + 1], w.hid + x * Fh, 4 * Fh, B, Fh, F, GF_RELU);
+    set_drop(p, SITE_HEAD0 + x);
+  }
+  CK(g.run(), "heads hidden");
+  for (int x = 0; x < 4; ++x)
+    g.nt(w.hid + x * Fh, 4 * Fh, hp[4 * x + 2], Fh, hp[4 * x + 3], outs + coff[x], Wd, B, nout[x], Fh, x == 3 ? GF_SIGMOID : 0);
+  CK(g.run(), "heads out");
+  return 0;
+}
+
+// d_outs -> dfused (w.dfused, zeroed here) and the 16 head-parameter gradients
+int heads_backward(const camo_dims_t& d, const float* const* hp, float* const* hg, const Ws& w, int B, int F,
+                   const float* outs, const float* d_outs, const DropCfg& drop, int prec, hipStream_t st) {
+  const int Fh = F / 2, C = d.num_classes, Wd = 2 * C + 2;
+  const int nout[4] = {C, C, 1, 1}, coff[4] = {0, C, 2 * C, 2 * C + 1};
+  CK((int)hipMemsetAsync(w.dfused, 0, sizeof(float) * (size_t)B * F, st), "memset dfused");
+  CK(launch_head_out_grad(outs, d_outs, w.dlog, B, Wd, st), "head_out_grad");
+  GB g(drop, prec, st);
+  for (int x = 0; x < 4; ++x) {
+    GemmProb& p = g.nn(w.dlog + coff[x], Wd, hp[4 * x + 2], Fh, w.dhid + x * Fh, 4 * Fh, B, Fh, nout[x]);
+    set_relu_bwd(p, w.hid + x * Fh, 4 * Fh, drop.scale);
+    g.tn(w.dlog + coff[x], Wd, w.hid + x * Fh, 4 * Fh, hg[4 * x + 2], Fh, hg[4 * x + 3], nout[x], Fh, B);
+  }
+  CK(g.run(), "heads out bwd");
+  for (int x = 0; x < 4; ++x) {
+    g.nn(w.dhid + x * Fh, 4 * Fh, hp[4 * x], F, w.dfused, F, B, F, Fh, GF_ATOMIC);
+    g.tn(w.dhid + x * Fh, 4 * Fh, w.fused, F, hg[4 * x], F, hg[4 * x + 1], Fh, F, B);
+  }
+  CK(g.run(), "heads hidden bwd");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int camo_abi_version(void) { return CAMO_ABI_VERSION; }
+const char* camo_last_error(void) { return g_err.c_str(); }
+
+size_t camo_workspace_bytes(const camo_dims_t* dims, int32_t B, int32_t T, int32_t Nk) {
+  if (check_dims(dims, B, T, Nk)) return 0;
+  return carve(*dims, B, T, Nk, nullptr).bytes;
+}
+
+int camo_forward(const camo_dims_t* dims, const float* const* params, const float* rg, const int32_t* rg_offsets,
+                 const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace,
+                 size_t workspace_bytes, float* outs, float* attn_rg2kg, float* attn_kg2rg, int32_t training,
+                 uint64_t seed, int32_t precision, void* stream) {
+  if (int e = check_dims(dims, B, T, Nk)) return e;
+  if (!params || !rg || !rg_offsets || !kg || !workspace || !outs) return fail(CAMO_E_ARG, "null pointer argument");
+  if (max_nr < 1 || max_nr > T) return fail(CAMO_E_ARG, "max_nr out of range");
+  if (precision != CAMO_PREC_F32 && precision != CAMO_PREC_BF16) return fail(CAMO_E_ARG, "unknown precision");
+  const camo_dims_t& d = *dims;
+  const Ws w = carve(d, B, T, Nk, workspace);
+  if (workspace_bytes < w.bytes) return fail(CAMO_E_WORKSPACE, "workspace smaller than camo_workspace_bytes()");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const DropCfg drop = make_drop(training, d.dropout, seed);
+  const int H = d.hidden_dim, D = d.rg_dim, Dk = d.kg_dim, TK = B * Nk, nh = d.num_heads;
+  const float* const* P = params;
+  GB g(drop, precision, st);
+
+  if (d.fusion_type == CAMO_FUSION_LATE) {
+    // LateFusion.forward, fusion_model.py:164-171
+    const int F = H / 2, Dc = D + Dk;
+    CK((int)hipMemsetAsync(w.means, 0, sizeof(float) * w.means_n, st), "memset means");
+    SegMean sm[2] = {{rg, D, D, rg_offsets, 0, w.comb, Dc}, {kg, Dk, Dk, nullptr, Nk, w.comb + D, Dc}};
+    CK(launch_seg_mean(sm, 2, B, max_nr > Nk ? max_nr : Nk, st), "late means");
+    set_drop(g.nt(w.comb, Dc, P[CAMO_PL_W0], Dc, P[CAMO_PL_B0], w.F1, H, B, H, Dc, GF_RELU), SITE_LATE0);
+    CK(g.run(), "late fc0");
+    set_drop(g.nt(w.F1, H, P[CAMO_PL_W3], H, P[CAMO_PL_B3], w.a2, F, B, F, H, GF_RELU), SITE_LATE0 + 1);
+    CK(g.run(), "late fc3");
+    g.nt(w.a2, F, P[CAMO_PL_W6], F, P[CAMO_PL_B6], w.fused, F, B, F, F);
+    CK(g.run(), "late fc6");
+    return heads_forward(d, P + CAMO_PL_HEADS, w, B, F, outs, drop, precision, st);
+  }
+
+  // ---- CrossAttentionFusion.forward, fusion_model.py:75-146
+  CK(launch_rowmap(rg_offsets, w.row_sample, w.inv_nr, B, max_nr, st), "rowmap");
+  const float* R = rg; const float* G = kg;
+  if (P[CAMO_P_RG_PROJ_W]) { g.nt(rg, D, P[CAMO_P_RG_PROJ_W], D, P[CAMO_P_RG_PROJ_B], w.R, H, T, H, D); R = w.R; }
+  else if (D != H) return fail(CAMO_E_ARG, "rg_proj weight missing but rg_dim != hidden_dim");
+  if (P[CAMO_P_KG_PROJ_W]) { g.nt(kg, Dk, P[CAMO_P_KG_PROJ_W], Dk, P[CAMO_P_KG_PROJ_B], w.G, H, TK, H, Dk); G = w.G; }
+  else if (Dk != H) return fail(CAMO_E_ARG, "kg_proj weight missing but kg_dim != hidden_dim");
+  CK(g.run(), "input projections");
+  // in-projections of both attention blocks (packed in_proj_weight: rows 0..H-1 = Wq, H..3H-1 = Wk|Wv)
+  g.nt(R, H, P[CAMO_P_A1_IN_W], H, P[CAMO_P_A1_IN_B], w.Q, H, T, H, H);
+  g.nt(R, H, P[CAMO_P_A2_IN_W] + (size_t)H * H, H, P[CAMO_P_A2_IN_B] + H, w.KV2, 2 * H, T, 2 * H, H);
+  g.nt(G, H, P[CAMO_P_A1_IN_W] + (size_t)H * H, H, P[CAMO_P_A1_IN_B] + H, w.KV, 2 * H, TK, 2 * H, H);
+  g.nt(G, H, P[CAMO_P_A2_IN_W], H, P[CAMO_P_A2_IN_B], w.Q2, H, TK, H, H);
+  CK(g.run(), "attention in-projections");
+  CK(launch_attn_rg2kg_fwd(w.Q, w.KV, rg_offsets, w.P, w.O, attn_rg2kg, B, max_nr, H, nh, Nk, drop, st), "attn rg2kg fwd");
+  CK(launch_attn_kg2rg_fwd(w.Q2, w.KV2, rg_offsets, w.P2, w.O2, B, H, nh, Nk, drop, st), "attn kg2rg fwd");
+  if (attn_kg2rg) CK(launch_attn_avg(w.P2, attn_kg2rg, T, nh, Nk, drop, st), "attn avg");
+  // out-projection + residual (fusion_model.py:119,130), then LayerNorm
+  set_res(g.nt(w.O, H, P[CAMO_P_A1_OUT_W], H, P[CAMO_P_A1_OUT_B], w.U, H, T, H, H), R, H);
+  set_res(g.nt(w.O2, H, P[CAMO_P_A2_OUT_W], H, P[CAMO_P_A2_OUT_B], w.U2, H, TK, H, H), G, H);
+  CK(g.run(), "attention out-projections");
+  {
+    LnSeg s0{w.U, w.Y, w.st1, P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], T};
+    LnSeg s1{w.U2, w.Y2, w.st2, P[CAMO_P_LN2_W], P[CAMO_P_LN2_B], TK};
+    CK(launch_ln_fwd(s0, s1, H, st), "layernorm fwd");
+  }
+  // FFN first layers (ReLU + dropout fused), fusion_model.py:53-65
+  set_drop(g.nt(w.Y, H, P[CAMO_P_F1_W0], H, P[CAMO_P_F1_B0], w.H1, 2 * H, T, 2 * H, H, GF_RELU), SITE_FFN_RG);
+  set_drop(g.nt(w.Y2, H, P[CAMO_P_F2_W0], H, P[CAMO_P_F2_B0], w.H2, 2 * H, TK, 2 * H, H, GF_RELU), SITE_FFN_KG);
+  CK(g.run(), "ffn layer 0");
+  // per-sample means of Y and H1d, then the second FFN layer on the means (mean-pool linearity)
+  CK((int)hipMemsetAsync(w.means, 0, sizeof(float) * w.means_n, st), "memset means");
+  {
+    SegMean sm[4] = {{w.Y, H, H, rg_offsets, 0, w.Ymean, H}, {w.H1, 2 * H, 2 * H, rg_offsets, 0, w.H1mean, 2 * H},
+                     {w.Y2, H, H, nullptr, Nk, w.Y2mean, H}, {w.H2, 2 * H, 2 * H, nullptr, Nk, w.H2mean, 2 * H}};
+    CK(launch_seg_mean(sm, 4, B, max_nr > Nk ? max_nr : Nk, st), "pool");
+  }
+  set_res(g.nt(w.H1mean, 2 * H, P[CAMO_P_F1_W3], 2 * H, P[CAMO_P_F1_B3], w.comb, 2 * H, B, H, 2 * H), w.Ymean, H);
+  set_res(g.nt(w.H2mean, 2 * H, P[CAMO_P_F2_W3], 2 * H, P[CAMO_P_F2_B3], w.comb + H, 2 * H, B, H, 2 * H), w.Y2mean, H);
+  CK(g.run(), "ffn layer 3 on pooled rows");
+  // fusion layer (fusion_model.py:68-73,138-139)
+  set_drop(g.nt(w.comb, 2 * H, P[CAMO_P_FU_W0], 2 * H, P[CAMO_P_FU_B0], w.F1, H, B, H, 2 * H, GF_RELU), SITE_FUSE);
+  CK(g.run(), "fusion layer 0");
+  g.nt(w.F1, H, P[CAMO_P_FU_W3], H, P[CAMO_P_FU_B3], w.fused, H, B, H, H);
+  CK(g.run(), "fusion layer 3");
+  return heads_forward(d, P + CAMO_P_HEADS, w, B, H, outs, drop, precision, st);
+}
+
+int camo_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
+                  const int32_t* rg_offsets, const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr,
+                  void* workspace, size_t workspace_bytes, const float* outs, const float* d_outs,
+                  int32_t training, uint64_t seed, int32_t precision, void* stream) {
+  if (int e = check_dims(dims, B, T, Nk)) return e;
+  if (!params || !grads || !rg || !rg_offsets || !kg || !workspace || !outs || !d_outs)
+    return fail(CAMO_E_ARG, "null pointer argument");
+  if (max_nr < 1 || max_nr > T) return fail(CAMO_E_ARG, "max_nr out of range");
+  if (precision != CAMO_PREC_F32 && precision != CAMO_PREC_BF16) return fail(CAMO_E_ARG, "unknown precision");
+  const camo_dims_t& d = *dims;
+  const Ws w = carve(d, B, T, Nk, workspace);
+  if (workspace_bytes < w.bytes) return fail(CAMO_E_WORKSPACE, "workspace smaller than camo_workspace_bytes()");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const DropCfg drop = make_drop(training, d.dropout, seed);
+  const int H = d.hidden_dim, D = d.rg_dim, Dk = d.kg_dim, TK = B * Nk, nh = d.num_heads;
+  const float* const* P = params;
+  float* const* Gr = grads;
+  GB g(drop, precision, st);
+
+  if (d.fusion_type == CAMO_FUSION_LATE) {
+    const int F = H / 2, Dc = D + Dk;
+    if (int e = heads_backward(d, P + CAMO_PL_HEADS, Gr + CAMO_PL_HEADS, w, B, F, outs, d_outs, drop, precision, st)) return e;
+    set_relu_bwd(g.nn(w.dfused, F, P[CAMO_PL_W6], F, w.da2, F, B, F, F), w.a2, F, drop.scale);
+    g.tn(w.dfused, F, w.a2, F, Gr[CAMO_PL_W6], F, Gr[CAMO_PL_B6], F, F, B);
+    CK(g.run(), "late fc6 bwd");
+    set_relu_bwd(g.nn(w.da2, F, P[CAMO_PL_W3], H, w.dF1, H, B, H, F), w.F1, H, drop.scale);
+    g.tn(w.da2, F, w.F1, H, Gr[CAMO_PL_W3], H, Gr[CAMO_PL_B3], F, H, B);
+    CK(g.run(), "late fc3 bwd");
+    g.tn(w.dF1, H, w.comb, Dc, Gr[CAMO_PL_W0], Dc, Gr[CAMO_PL_B0], H, Dc, B);
+    CK(g.run(), "late fc0 bwd");
+    return 0;
+  }
+
+  const bool has_rgp = P[CAMO_P_RG_PROJ_W] != nullptr, has_kgp = P[CAMO_P_KG_PROJ_W] != nullptr;
+  const float* R = has_rgp ? w.R : rg;
+  const float* G = has_kgp ? w.G : kg;
+  if (int e = heads_backward(d, P + CAMO_P_HEADS, Gr + CAMO_P_HEADS, w, B, H, outs, d_outs, drop, precision, st)) return e;
+  CK((int)hipMemsetAsync(w.dKV, 0, sizeof(float) * (size_t)TK * 2 * H, st), "memset dKV");
+  // fusion layer
+  set_relu_bwd(g.nn(w.dfused, H, P[CAMO_P_FU_W3], H, w.dF1, H, B, H, H), w.F1, H, drop.scale);
+  g.tn(w.dfused, H, w.F1, H, Gr[CAMO_P_FU_W3], H, Gr[CAMO_P_FU_B3], H, H, B);
+  CK(g.run(), "fusion layer 3 bwd");
+  g.nn(w.dF1, H, P[CAMO_P_FU_W0], 2 * H, w.dcomb, 2 * H, B, 2 * H, H);
+  g.tn(w.dF1, H, w.comb, 2 * H, Gr[CAMO_P_FU_W0], 2 * H, Gr[CAMO_P_FU_B0], H, 2 * H, B);
+  CK(g.run(), "fusion layer 0 bwd");
+  // pooled second FFN layer: d(mean H1d) = dpool.W2 ; dW2 += dpool^T.mean(H1d) ; db2 += sum_b dpool
+  g.nn(w.dcomb, 2 * H, P[CAMO_P_F1_W3], 2 * H, w.dHm1, 2 * H, B, 2 * H, H);
+  g.nn(w.dcomb + H, 2 * H, P[CAMO_P_F2_W3], 2 * H, w.dHm2, 2 * H, B, 2 * H, H);
+  g.tn(w.dcomb, 2 * H, w.H1mean, 2 * H, Gr[CAMO_P_F1_W3], 2 * H, Gr[CAMO_P_F1_B3], H, 2 * H, B);
+  g.tn(w.dcomb + H, 2 * H, w.H2mean, 2 * H, Gr[CAMO_P_F2_W3], 2 * H, Gr[CAMO_P_F2_B3], H, 2 * H, B);
+  CK(g.run(), "ffn layer 3 bwd (pooled)");
+  {
+    BcastSeg s0{w.H1, w.dHm1, 2 * H, w.row_sample, w.inv_nr, 0, w.dH1, T};
+    BcastSeg s1{w.H2, w.dHm2, 2 * H, nullptr, nullptr, Nk, w.dH2, TK};
+    CK(launch_relu_bcast_bwd(s0, s1, 2 * H, drop.scale, st), "relu bcast bwd");
+  }
+  // first FFN layer: dY = bcast(dpool)/n + dH1.W1 ; dW1 += dH1^T.Y
+  set_bcast(g.nn(w.dH1, 2 * H, P[CAMO_P_F1_W0], H, w.dY, H, T, H, 2 * H), w.dcomb, 2 * H, w.row_sample, w.inv_nr, 0);
+  set_bcast(g.nn(w.dH2, 2 * H, P[CAMO_P_F2_W0], H, w.dY2, H, TK, H, 2 * H), w.dcomb + H, 2 * H, nullptr, nullptr, Nk);
+  g.tn(w.dH1, 2 * H, w.Y, H, Gr[CAMO_P_F1_W0], H, Gr[CAMO_P_F1_B0], 2 * H, H, T);
+  g.tn(w.dH2, 2 * H, w.Y2, H, Gr[CAMO_P_F2_W0], H, Gr[CAMO_P_F2_B0], 2 * H, H, TK);
+  CK(g.run(), "ffn layer 0 bwd");
+  {
+    LnBwdSeg s0{w.U, w.dY, w.st1, P[CAMO_P_LN1_W], w.dU, Gr[CAMO_P_LN1_W], Gr[CAMO_P_LN1_B], T};
+    LnBwdSeg s1{w.U2, w.dY2, w.st2, P[CAMO_P_LN2_W], w.dU2, Gr[CAMO_P_LN2_W], Gr[CAMO_P_LN2_B], TK};
+    CK(launch_ln_bwd(s0, s1, H, st), "layernorm bwd");
+  }
+  // out-projections
+  g.nn(w.dU, H, P[CAMO_P_A1_OUT_W], H, w.dO, H, T, H, H);
+  g.nn(w.dU2, H, P[CAMO_P_A2_OUT_W], H, w.dO2, H, TK, H, H);
+  g.tn(w.dU, H, w.O, H, Gr[CAMO_P_A1_OUT_W], H, Gr[CAMO_P_A1_OUT_B], H, H, T);
+  g.tn(w.dU2, H, w.O2, H, Gr[CAMO_P_A2_OUT_W], H, Gr[CAMO_P_A2_OUT_B], H, H, TK);
+  CK(g.run(), "out-projection bwd");
+  CK(launch_attn_rg2kg_bwd(w.Q, w.KV, w.P, w.dO, rg_offsets, w.dQ, w.dKV, B, max_nr, H, nh, Nk, drop, st), "attn rg2kg bwd");
+  CK(launch_attn_kg2rg_bwd(w.Q2, w.KV2, w.P2, w.dO2, rg_offsets, w.dQ2, w.dKV2, w.dS2, B, H, nh, Nk, drop, st), "attn kg2rg bwd");
+  // in-projection weight gradients, and the gradients flowing into R and G
+  const size_t HH = (size_t)H * H;
+  g.tn(w.dQ, H, R, H, Gr[CAMO_P_A1_IN_W], H, Gr[CAMO_P_A1_IN_B], H, H, T);
+  g.tn(w.dKV2, 2 * H, R, H, Gr[CAMO_P_A2_IN_W] + HH, H, Gr[CAMO_P_A2_IN_B] + H, 2 * H, H, T);
+  g.tn(w.dKV, 2 * H, G, H, Gr[CAMO_P_A1_IN_W] + HH, H, Gr[CAMO_P_A1_IN_B] + H, 2 * H, H, TK);
+  g.tn(w.dQ2, H, G, H, Gr[CAMO_P_A2_IN_W], H, Gr[CAMO_P_A2_IN_B], H, H, TK);
+  if (has_rgp) set_res(g.nn(w.dQ, H, P[CAMO_P_A1_IN_W], H, w.dR, H, T, H, H), w.dU, H);
+  if (has_kgp) set_res(g.nn(w.dQ2, H, P[CAMO_P_A2_IN_W], H, w.dG, H, TK, H, H), w.dU2, H);
+  CK(g.run(), "in-projection bwd");
+  if (has_rgp) set_res(g.nn(w.dKV2, 2 * H, P[CAMO_P_A2_IN_W] + HH, H, w.dR, H, T, H, 2 * H), w.dR, H);
+  if (has_kgp) set_res(g.nn(w.dKV, 2 * H, P[CAMO_P_A1_IN_W] + HH, H, w.dG, H, TK, H, 2 * H), w.dG, H);
+  CK(g.run(), "k|v input gradients");
+  if (has_rgp) g.tn(w.dR, H, rg, D, Gr[CAMO_P_RG_PROJ_W], D, Gr[CAMO_P_RG_PROJ_B], H, D, T);
+  if (has_kgp) g.tn(w.dG, H, kg, Dk, Gr[CAMO_P_KG_PROJ_W], Dk, Gr[CAMO_P_KG_PROJ_B], H, Dk, TK);
+  CK(g.run(), "input projection bwd");
+  return 0;
+}
+
+int camo_loss(const float* outs, const int64_t* y, const float* e, const float* s, int32_t B, int32_t num_classes,
+              float* loss_terms, float* d_outs, int32_t* pred, void* stream) {
+  if (!outs || !y || !e || !s || !loss_terms || !d_outs) return fail(CAMO_E_ARG, "null pointer argument");
+  if (B < 1 || num_classes < 2) return fail(CAMO_E_ARG, "need B >= 1 and num_classes >= 2");
+  CK(launch_loss(outs, reinterpret_cast<const long long*>(y), e, s, B, num_classes, loss_terms, d_outs, pred,
+                 static_cast<hipStream_t>(stream)), "loss");
+  return 0;
+}
+
+int camo_grad_sumsq(const float* g, size_t n, float* sumsq, void* stream) {
+  if (!g || !sumsq || n == 0) return fail(CAMO_E_ARG, "null pointer or empty buffer");
+  CK(launch_sumsq(g, n, sumsq, static_cast<hipStream_t>(stream)), "grad sumsq");
+  return 0;
+}
+
+int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, const float* sumsq, float max_norm, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+  if (!p || !g || !m || !v || !sumsq || n == 0) return fail(CAMO_E_ARG, "null pointer or empty buffer");
+  if (step < 1) return fail(CAMO_E_ARG, "step is 1-based");
+  CK(launch_clip_adamw(p, g, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step,
+                       static_cast<hipStream_t>(stream)), "clip+adamw");
+  return 0;
+}
+
+}  // extern "C"

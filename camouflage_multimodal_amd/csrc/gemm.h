@@ -1,0 +1,44 @@
+// Grouped GEMM with fused epilogues: one launch runs up to GEMM_MAXP independent
+// problems (different pointers / shapes / operand layouts / epilogues).
+#pragma once
+#include "common.h"
+
+#define GEMM_MAXP 8
+
+enum : int {
+  GF_RELU = 1,        // v = max(v, 0)                       (after bias)
+  GF_DROPOUT = 2,     // v *= keep(site, row*N+col)/(1-p)
+  GF_ATOMIC = 4,      // C += v with atomicAdd (split-K partials, shared accumulators)
+  GF_RELU_BWD = 8,    // v *= (aux[row,col] > 0 ? aux_scale : 0); aux = `res` pointer
+  GF_RES_BCAST = 16,  // residual row = res[sample(row), col] * inv_n(sample(row)); sample(): see GemmProb
+  GF_SIGMOID = 32,    // v = 1/(1+exp(-v))                   (last)
+  GF_A_KMAJOR = 64,   // A element (m,k) at A[k*lda + m] instead of A[m*lda + k]
+  GF_B_KMAJOR = 128   // B element (k,n) at B[k*ldb + n] instead of B[n*ldb + k]
+};
+
+// C[m,n] (+)= epi( sum_k A(m,k) * B(k,n) + bias[n] ) (+ res[m,n])
+struct GemmProb {
+  const float* A; const float* B; float* C;
+  const float* bias;      // [N] or null
+  const float* res;       // residual / aux, ld = ldr, or null
+  float* bias_grad;       // [M] += sum_k A(m,k)   (A k-major only; the bias gradient of a dW GEMM) or null
+  int M, N, K;
+  int lda, ldb, ldc, ldr;
+  int flags;
+  uint32_t drop_site;
+  float aux_scale;
+  // GF_RES_BCAST: sample(row) = row_sample[row], inv_n = inv_nr[sample]; or, when row_sample is
+  // null, sample(row) = row / uniform_n and inv_n = 1/uniform_n
+  const int* row_sample; const float* inv_nr; int uniform_n;
+  // filled by the launcher
+  int tiles_n, ksplit, kchunk, tile_begin;
+};
+
+struct GemmBatch {
+  GemmProb p[GEMM_MAXP];
+  int n;
+  DropCfg drop;
+};
+
+// precision: CAMO_PREC_F32 / CAMO_PREC_BF16.  Returns hipError_t as int.
+int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream);

@@ -1,0 +1,24 @@
+// Launchers of the bandwidth-bound kernels (misc.hip).  All return hipError_t as int.
+#pragma once
+#include "common.h"
+
+struct LnSeg { const float* U; float* Y; float* stats; const float* gamma; const float* beta; int rows; };
+struct LnBwdSeg { const float* U; const float* dY; const float* stats; const float* gamma; float* dU;
+                  float* dgamma; float* dbeta; int rows; };
+// per-sample column means: rows of sample b are offs[b]..offs[b+1]-1, or b*uniform_n.. when offs == null
+struct SegMean { const float* X; int ld, C; const int* offs; int uniform_n; float* out; int ldo; };
+struct BcastSeg { const float* act; const float* v; int ldv; const int* row_sample; const float* inv_n;
+                  int uniform_n; float* dst; int rows; };
+
+int ln_supported(int H);
+int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int B, int max_nr, hipStream_t stream);
+int launch_ln_fwd(const LnSeg& s0, const LnSeg& s1, int H, hipStream_t stream);
+int launch_ln_bwd(const LnBwdSeg& s0, const LnBwdSeg& s1, int H, hipStream_t stream);
+int launch_seg_mean(const SegMean* segs, int nseg, int B, int max_rows, hipStream_t stream);
+int launch_relu_bcast_bwd(const BcastSeg& s0, const BcastSeg& s1, int C, float scale, hipStream_t stream);
+int launch_head_out_grad(const float* outs, const float* d_outs, float* d_logits, int B, int W, hipStream_t stream);
+int launch_loss(const float* outs, const long long* y, const float* e, const float* s, int B, int C,
+                float* terms, float* d_outs, int* pred, hipStream_t stream);
+int launch_sumsq(const float* g, size_t n, float* out, hipStream_t stream);
+int launch_clip_adamw(float* p, float* g, float* m, float* v, size_t n, const float* sumsq, float max_norm,
+                      float lr, float b1, float b2, float eps, float wd, int step, hipStream_t stream);

@@ -1,0 +1,237 @@
+"""Host-side engine: owns the flat parameter / gradient buffers, the workspace and the
+ctypes calls into ``libcamo_fusion.so``.  PyTorch is used for device memory, streams and
+autograd plumbing only; no arithmetic of the path happens in torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import torch
+
+from . import _lib
+
+# parameter slots in the order of include/camo_fusion.h (= the reference state_dict order)
+_HEADS = [f"{h}.{i}.{k}" for h in ("mask_head", "instance_head", "edge_head", "score_head")
+          for i, k in ((0, "weight"), (0, "bias"), (3, "weight"), (3, "bias"))]
+CROSS_SLOTS = (
+    ["fusion.rg_proj.weight", "fusion.rg_proj.bias", "fusion.kg_proj.weight", "fusion.kg_proj.bias"]
+    + [f"fusion.{a}.{k}" for a in ("cross_attn_rg2kg", "cross_attn_kg2rg")
+       for k in ("in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias")]
+    + ["fusion.ln_rg.weight", "fusion.ln_rg.bias", "fusion.ln_kg.weight", "fusion.ln_kg.bias"]
+    + [f"fusion.{f}.{i}.{k}" for f in ("ffn_rg", "ffn_kg", "fusion_layer") for i in (0, 3) for k in ("weight", "bias")]
+    + _HEADS)
+LATE_SLOTS = [f"fusion.fusion.{i}.{k}" for i in (0, 3, 6) for k in ("weight", "bias")] + _HEADS
+assert len(CROSS_SLOTS) == _lib.NPARAMS_CROSS and len(LATE_SLOTS) == _lib.NPARAMS_LATE
+
+_PREC = {"f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Batch:
+    """A packed minibatch on the device, ready for the C ABI."""
+    __slots__ = ("rg", "kg", "offsets", "nrs", "B", "T", "Nk", "max_nr")
+
+    def __init__(self, rg, kg, offsets, nrs):
+        self.rg, self.kg, self.offsets, self.nrs = rg, kg, offsets, nrs
+        self.B, self.T, self.Nk, self.max_nr = len(nrs), rg.shape[0], kg.shape[1], max(nrs)
+
+
+class FusionEngine:
+    def __init__(self, module):
+        self._mod = weakref.ref(module)
+        c = module.config
+        self.cross = c["fusion_type"] == "cross_attention"
+        self.slots = CROSS_SLOTS if self.cross else LATE_SLOTS
+        self.dims = _lib.CamoDims(c["rg_dim"], c["kg_dim"], c["hidden_dim"], c["num_heads"], c["num_classes"],
+                                  _lib.FUSION_CROSS_ATTENTION if self.cross else _lib.FUSION_LATE, c["dropout"])
+        self.out_width = 2 * c["num_classes"] + 2
+        self.flat_params = None
+        self.flat_grads = None
+        self._layout = None           # [(slot index, name, offset, numel, shape)]
+        self._ptab = None             # ctypes array of parameter pointers
+        self._gtab = None
+        self._offsets_cache = {}
+        self._ws = None
+        self._seed_base = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self._calls = 0
+        self.reflatten()
+
+    # ------------------------------------------------------------------ flat buffers
+    def module(self):
+        m = self._mod()
+        if m is None:
+            raise RuntimeError("model was garbage-collected")
+        return m
+
+    def reflatten(self):
+        """(Re)build the flat fp32 parameter buffer and point every nn.Parameter at its slice.
+        Called at construction and after every nn.Module._apply (.to(), .cuda(), ...)."""
+        mod = self.module()
+        named = dict(mod.named_parameters())
+        extra = set(named) - set(self.slots)
+        if extra:
+            raise RuntimeError(f"unexpected parameters {sorted(extra)}")
+        layout, off = [], 0
+        for i, name in enumerate(self.slots):
+            p = named.get(name)
+            if p is None:
+                continue                    # nn.Identity projection: slot stays NULL
+            layout.append((i, name, off, p.numel(), tuple(p.shape)))
+            off += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned
+        dev = next(iter(named.values())).device
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        for i, name, o, n, shape in layout:
+            p = named[name]
+            flat[o:o + n].copy_(p.data.reshape(-1).to(torch.float32))
+            p.data = flat[o:o + n].view(shape)
+            p.grad = None
+        self.flat_params, self._layout = flat, layout
+        self.flat_grads = None
+        self._ptab = self._gtab = None
+        self._ws = None
+        self._offsets_cache = {}
+        if dev.type == "cuda":
+            n = len(self.slots)
+            tab = (C.c_void_p * n)()
+            for i, name, o, cnt, shape in layout:
+                tab[i] = flat.data_ptr() + 4 * o
+            self._ptab = tab
+
+    def ensure_flat_grads(self, attach=True):
+        """Persistent flat gradient buffer (native training mode); ``param.grad`` become views of it."""
+        if self.flat_grads is None:
+            self.flat_grads = torch.zeros_like(self.flat_params)
+            self._gtab = self._grad_table(self.flat_grads)
+        if attach:
+            named = dict(self.module().named_parameters())
+            for i, name, o, n, shape in self._layout:
+                p = named[name]
+                if p.grad is None or p.grad.data_ptr() != self.flat_grads.data_ptr() + 4 * o:
+                    p.grad = self.flat_grads[o:o + n].view(shape)
+        return self.flat_grads
+
+    def _grad_table(self, gflat):
+        tab = (C.c_void_p * len(self.slots))()
+        for i, name, o, n, shape in self._layout:
+            tab[i] = gflat.data_ptr() + 4 * o
+        return tab
+
+    # ------------------------------------------------------------------ batches
+    def _require_ready(self):
+        _lib.lib()
+        _lib.require_device(self.flat_params, "model parameters")
+        if self._ptab is None:
+            self.reflatten()
+
+    def make_batch(self, rg_packed, nrs, kg):
+        """rg_packed [T, rg_dim], nrs: host ints, kg [B, Nk, kg_dim] -> Batch (device, fp32, contiguous)."""
+        self._require_ready()
+        _lib.require_device(rg_packed, "rg_embeddings")
+        _lib.require_device(kg, "kg_embeddings")
+        nrs = [int(n) for n in nrs]
+        B = len(nrs)
+        if B < 1 or min(nrs) < 1:
+            raise ValueError("every sample needs at least one RG node")
+        if rg_packed.dim() != 2 or rg_packed.shape[0] != sum(nrs) or rg_packed.shape[1] != self.dims.rg_dim:
+            raise RuntimeError(f"rg embeddings of shape {tuple(rg_packed.shape)} do not match {sum(nrs)} rows x rg_dim {self.dims.rg_dim}")
+        if kg.dim() != 3 or kg.shape[0] != B or kg.shape[2] != self.dims.kg_dim:
+            raise RuntimeError(f"kg embeddings of shape {tuple(kg.shape)} do not match batch {B} x kg_dim {self.dims.kg_dim}")
+        rg_packed = rg_packed.detach().to(torch.float32).contiguous()
+        kg = kg.detach().to(torch.float32).contiguous()
+        key = tuple(nrs)
+        offs = self._offsets_cache.get(key)
+        if offs is None:
+            if len(self._offsets_cache) > 4096:
+                self._offsets_cache.clear()
+            host = torch.zeros(B + 1, dtype=torch.int32)
+            host[1:] = torch.tensor(nrs, dtype=torch.int32).cumsum(0)
+            offs = host.to(rg_packed.device, non_blocking=False)
+            self._offsets_cache[key] = offs
+        return Batch(rg_packed, kg, offs, nrs)
+
+    def workspace(self, batch, private=False):
+        need = _lib.lib().camo_workspace_bytes(C.byref(self.dims), batch.B, batch.T, batch.Nk)
+        if need == 0:
+            _lib.check(-1, "camo_workspace_bytes")
+        if private:
+            return torch.empty(need, dtype=torch.uint8, device=batch.rg.device)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need * 1.25), dtype=torch.uint8, device=batch.rg.device)
+        return self._ws
+
+    def next_seed(self):
+        self._calls += 1
+        return (self._seed_base + 0x9E3779B97F4A7C15 * self._calls) & 0xFFFFFFFFFFFFFFFF
+
+    # ------------------------------------------------------------------ raw calls
+    def forward_raw(self, batch, ws, training, seed, want_attention=False, outs=None):
+        mod = self.module()
+        if outs is None:
+            outs = torch.empty(batch.B, self.out_width, dtype=torch.float32, device=batch.rg.device)
+        a1 = a2 = None
+        if want_attention and self.cross:
+            a1 = torch.empty(batch.T, batch.Nk, dtype=torch.float32, device=batch.rg.device)
+            a2 = torch.empty(batch.T, batch.Nk, dtype=torch.float32, device=batch.rg.device)
+        rc = _lib.lib().camo_forward(C.byref(self.dims), self._ptab, _ptr(batch.rg), _ptr(batch.offsets), _ptr(batch.kg),
+                                     batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs),
+                                     _ptr(a1), _ptr(a2), int(bool(training)), seed, _PREC[mod.precision], _stream_ptr())
+        _lib.check(rc, "camo_forward")
+        return outs, ((a1, a2) if a1 is not None else None)
+
+    def backward_raw(self, batch, ws, outs, d_outs, training, seed, gtab):
+        mod = self.module()
+        rc = _lib.lib().camo_backward(C.byref(self.dims), self._ptab, gtab, _ptr(batch.rg), _ptr(batch.offsets),
+                                      _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(),
+                                      _ptr(outs), _ptr(d_outs), int(bool(training)), seed, _PREC[mod.precision],
+                                      _stream_ptr())
+        _lib.check(rc, "camo_backward")
+
+    # ------------------------------------------------------------------ autograd (drop-in) mode
+    def forward_autograd(self, rg_packed, nrs, kg, want_attention=False):
+        mod = self.module()
+        batch = self.make_batch(rg_packed, nrs, kg)
+        named = dict(mod.named_parameters())
+        params = [named[name] for _, name, _, _, _ in self._layout]
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        seed = self.next_seed()
+        if not needs_grad:
+            return self.forward_raw(batch, self.workspace(batch), mod.training, seed, want_attention)
+        ws = self.workspace(batch, private=True)   # saved activations live until this call's backward
+        res = _FusionFn.apply(self, batch, ws, mod.training, seed, want_attention and self.cross, *params)
+        if want_attention and self.cross:
+            return res[0], (res[1], res[2])
+        return res, None
+
+
+class _FusionFn(torch.autograd.Function):
+    """Lets ``loss.backward()`` of an unmodified reference training loop drive camo_backward."""
+
+    @staticmethod
+    def forward(ctx, eng, batch, ws, training, seed, want_attention, *params):
+        outs, attn = eng.forward_raw(batch, ws, training, seed, want_attention)
+        ctx.eng, ctx.batch, ctx.ws, ctx.training, ctx.seed = eng, batch, ws, training, seed
+        ctx.save_for_backward(outs)
+        ctx.n_params = len(params)
+        if attn is not None:
+            ctx.mark_non_differentiable(*attn)
+            return outs, attn[0], attn[1]
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_outs, *_):
+        eng = ctx.eng
+        (outs,) = ctx.saved_tensors
+        g = torch.zeros_like(eng.flat_params)
+        eng.backward_raw(ctx.batch, ctx.ws, outs, d_outs.contiguous().to(torch.float32), ctx.training, ctx.seed,
+                         eng._grad_table(g))
+        ctx.ws = None
+        grads = [g[o:o + n].view(shape) for _, _, o, n, shape in eng._layout]
+        return (None, None, None, None, None, None, *grads)

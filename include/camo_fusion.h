@@ -1,0 +1,154 @@
+/*
+ * camo_fusion.h -- C ABI of the MI355X-native fusion hot path.
+ *
+ * The reference (rajan-dubey8/camouflage-multimodal) is pure Python and has no
+ * FFI of its own; its boundary for this path is a Python operator API.  Each
+ * entry point below states the reference interface it stands behind (paths
+ * relative to the reference root).  Host code (the .py files of camouflage_multimodal_amd)
+ * keeps that Python API and reaches these functions through ctypes with raw
+ * device pointers; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its comment says "host";
+ *    the caller (PyTorch-ROCm, or any HIP program) owns every buffer;
+ *  - all tensors are float32, row-major, contiguous; a batch is PACKED:
+ *    the RG rows of sample b are rows rg_offsets[b] .. rg_offsets[b+1]-1 of
+ *    one [T, rg_dim] matrix (variable Nr per sample, no padding), the KG rows
+ *    are [B*Nk, kg_dim];
+ *  - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*); no
+ *    allocation, no synchronisation, no global mutable state => graph-capturable
+ *    and thread-compatible;
+ *  - return value: 0 on success, a negative CAMO_E_* code otherwise; no C++
+ *    exception crosses the boundary; camo_last_error() gives a thread-local
+ *    message for the last failing call.
+ */
+#ifndef CAMO_FUSION_H
+#define CAMO_FUSION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAMO_ABI_VERSION 1
+
+enum {
+  CAMO_OK = 0,
+  CAMO_E_ARG = -1,         /* bad argument (null pointer, non-positive size ...)        */
+  CAMO_E_UNSUPPORTED = -2, /* configuration outside the kernels' envelope               */
+  CAMO_E_WORKSPACE = -3,   /* workspace too small                                        */
+  CAMO_E_HIP = -4          /* a HIP launch failed (message has hipGetErrorString)        */
+};
+
+enum { CAMO_FUSION_CROSS_ATTENTION = 0, CAMO_FUSION_LATE = 1 };
+enum { CAMO_PREC_F32 = 0,  /* f32-input MFMA: bit-faithful fp32 FMA chains            */
+       CAMO_PREC_BF16 = 1  /* bf16 MFMA operands, fp32 accumulate/activations         */ };
+
+/* Model dimensions = the keys build_multimodal_model() reads
+ * (models/multimodal/fusion_model.py:249-259). */
+typedef struct camo_dims {
+  int32_t rg_dim, kg_dim, hidden_dim, num_heads, num_classes;
+  int32_t fusion_type; /* CAMO_FUSION_* */
+  float dropout;
+} camo_dims_t;
+
+/* Parameter table: an array of CAMO_NPARAMS_* device pointers in the order of the
+ * reference module's state_dict (fusion_model.py:21-73, :151-162, :208-235).
+ * Slots of layers the configuration does not have (rg_proj/kg_proj when the
+ * input dim equals hidden_dim -> nn.Identity, fusion_model.py:29-30) are NULL.
+ * Gradient tables use the same indices. */
+enum {
+  CAMO_P_RG_PROJ_W = 0, CAMO_P_RG_PROJ_B, CAMO_P_KG_PROJ_W, CAMO_P_KG_PROJ_B,
+  CAMO_P_A1_IN_W, CAMO_P_A1_IN_B, CAMO_P_A1_OUT_W, CAMO_P_A1_OUT_B, /* cross_attn_rg2kg */
+  CAMO_P_A2_IN_W, CAMO_P_A2_IN_B, CAMO_P_A2_OUT_W, CAMO_P_A2_OUT_B, /* cross_attn_kg2rg */
+  CAMO_P_LN1_W, CAMO_P_LN1_B, CAMO_P_LN2_W, CAMO_P_LN2_B,           /* ln_rg, ln_kg      */
+  CAMO_P_F1_W0, CAMO_P_F1_B0, CAMO_P_F1_W3, CAMO_P_F1_B3,           /* ffn_rg.{0,3}      */
+  CAMO_P_F2_W0, CAMO_P_F2_B0, CAMO_P_F2_W3, CAMO_P_F2_B3,           /* ffn_kg.{0,3}      */
+  CAMO_P_FU_W0, CAMO_P_FU_B0, CAMO_P_FU_W3, CAMO_P_FU_B3,           /* fusion_layer      */
+  CAMO_P_HEADS = 28, /* 4 heads x {0.weight,0.bias,3.weight,3.bias}: mask, instance, edge, score */
+  CAMO_NPARAMS_CROSS = 44
+};
+enum {
+  CAMO_PL_W0 = 0, CAMO_PL_B0, CAMO_PL_W3, CAMO_PL_B3, CAMO_PL_W6, CAMO_PL_B6, /* LateFusion.fusion.{0,3,6} */
+  CAMO_PL_HEADS = 6,
+  CAMO_NPARAMS_LATE = 22
+};
+
+/* ---- sizes ------------------------------------------------------------- */
+int camo_abi_version(void);
+const char* camo_last_error(void);
+
+/* Bytes of workspace camo_forward/camo_backward need for a packed batch of B
+ * samples, T RG rows in total, Nk KG rows per sample.  The same workspace must
+ * be handed, unmodified, from camo_forward to the camo_backward of that batch:
+ * it holds the saved activations.  Returns 0 and sets the error on bad input. */
+size_t camo_workspace_bytes(const camo_dims_t* dims, int32_t B, int32_t T, int32_t Nk);
+
+/* ---- forward -------------------------------------------------------------
+ * Stands behind MultimodalCamouflageDetector.forward (fusion_model.py:237-246)
+ * = CrossAttentionFusion.forward (:75-146) or LateFusion.forward (:164-171)
+ * followed by the four heads, on inputs already normalised to 3-D
+ * (:86-105, done by the host).
+ *   rg          [T, rg_dim]           packed RG node embeddings
+ *   rg_offsets  int32 [B+1]           device; rg_offsets[0]=0, rg_offsets[B]=T, every Nr_b >= 1
+ *   kg          [B*Nk, kg_dim]
+ *   max_nr      host value: max_b Nr_b (grid sizing only)
+ *   outs        [B, 2*num_classes+2]  = mask logits | instance logits | edge logit | sigmoid(score)
+ *   attn_rg2kg  [T, Nk] or NULL       head-averaged attention, row t = RG node t
+ *   attn_kg2rg  [T, Nk] or NULL       TRANSPOSED head-averaged map: element (t, j) = weight of
+ *                                     KG query j on RG key t (host transposes per sample to [Nk, Nr])
+ *   training    0: eval (no dropout); 1: train, dropout p = dims->dropout with the
+ *               counter-based mask of (seed, site, element index)
+ */
+int camo_forward(const camo_dims_t* dims, const float* const* params,
+                 const float* rg, const int32_t* rg_offsets, const float* kg,
+                 int32_t B, int32_t T, int32_t Nk, int32_t max_nr,
+                 void* workspace, size_t workspace_bytes,
+                 float* outs, float* attn_rg2kg, float* attn_kg2rg,
+                 int32_t training, uint64_t seed, int32_t precision, void* stream);
+
+/* ---- backward ------------------------------------------------------------
+ * Stands behind loss.backward() through the model (train_multimodal.py:270):
+ * given d(loss)/d(outs) it ACCUMULATES (+=) parameter gradients into `grads`
+ * (the reference sums gradients over the samples of a minibatch,
+ * train_multimodal.py:239-279).  Inputs carry no gradient in the reference, so
+ * none is produced.  Arguments as camo_forward; `workspace` is the one that
+ * call filled. */
+int camo_backward(const camo_dims_t* dims, const float* const* params, float* const* grads,
+                  const float* rg, const int32_t* rg_offsets, const float* kg,
+                  int32_t B, int32_t T, int32_t Nk, int32_t max_nr,
+                  void* workspace, size_t workspace_bytes,
+                  const float* outs, const float* d_outs,
+                  int32_t training, uint64_t seed, int32_t precision, void* stream);
+
+/* ---- loss ----------------------------------------------------------------
+ * Per-sample loss of train_multimodal.py:256-268 --
+ *   3.0*AggressiveFocalLoss(alpha .75, gamma 3)(mask, y)  (:29-57)
+ * + 1.0*cross_entropy(instance, y) + 0.5*BCEWithLogits(edge, e) + 0.3*MSE(score, s)
+ * each evaluated at batch size 1 as the reference loop does, so the batch loss is
+ * the SUM over samples.  Writes loss_terms [B,4] (already weighted), d_outs
+ * [B, 2C+2] = d(sum of losses)/d(outs) and pred [B] = argmax(mask logits) (:273).
+ *   y int64 [B]; e, s float [B]. */
+int camo_loss(const float* outs, const int64_t* y, const float* e, const float* s,
+              int32_t B, int32_t num_classes,
+              float* loss_terms, float* d_outs, int32_t* pred, void* stream);
+
+/* ---- optimizer -----------------------------------------------------------
+ * clip_grad_norm_(params, 1.0) + AdamW.step (train_multimodal.py:278-279,
+ * :403-407) over flat buffers of n floats.
+ * camo_grad_sumsq: *sumsq = sum(g*g) (overwrites).  Between the two calls a
+ * data-parallel caller all-reduces g (SUM) -- see ddp.py.
+ * camo_clip_adamw: coef = min(1, max_norm/(sqrt(*sumsq)+1e-6)); g <- g*coef (in place, as
+ * the reference leaves clipped grads behind); decoupled weight decay; Adam moments;
+ * bias correction with `step` (1-based). */
+int camo_grad_sumsq(const float* g, size_t n, float* sumsq, void* stream);
+int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, const float* sumsq,
+                    float max_norm, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAMO_FUSION_H */

@@ -1,0 +1,291 @@
+"""HIP path vs the CPU oracle and the reference's golden vectors.  Needs an MI355X.
+
+Everything goes through the product's public surface (nn.Module / NativeTrainer), i.e. through
+the C ABI of libcamo_fusion.so.  Tolerances:
+  * precision 'f32' (v_mfma_f32_32x32x2_f32): logits within 2e-5 of the oracle -- well inside
+    north_star's 1e-3 -- gradients within 2e-4 relative to each tensor's RMS;
+  * precision 'bf16' (bf16 MFMA operands, fp32 accumulate): logits within 1e-3 (north_star's
+    bound), prediction agreement IoU >= 0.999 on the synthetic set, gradients within a few
+    percent (reported, loosely asserted).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import TRAIN_CASES, assert_close, assert_params_close, sub, train_batch, train_case
+from oracle import fusion_oracle as FO
+from oracle import params as OP
+
+pytestmark = pytest.mark.gpu
+
+OUT_KEYS = ("mask", "instance", "edge", "score")
+
+
+def make_model(cfg, seed, precision="f32"):
+    from camouflage_multimodal_amd import build_multimodal_model
+    from camouflage_multimodal_amd import _lib
+    assert _lib.lib() is not None
+    m = build_multimodal_model(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in OP.make_params(cfg, seed).items()}, strict=True)
+    return m.to("cuda").set_precision(precision)
+
+
+def outs6(o):
+    return np.concatenate([np.asarray(o[k]).reshape(len(o["mask"]), -1) for k in OUT_KEYS], axis=1)
+
+
+def t2n(t):
+    return t.detach().float().cpu().numpy()
+
+
+@pytest.mark.parametrize("nr", [303, 481, 500, 530])
+def test_eval_forward_golden_real_kg(nr, kg_real):
+    g = load_golden(f"eval_nr{nr}")
+    m = make_model(OP.full_cfg(), 0).eval()
+    rg = torch.from_numpy(OP.make_rg(nr, 128, seed=nr))[None].cuda()
+    kg = torch.from_numpy(kg_real)[None, :, None, :].cuda()          # the 4-D layout real data arrives in
+    with torch.no_grad():
+        mo, io, eo, so, attn = m(rg, kg, return_attention=True)
+    for k, v in zip(OUT_KEYS, (mo, io, eo, so)):
+        assert v.shape == g[k].shape
+        assert_close(t2n(v), g[k], 2e-5, 1e-5, k)
+    assert attn["rg2kg"].shape == (1, nr, 13) and attn["kg2rg"].shape == (1, 13, nr)
+    assert_close(t2n(attn["rg2kg"]), g["attn_rg2kg"], 2e-6, 1e-4, "attn rg2kg")
+    assert_close(t2n(attn["kg2rg"]), g["attn_kg2rg"], 2e-7, 1e-4, "attn kg2rg")
+
+
+def test_eval_selftest_shape_and_input_layouts():
+    m = make_model(OP.full_cfg(), 0).eval()
+    g = load_golden("eval_selftest_b4")
+    rg = np.stack([OP.make_rg(500, 128, seed=40 + b, kind="randn") for b in range(4)])
+    kg = np.stack([OP.make_rg(10, 128, seed=50 + b, kind="randn") for b in range(4)])
+    with torch.no_grad():
+        o = m(torch.from_numpy(rg).cuda(), torch.from_numpy(kg).cuda(), return_attention=True)
+    for k, v in zip(OUT_KEYS, o[:4]):
+        assert_close(t2n(v), g[k], 5e-5, 1e-5, k)
+    assert_close(sub(t2n(o[4]["rg2kg"])), g["attn_rg2kg_sub"], 2e-6, 2e-4, "attn rg2kg")
+    assert_close(sub(t2n(o[4]["kg2rg"].contiguous())), g["attn_kg2rg_sub"], 2e-7, 2e-4, "attn kg2rg")
+    # 2-D and 4-D inputs (fusion_model.py:86-105), 5-D raises the reference's ValueError
+    g2, g4 = load_golden("eval_2d"), load_golden("eval_4d")
+    rg4 = np.stack([OP.make_rg(12, 128, seed=62 + b) for b in range(2)]).reshape(2, 3, 4, 128)
+    kg4 = np.stack([OP.make_kg(5, 128, seed=64 + b) for b in range(2)]).reshape(2, 1, 5, 128)
+    with torch.no_grad():
+        o2 = m(torch.from_numpy(OP.make_rg(6, 128, seed=60)).cuda(), torch.from_numpy(OP.make_kg(6, 128, seed=61)).cuda())
+        o4 = m(torch.from_numpy(rg4).cuda(), torch.from_numpy(kg4).cuda())
+    for k, a, b in zip(OUT_KEYS, o2, o4):
+        assert_close(t2n(a), g2[k], 2e-5, 1e-5, "2d " + k)
+        assert_close(t2n(b), g4[k], 2e-5, 1e-5, "4d " + k)
+    with pytest.raises(ValueError, match="must be 2D/3D/4D tensor"):
+        m(torch.zeros(1, 1, 1, 2, 128).cuda(), torch.zeros(1, 128).cuda())
+
+
+def _native_replay(name, precision="f32", steps=2):
+    """Replays the golden optimizer steps with the native trainer; checks outs, loss terms,
+    raw gradients (vs the oracle run in lock-step) and post-step parameters (vs golden)."""
+    from camouflage_multimodal_amd import NativeTrainer
+    cfg, seed, nrs, nk, kg_fixed, full = train_case(name)
+    m = make_model(cfg, seed, precision).train()
+    tr = NativeTrainer(m, lr=5e-4, weight_decay=1e-4)
+    orc = FO.FusionOracle(cfg, OP.make_params(cfg, seed))
+    oopt = FO.AdamW(orc.p, lr=5e-4, weight_decay=1e-4)
+    real = {}
+    for st in range(steps):
+        g = load_golden(f"train_{name}_step{st}")
+        rg, kg, y, e, s = train_batch(cfg, seed, nrs, nk, kg_fixed, st)
+        ref = FO.train_step(orc, oopt, rg, kg, y, e, s, training=True, seed=0)
+        terms, pred = tr.step(torch.from_numpy(np.concatenate(rg)).cuda(), list(nrs), torch.from_numpy(kg).cuda(),
+                              torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s))
+        assert_close(t2n(terms), g["loss_terms"], 2e-5, 1e-4, f"{name} step{st} loss terms")
+        assert_close(t2n(tr.opt.grad_norm())[0], g["grad_norm"], 0, 2e-4, f"{name} step{st} grad norm")
+        assert (t2n(pred) == outs6(ref["outs"])[:, :cfg["num_classes"]].argmax(1)).all()
+        # clipped gradients left behind in .grad, like clip_grad_norm_ does
+        coef = min(1.0, 1.0 / (float(g["grad_norm"]) + 1e-6))
+        named = dict(m.named_parameters())
+        tr.engine.ensure_flat_grads(attach=True)
+        for k, _ in OP.param_specs(cfg):
+            got = t2n(named[k].grad) / coef
+            want = ref["raw_grads"][k]
+            rms = float(np.sqrt((want.astype(np.float64) ** 2).mean()))
+            assert_close(got, want, 3e-4 * rms + 2e-7, 3e-4, f"{name} step{st} grad {k}")
+            real[k] = (np.abs(g[f"g/{k}"]) >= 1e-6) & real.get(k, True)
+            p = t2n(named[k])
+            assert_params_close(p if full else sub(p), g[f"p/{k}"], 5e-4 * (st + 1), real[k], f"{name} step{st} param {k}")
+
+
+def test_native_train_steps_default_config_golden():
+    _native_replay("default")
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_native_train_steps_small_configs_golden(name):
+    _native_replay(name)
+
+
+def test_dropin_autograd_loop_matches_golden():
+    """The reference's own training loop shape (train_multimodal.py:238-279): per-sample B=1
+    forward, torch loss functions, loss.backward(), clip_grad_norm_, torch AdamW -- with only
+    the model swapped for the HIP one."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from camouflage_multimodal_amd import AggressiveFocalLoss
+    cfg, seed, nrs, nk, kg_fixed, full = train_case("default")
+    m = make_model(cfg, seed).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=5e-4, weight_decay=1e-4)
+    focal, bce, mse = AggressiveFocalLoss(0.75, 3.0), nn.BCEWithLogitsLoss(), nn.MSELoss()
+    real = {}
+    for st in range(2):
+        g = load_golden(f"train_default_step{st}")
+        rg, kg, y, e, s = train_batch(cfg, seed, nrs, nk, kg_fixed, st)
+        opt.zero_grad()
+        for b in range(len(nrs)):
+            yl = torch.tensor([int(y[b])]).cuda(); el = torch.tensor([float(e[b])]).cuda(); sl = torch.tensor([float(s[b])]).cuda()
+            mo, io, eo, so = m(torch.from_numpy(rg[b])[None].cuda(), torch.from_numpy(kg[b])[None, :, None, :].cuda())
+            loss = focal(mo, yl) * 3.0 + F.cross_entropy(io, yl) + bce(eo.squeeze(1), el) * 0.5 + mse(so.squeeze(1), sl) * 0.3
+            loss.backward()
+            assert_close(np.concatenate([t2n(mo)[0], t2n(io)[0], t2n(eo)[0], t2n(so)[0]]), g["outs"][b], 2e-5, 1e-5, "outs")
+        norm = float(torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1.0))
+        assert_close(norm, g["grad_norm"], 0, 2e-4, "grad norm")
+        opt.step()
+        for k, p in m.named_parameters():
+            real[k] = (np.abs(g[f"g/{k}"]) >= 1e-6) & real.get(k, True)
+            assert_params_close(sub(t2n(p)), g[f"p/{k}"], 5e-4 * (st + 1), real[k], f"dropin step{st} param {k}")
+
+
+@pytest.mark.parametrize("name", ["default", "small_a", "late"])
+def test_train_mode_dropout_matches_oracle_masks(name):
+    """dropout>0, train mode: the kernels regenerate the oracle's counter-hash masks, so outputs
+    and gradients are comparable element for element."""
+    from camouflage_multimodal_amd import NativeTrainer
+    cfg, seed, nrs, nk, kg_fixed, _ = train_case(name)
+    cfg = dict(cfg, dropout=0.3)
+    m = make_model(cfg, seed).train()
+    tr = NativeTrainer(m)
+    orc = FO.FusionOracle(cfg, OP.make_params(cfg, seed))
+    rg, kg, y, e, s = train_batch(cfg, seed, nrs, nk, kg_fixed, 0)
+    dseed = 0x0123456789ABCDEF
+    ref = FO.train_step(orc, FO.AdamW(orc.p), rg, kg, y, e, s, training=True, seed=dseed)
+    terms, _ = tr.step(torch.from_numpy(np.concatenate(rg)).cuda(), list(nrs), torch.from_numpy(kg).cuda(),
+                       torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s), seed=dseed)
+    assert_close(t2n(terms), ref["loss_terms"], 3e-5, 2e-4, "loss terms under dropout")
+    coef = min(1.0, 1.0 / (float(ref["grad_norm"]) + 1e-6))
+    tr.engine.ensure_flat_grads(attach=True)
+    for k, p in m.named_parameters():
+        want = ref["raw_grads"][k]
+        rms = float(np.sqrt((want.astype(np.float64) ** 2).mean()))
+        assert_close(t2n(p.grad) / coef, want, 5e-4 * rms + 2e-7, 5e-4, f"dropout grad {k}")
+    # a different seed must give a different loss (the masks really are applied)
+    m2 = make_model(cfg, seed).train()
+    t2, _ = NativeTrainer(m2).step(torch.from_numpy(np.concatenate(rg)).cuda(), list(nrs), torch.from_numpy(kg).cuda(),
+                                   torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s), seed=dseed + 1)
+    assert np.abs(t2n(t2) - t2n(terms)).max() > 1e-4
+
+
+def test_edge_shapes_vs_oracle():
+    """Nr=1, Nk=1, Nk=16/17 (register-array dispatch boundary), odd dims, many heads."""
+    small = [((1, 2, 70), 1), ((5, 64, 65), 16), ((3, 130), 17)]
+    cases = [(dict(rg_dim=20, kg_dim=12, hidden_dim=32, num_heads=4), small + [((257,), 64)]),
+             (dict(rg_dim=128, kg_dim=128, hidden_dim=256, num_heads=8), small + [((40, 9), 64)]),
+             (dict(rg_dim=64, kg_dim=64, hidden_dim=64, num_heads=64), small),
+             (dict(rg_dim=8, kg_dim=8, hidden_dim=512, num_heads=8), small)]
+    for ci, (c, shapes) in enumerate(cases):
+        cfg = OP.full_cfg(dict(c, dropout=0.0))
+        m = make_model(cfg, 11 + ci).eval()
+        orc = FO.FusionOracle(cfg, OP.make_params(cfg, 11 + ci))
+        for nrs, nk in shapes:
+            rg = [OP.make_rg(n, cfg["rg_dim"], seed=i + 7, kind="randn") for i, n in enumerate(nrs)]
+            kg = np.stack([OP.make_kg(nk, cfg["kg_dim"], seed=90 + i) for i in range(len(nrs))])
+            ref, _ = orc.forward_list(rg, kg)
+            with torch.no_grad():
+                o = m.forward_packed(torch.from_numpy(np.concatenate(rg)).cuda(), list(nrs), torch.from_numpy(kg).cuda(),
+                                     return_attention=True)
+            got = np.concatenate([t2n(v) for v in o[:4]], axis=1)
+            assert_close(got, outs6(ref), 5e-5, 1e-4, f"cfg{ci} nrs={nrs} nk={nk}")
+            for b in range(len(nrs)):
+                assert_close(t2n(o[4]["rg2kg"][b]), ref["attn_rg2kg"][b], 2e-6, 2e-4, "attn rg2kg")
+                assert_close(t2n(o[4]["kg2rg"][b]), ref["attn_kg2rg"][b], 2e-6, 2e-4, "attn kg2rg")
+
+
+def test_full_size_properties_b16(kg_real):
+    """BASELINE config size (B=16, real Nr spread): packed batch == 16 x (B=1); logits invariant
+    to KG-row and RG-row permutations; attention rows sum to 1."""
+    h = load_golden("nr_histogram")
+    rs = np.random.RandomState(0)
+    nrs = [int(x) for x in rs.choice(h["values"], size=16, p=h["counts"] / h["counts"].sum())]
+    m = make_model(OP.full_cfg(), 0).eval()
+    rg = [OP.make_rg(n, 128, seed=200 + i) for i, n in enumerate(nrs)]
+    kg = np.stack([kg_real] * 16)
+    with torch.no_grad():
+        o = m.forward_packed(torch.from_numpy(np.concatenate(rg)).cuda(), nrs, torch.from_numpy(kg).cuda(), return_attention=True)
+        packed = np.concatenate([t2n(v) for v in o[:4]], axis=1)
+        singles = []
+        for b in range(16):
+            ob = m(torch.from_numpy(rg[b])[None].cuda(), torch.from_numpy(kg_real)[None].cuda())
+            singles.append(np.concatenate([t2n(v) for v in ob], axis=1)[0])
+        assert_close(packed, np.stack(singles), 2e-6, 0, "packed vs singles")
+        perm_k = rs.permutation(13)
+        rgp = [r[rs.permutation(len(r))] for r in rg]
+        o2 = m.forward_packed(torch.from_numpy(np.concatenate(rgp)).cuda(), nrs, torch.from_numpy(kg[:, perm_k]).cuda())
+        assert_close(np.concatenate([t2n(v) for v in o2], axis=1), packed, 5e-6, 0, "permutation invariance")
+    for b in range(16):
+        assert_close(t2n(o[4]["rg2kg"][b]).sum(1), np.ones(nrs[b]), 1e-5, 0, "rg2kg rows sum to 1")
+        assert_close(t2n(o[4]["kg2rg"][b]).sum(1), np.ones(13), 1e-5, 0, "kg2rg rows sum to 1")
+    orc = FO.FusionOracle(OP.full_cfg(), OP.make_params(OP.full_cfg(), 0))
+    ref, _ = orc.forward_list(rg[:4], kg[:4])
+    assert_close(packed[:4], outs6(ref), 2e-5, 1e-5, "first four samples vs oracle")
+
+
+def test_bf16_mode_within_north_star_tolerance(kg_real):
+    """bf16 MFMA operands: logits within 1e-3 of the fp32 oracle and prediction-agreement IoU
+    >= 0.999 (utils/metrics.py:9-18's IoU formula on arg-max vectors) over a 64-sample synthetic set."""
+    cfg = OP.full_cfg()
+    m = make_model(cfg, 0, "bf16").eval()
+    orc = FO.FusionOracle(cfg, OP.make_params(cfg, 0))
+    h = load_golden("nr_histogram")
+    rs = np.random.RandomState(1)
+    nrs = [int(x) for x in rs.choice(h["values"], size=64, p=h["counts"] / h["counts"].sum())]
+    rg = [OP.make_rg(n, 128, seed=300 + i) for i, n in enumerate(nrs)]
+    kg = np.stack([kg_real] * 64)
+    ref, _ = orc.forward_list(rg, kg)
+    with torch.no_grad():
+        o = m.forward_packed(torch.from_numpy(np.concatenate(rg)).cuda(), nrs, torch.from_numpy(kg).cuda())
+    got = np.concatenate([t2n(v) for v in o], axis=1)
+    err = np.abs(got - outs6(ref)).max()
+    print("bf16 max |logit err| =", err)
+    assert err < 1e-3
+    pa, pb = got[:, :2].argmax(1), outs6(ref)[:, :2].argmax(1)
+    inter = float(((pa == 1) & (pb == 1)).sum()); union = float(((pa == 1) | (pb == 1)).sum())
+    assert (inter + 1e-8) / (union + 1e-8) >= 0.999
+
+
+def test_bf16_training_step_close_to_oracle():
+    from camouflage_multimodal_amd import NativeTrainer
+    cfg, seed, nrs, nk, kg_fixed, _ = train_case("default")
+    m = make_model(cfg, seed, "bf16").train()
+    tr = NativeTrainer(m)
+    orc = FO.FusionOracle(cfg, OP.make_params(cfg, seed))
+    rg, kg, y, e, s = train_batch(cfg, seed, nrs, nk, kg_fixed, 0)
+    ref = FO.train_step(orc, FO.AdamW(orc.p), rg, kg, y, e, s, training=True)
+    terms, _ = tr.step(torch.from_numpy(np.concatenate(rg)).cuda(), list(nrs), torch.from_numpy(kg).cuda(),
+                       torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s))
+    assert_close(t2n(terms), ref["loss_terms"], 2e-3, 2e-3, "bf16 loss terms")
+    assert_close(t2n(tr.opt.grad_norm())[0], ref["grad_norm"], 0, 2e-2, "bf16 grad norm")
+    coef = min(1.0, 1.0 / (float(ref["grad_norm"]) + 1e-6))
+    tr.engine.ensure_flat_grads(attach=True)
+    worst = 0.0
+    for k, p in m.named_parameters():
+        want = ref["raw_grads"][k].astype(np.float64); got = t2n(p.grad).astype(np.float64) / coef
+        rel = np.sqrt(((got - want) ** 2).sum()) / max(np.sqrt((want ** 2).sum()), 1e-12)
+        if np.sqrt((want ** 2).sum()) > 1e-6:
+            worst = max(worst, rel)
+    print("bf16 worst per-tensor relative gradient error =", worst)
+    assert worst < 3e-2
+
+
+def test_product_path_loaded_native_library():
+    import ctypes
+    from camouflage_multimodal_amd import _lib
+    L = _lib.lib()
+    assert isinstance(L, ctypes.CDLL) and L.camo_abi_version() == _lib.ABI_VERSION
+    with open("/proc/self/maps") as f:
+        assert "libcamo_fusion.so" in f.read()
