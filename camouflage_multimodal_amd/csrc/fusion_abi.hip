@@ -138,6 +138,7 @@ struct GB {
   GB(const DropCfg& d, int prec_, hipStream_t st_) : prec(prec_), st(st_) { std::memset(&b, 0, sizeof(b)); b.drop = d; }
   GemmProb& add(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K, int flags) {
     GemmProb& p = b.p[b.n++];
+    std::memset(&p, 0, sizeof(p));   // slots are reused across launches: no stale res/bias_grad/flags
     p.A = A; p.lda = lda; p.B = Bm; p.ldb = ldb; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.flags = flags;
     p.aux_scale = 1.f;
     return p;
@@ -176,8 +177,11 @@ void set_bcast(GemmProb& p, const float* v, int ldv, const int* row_sample, cons
 }
 
 // ---- the four heads (fusion_model.py:208-235), shared by both fusion types -------------------
+// The per-sample ("tail") GEMMs have M = B rows and a negligible FLOP share, so they always run
+// on the exact f32 MFMA; `precision` selects the MFMA type of the node-level (T-row) GEMMs only.
 int heads_forward(const camo_dims_t& d, const float* const* hp /*16 pointers*/, const Ws& w, int B, int F,
-                  float* outs, const DropCfg& drop, int prec, hipStream_t st) {
+                  float* outs, const DropCfg& drop, hipStream_t st) {
+  const int prec = CAMO_PREC_F32;
   const int Fh = F / 2, C = d.num_classes, Wd = 2 * C + 2;
   const int nout[4] = {C, C, 1, 1}, coff[4] = {0, C, 2 * C, 2 * C + 1};
   GB g(drop, prec, st);
@@ -194,7 +198,8 @@ int heads_forward(const camo_dims_t& d, const float* const* hp /*16 pointers*/, 
 
 // d_outs -> dfused (w.dfused, zeroed here) and the 16 head-parameter gradients
 int heads_backward(const camo_dims_t& d, const float* const* hp, float* const* hg, const Ws& w, int B, int F,
-                   const float* outs, const float* d_outs, const DropCfg& drop, int prec, hipStream_t st) {
+                   const float* outs, const float* d_outs, const DropCfg& drop, hipStream_t st) {
+  const int prec = CAMO_PREC_F32;
   const int Fh = F / 2, C = d.num_classes, Wd = 2 * C + 2;
   const int nout[4] = {C, C, 1, 1}, coff[4] = {0, C, 2 * C, 2 * C + 1};
   CK((int)hipMemsetAsync(w.dfused, 0, sizeof(float) * (size_t)B * F, st), "memset dfused");
@@ -242,6 +247,7 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
   const int H = d.hidden_dim, D = d.rg_dim, Dk = d.kg_dim, TK = B * Nk, nh = d.num_heads;
   const float* const* P = params;
   GB g(drop, precision, st);
+  GB gt(drop, CAMO_PREC_F32, st);   // per-sample (B-row) GEMMs
 
   if (d.fusion_type == CAMO_FUSION_LATE) {
     // LateFusion.forward, fusion_model.py:164-171
@@ -249,13 +255,13 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
     CK((int)hipMemsetAsync(w.means, 0, sizeof(float) * w.means_n, st), "memset means");
     SegMean sm[2] = {{rg, D, D, rg_offsets, 0, w.comb, Dc}, {kg, Dk, Dk, nullptr, Nk, w.comb + D, Dc}};
     CK(launch_seg_mean(sm, 2, B, max_nr > Nk ? max_nr : Nk, st), "late means");
-    set_drop(g.nt(w.comb, Dc, P[CAMO_PL_W0], Dc, P[CAMO_PL_B0], w.F1, H, B, H, Dc, GF_RELU), SITE_LATE0);
-    CK(g.run(), "late fc0");
-    set_drop(g.nt(w.F1, H, P[CAMO_PL_W3], H, P[CAMO_PL_B3], w.a2, F, B, F, H, GF_RELU), SITE_LATE0 + 1);
-    CK(g.run(), "late fc3");
-    g.nt(w.a2, F, P[CAMO_PL_W6], F, P[CAMO_PL_B6], w.fused, F, B, F, F);
-    CK(g.run(), "late fc6");
-    return heads_forward(d, P + CAMO_PL_HEADS, w, B, F, outs, drop, precision, st);
+    set_drop(gt.nt(w.comb, Dc, P[CAMO_PL_W0], Dc, P[CAMO_PL_B0], w.F1, H, B, H, Dc, GF_RELU), SITE_LATE0);
+    CK(gt.run(), "late fc0");
+    set_drop(gt.nt(w.F1, H, P[CAMO_PL_W3], H, P[CAMO_PL_B3], w.a2, F, B, F, H, GF_RELU), SITE_LATE0 + 1);
+    CK(gt.run(), "late fc3");
+    gt.nt(w.a2, F, P[CAMO_PL_W6], F, P[CAMO_PL_B6], w.fused, F, B, F, F);
+    CK(gt.run(), "late fc6");
+    return heads_forward(d, P + CAMO_PL_HEADS, w, B, F, outs, drop, st);
   }
 
   // ---- CrossAttentionFusion.forward, fusion_model.py:75-146
@@ -295,15 +301,15 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
                      {w.Y2, H, H, nullptr, Nk, w.Y2mean, H}, {w.H2, 2 * H, 2 * H, nullptr, Nk, w.H2mean, 2 * H}};
     CK(launch_seg_mean(sm, 4, B, max_nr > Nk ? max_nr : Nk, st), "pool");
   }
-  set_res(g.nt(w.H1mean, 2 * H, P[CAMO_P_F1_W3], 2 * H, P[CAMO_P_F1_B3], w.comb, 2 * H, B, H, 2 * H), w.Ymean, H);
-  set_res(g.nt(w.H2mean, 2 * H, P[CAMO_P_F2_W3], 2 * H, P[CAMO_P_F2_B3], w.comb + H, 2 * H, B, H, 2 * H), w.Y2mean, H);
-  CK(g.run(), "ffn layer 3 on pooled rows");
+  set_res(gt.nt(w.H1mean, 2 * H, P[CAMO_P_F1_W3], 2 * H, P[CAMO_P_F1_B3], w.comb, 2 * H, B, H, 2 * H), w.Ymean, H);
+  set_res(gt.nt(w.H2mean, 2 * H, P[CAMO_P_F2_W3], 2 * H, P[CAMO_P_F2_B3], w.comb + H, 2 * H, B, H, 2 * H), w.Y2mean, H);
+  CK(gt.run(), "ffn layer 3 on pooled rows");
   // fusion layer (fusion_model.py:68-73,138-139)
-  set_drop(g.nt(w.comb, 2 * H, P[CAMO_P_FU_W0], 2 * H, P[CAMO_P_FU_B0], w.F1, H, B, H, 2 * H, GF_RELU), SITE_FUSE);
-  CK(g.run(), "fusion layer 0");
-  g.nt(w.F1, H, P[CAMO_P_FU_W3], H, P[CAMO_P_FU_B3], w.fused, H, B, H, H);
-  CK(g.run(), "fusion layer 3");
-  return heads_forward(d, P + CAMO_P_HEADS, w, B, H, outs, drop, precision, st);
+  set_drop(gt.nt(w.comb, 2 * H, P[CAMO_P_FU_W0], 2 * H, P[CAMO_P_FU_B0], w.F1, H, B, H, 2 * H, GF_RELU), SITE_FUSE);
+  CK(gt.run(), "fusion layer 0");
+  gt.nt(w.F1, H, P[CAMO_P_FU_W3], H, P[CAMO_P_FU_B3], w.fused, H, B, H, H);
+  CK(gt.run(), "fusion layer 3");
+  return heads_forward(d, P + CAMO_P_HEADS, w, B, H, outs, drop, st);
 }
 
 int camo_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
@@ -324,39 +330,40 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
   const float* const* P = params;
   float* const* Gr = grads;
   GB g(drop, precision, st);
+  GB gt(drop, CAMO_PREC_F32, st);   // per-sample (B-row) GEMMs
 
   if (d.fusion_type == CAMO_FUSION_LATE) {
     const int F = H / 2, Dc = D + Dk;
-    if (int e = heads_backward(d, P + CAMO_PL_HEADS, Gr + CAMO_PL_HEADS, w, B, F, outs, d_outs, drop, precision, st)) return e;
-    set_relu_bwd(g.nn(w.dfused, F, P[CAMO_PL_W6], F, w.da2, F, B, F, F), w.a2, F, drop.scale);
-    g.tn(w.dfused, F, w.a2, F, Gr[CAMO_PL_W6], F, Gr[CAMO_PL_B6], F, F, B);
-    CK(g.run(), "late fc6 bwd");
-    set_relu_bwd(g.nn(w.da2, F, P[CAMO_PL_W3], H, w.dF1, H, B, H, F), w.F1, H, drop.scale);
-    g.tn(w.da2, F, w.F1, H, Gr[CAMO_PL_W3], H, Gr[CAMO_PL_B3], F, H, B);
-    CK(g.run(), "late fc3 bwd");
-    g.tn(w.dF1, H, w.comb, Dc, Gr[CAMO_PL_W0], Dc, Gr[CAMO_PL_B0], H, Dc, B);
-    CK(g.run(), "late fc0 bwd");
+    if (int e = heads_backward(d, P + CAMO_PL_HEADS, Gr + CAMO_PL_HEADS, w, B, F, outs, d_outs, drop, st)) return e;
+    set_relu_bwd(gt.nn(w.dfused, F, P[CAMO_PL_W6], F, w.da2, F, B, F, F), w.a2, F, drop.scale);
+    gt.tn(w.dfused, F, w.a2, F, Gr[CAMO_PL_W6], F, Gr[CAMO_PL_B6], F, F, B);
+    CK(gt.run(), "late fc6 bwd");
+    set_relu_bwd(gt.nn(w.da2, F, P[CAMO_PL_W3], H, w.dF1, H, B, H, F), w.F1, H, drop.scale);
+    gt.tn(w.da2, F, w.F1, H, Gr[CAMO_PL_W3], H, Gr[CAMO_PL_B3], F, H, B);
+    CK(gt.run(), "late fc3 bwd");
+    gt.tn(w.dF1, H, w.comb, Dc, Gr[CAMO_PL_W0], Dc, Gr[CAMO_PL_B0], H, Dc, B);
+    CK(gt.run(), "late fc0 bwd");
     return 0;
   }
 
   const bool has_rgp = P[CAMO_P_RG_PROJ_W] != nullptr, has_kgp = P[CAMO_P_KG_PROJ_W] != nullptr;
   const float* R = has_rgp ? w.R : rg;
   const float* G = has_kgp ? w.G : kg;
-  if (int e = heads_backward(d, P + CAMO_P_HEADS, Gr + CAMO_P_HEADS, w, B, H, outs, d_outs, drop, precision, st)) return e;
+  if (int e = heads_backward(d, P + CAMO_P_HEADS, Gr + CAMO_P_HEADS, w, B, H, outs, d_outs, drop, st)) return e;
   CK((int)hipMemsetAsync(w.dKV, 0, sizeof(float) * (size_t)TK * 2 * H, st), "memset dKV");
   // fusion layer
-  set_relu_bwd(g.nn(w.dfused, H, P[CAMO_P_FU_W3], H, w.dF1, H, B, H, H), w.F1, H, drop.scale);
-  g.tn(w.dfused, H, w.F1, H, Gr[CAMO_P_FU_W3], H, Gr[CAMO_P_FU_B3], H, H, B);
-  CK(g.run(), "fusion layer 3 bwd");
-  g.nn(w.dF1, H, P[CAMO_P_FU_W0], 2 * H, w.dcomb, 2 * H, B, 2 * H, H);
-  g.tn(w.dF1, H, w.comb, 2 * H, Gr[CAMO_P_FU_W0], 2 * H, Gr[CAMO_P_FU_B0], H, 2 * H, B);
-  CK(g.run(), "fusion layer 0 bwd");
+  set_relu_bwd(gt.nn(w.dfused, H, P[CAMO_P_FU_W3], H, w.dF1, H, B, H, H), w.F1, H, drop.scale);
+  gt.tn(w.dfused, H, w.F1, H, Gr[CAMO_P_FU_W3], H, Gr[CAMO_P_FU_B3], H, H, B);
+  CK(gt.run(), "fusion layer 3 bwd");
+  gt.nn(w.dF1, H, P[CAMO_P_FU_W0], 2 * H, w.dcomb, 2 * H, B, 2 * H, H);
+  gt.tn(w.dF1, H, w.comb, 2 * H, Gr[CAMO_P_FU_W0], 2 * H, Gr[CAMO_P_FU_B0], H, 2 * H, B);
+  CK(gt.run(), "fusion layer 0 bwd");
   // pooled second FFN layer: d(mean H1d) = dpool.W2 ; dW2 += dpool^T.mean(H1d) ; db2 += sum_b dpool
-  g.nn(w.dcomb, 2 * H, P[CAMO_P_F1_W3], 2 * H, w.dHm1, 2 * H, B, 2 * H, H);
-  g.nn(w.dcomb + H, 2 * H, P[CAMO_P_F2_W3], 2 * H, w.dHm2, 2 * H, B, 2 * H, H);
-  g.tn(w.dcomb, 2 * H, w.H1mean, 2 * H, Gr[CAMO_P_F1_W3], 2 * H, Gr[CAMO_P_F1_B3], H, 2 * H, B);
-  g.tn(w.dcomb + H, 2 * H, w.H2mean, 2 * H, Gr[CAMO_P_F2_W3], 2 * H, Gr[CAMO_P_F2_B3], H, 2 * H, B);
-  CK(g.run(), "ffn layer 3 bwd (pooled)");
+  gt.nn(w.dcomb, 2 * H, P[CAMO_P_F1_W3], 2 * H, w.dHm1, 2 * H, B, 2 * H, H);
+  gt.nn(w.dcomb + H, 2 * H, P[CAMO_P_F2_W3], 2 * H, w.dHm2, 2 * H, B, 2 * H, H);
+  gt.tn(w.dcomb, 2 * H, w.H1mean, 2 * H, Gr[CAMO_P_F1_W3], 2 * H, Gr[CAMO_P_F1_B3], H, 2 * H, B);
+  gt.tn(w.dcomb + H, 2 * H, w.H2mean, 2 * H, Gr[CAMO_P_F2_W3], 2 * H, Gr[CAMO_P_F2_B3], H, 2 * H, B);
+  CK(gt.run(), "ffn layer 3 bwd (pooled)");
   {
     BcastSeg s0{w.H1, w.dHm1, 2 * H, w.row_sample, w.inv_nr, 0, w.dH1, T};
     BcastSeg s1{w.H2, w.dHm2, 2 * H, nullptr, nullptr, Nk, w.dH2, TK};
@@ -421,6 +428,42 @@ int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, const floa
   CK(launch_clip_adamw(p, g, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step,
                        static_cast<hipStream_t>(stream)), "clip+adamw");
   return 0;
+}
+
+int camo_debug_gemm(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias,
+                    const float* res, int32_t ldr, float* bias_grad, int32_t M, int32_t N, int32_t K, int32_t flags,
+                    int32_t precision, void* stream) {
+  if (!A || !B || !C || M < 1 || N < 1 || K < 1) return fail(CAMO_E_ARG, "bad gemm arguments");
+  GB g(make_drop(0, 0.f, 0), precision, static_cast<hipStream_t>(stream));
+  GemmProb& p = g.add(A, lda, B, ldb, C, ldc, M, N, K, flags);
+  p.bias = bias; p.res = res; p.ldr = ldr; p.bias_grad = bias_grad;
+  CK(g.run(), "debug gemm");
+  return 0;
+}
+
+int camo_prof_begin(int32_t max_launches) {
+  CK(gemm_prof_begin(max_launches), "prof begin");
+  return 0;
+}
+
+int camo_prof_end(double* gemm_ms, int32_t* gemm_launches, double* gemm_flops) {
+  int n = 0;
+  CK(gemm_prof_end(gemm_ms, &n, gemm_flops), "prof end");
+  if (gemm_launches) *gemm_launches = n;
+  return 0;
+}
+
+int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int32_t Nk, const char* name) {
+  if (check_dims(dims, B, T, Nk) || !name) return -1;
+  char* base = reinterpret_cast<char*>(4096);
+  const Ws w = carve(*dims, B, T, Nk, base);
+  const struct { const char* n; const float* p; } tab[] = {
+      {"R", w.R}, {"G", w.G}, {"Q", w.Q}, {"KV2", w.KV2}, {"KV", w.KV}, {"Q2", w.Q2}, {"P", w.P}, {"P2", w.P2},
+      {"O", w.O}, {"O2", w.O2}, {"U", w.U}, {"U2", w.U2}, {"Y", w.Y}, {"Y2", w.Y2}, {"H1", w.H1}, {"H2", w.H2},
+      {"comb", w.comb}, {"fused", w.fused}};
+  for (const auto& e : tab)
+    if (std::strcmp(e.n, name) == 0 && e.p) return reinterpret_cast<const char*>(e.p) - base;
+  return -1;
 }
 
 }  // extern "C"

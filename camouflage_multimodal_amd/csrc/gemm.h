@@ -42,3 +42,8 @@ struct GemmBatch {
 
 // precision: CAMO_PREC_F32 / CAMO_PREC_BF16.  Returns hipError_t as int.
 int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream);
+
+// ---- opt-in launch timing (bench.py's roofline leg): HIP events recorded on the launch stream
+// around every grouped-GEMM launch between prof_begin and prof_end.  Single-threaded use only.
+int gemm_prof_begin(int max_launches);
+int gemm_prof_end(double* total_ms, int* launches, double* total_flops);

@@ -21,6 +21,8 @@
 // step s takes k = 16h + s (f32) or the 8 k's [16*step + 8h, +8) (bf16).
 #include "gemm.h"
 
+#include <vector>
+
 namespace {
 
 constexpr int BM = 64, BN = 128, BK = 32;
@@ -313,6 +315,46 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmBatch gb, i
 
 }  // namespace
 
+namespace {
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;     // 2 per launch
+  std::vector<double> flops;
+  size_t used = 0;
+} g_prof;
+}  // namespace
+
+int gemm_prof_begin(int max_launches) {
+  if (max_launches < 1) return (int)hipErrorInvalidValue;
+  while (g_prof.ev.size() < (size_t)2 * max_launches) {
+    hipEvent_t e;
+    hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) return (int)r;
+    g_prof.ev.push_back(e);
+  }
+  g_prof.flops.clear();
+  g_prof.used = 0;
+  g_prof.on = true;
+  return 0;
+}
+
+int gemm_prof_end(double* total_ms, int* launches, double* total_flops) {
+  g_prof.on = false;
+  double ms = 0.0, fl = 0.0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    hipError_t r = hipEventSynchronize(g_prof.ev[2 * i + 1]);
+    if (r != hipSuccess) return (int)r;
+    float t = 0.f;
+    r = hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+    if (r != hipSuccess) return (int)r;
+    ms += t; fl += g_prof.flops[i];
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = (int)g_prof.used;
+  if (total_flops) *total_flops = fl;
+  return 0;
+}
+
 int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
   if (gb.n <= 0) return 0;
   // tiles without split-K
@@ -344,9 +386,20 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
   }
   if (total == 0) return 0;
   const size_t lds = precision == 0 ? (size_t)(A_F32 + B_F32) * 4 : (size_t)(A_BF16 + B_BF16) * 2;
+  const bool prof = g_prof.on && 2 * (g_prof.used + 1) <= g_prof.ev.size();
+  if (prof) {
+    double fl = 0.0;
+    for (int i = 0; i < gb.n; ++i) fl += 2.0 * gb.p[i].M * (double)gb.p[i].N * gb.p[i].K;
+    g_prof.flops.push_back(fl);
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.used], stream);
+  }
   if (precision == 0)
     hipLaunchKernelGGL(gemm_grouped_kernel<0>, dim3(total), dim3(256), lds, stream, gb, total);
   else
     hipLaunchKernelGGL(gemm_grouped_kernel<1>, dim3(total), dim3(256), lds, stream, gb, total);
+  if (prof) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], stream);
+    ++g_prof.used;
+  }
   return (int)hipGetLastError();
 }

@@ -1,0 +1,69 @@
+"""Single-node data parallelism for the fusion trainer: one process per GPU, parameters
+replicated, ONE all-reduce of the flat fp32 gradient buffer per optimizer step (RCCL over xGMI
+when the process group's backend is ``nccl``; ``gloo`` on CPU in the tests).
+
+Semantics (the reference itself is single-process): the reference's gradients are the
+SUM over the samples of a minibatch, clipped once (train_multimodal.py:238-279).  A global
+minibatch sharded over ranks therefore needs ``all_reduce(SUM)`` -- not the mean -- BEFORE the
+clip, so that N ranks x B samples equals the reference run with ``batch_size = N*B``.  The clip
+coefficient and the AdamW update are then computed redundantly (and identically) on every rank
+from the reduced buffer, so parameters stay bit-identical across ranks without a broadcast.
+
+Samples are independent (no BatchNorm, per-row LayerNorm), so there is no other exchange step.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class GradAllReducer:
+    """Callable handed to ``FusedClipAdamW.step(allreduce=...)``."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def __call__(self, flat_grads: torch.Tensor):
+        if self.world > 1:
+            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+        return flat_grads
+
+
+def broadcast_parameters(flat_params: torch.Tensor, src=0, group=None):
+    """Make every rank start from rank ``src``'s parameters (one flat broadcast)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_params, src=src, group=group)
+    return flat_params
+
+
+def shard_by_rows(nrs, world, rank):
+    """Split a global minibatch over ranks balancing the total number of RG rows (Nr varies
+    303..530 in the real data) rather than the sample count: longest-first greedy bin packing.
+    Deterministic, identical on every rank.  Returns the sorted sample indices of ``rank``."""
+    order = sorted(range(len(nrs)), key=lambda i: (-int(nrs[i]), i))
+    load = [0] * world
+    bins = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        bins[r].append(i)
+        load[r] += int(nrs[i])
+    return sorted(bins[rank])
+
+
+def sharded_weighted_sampler(weights, num_samples, epoch, world, rank, seed=0):
+    """The reference draws ``num_samples`` indices with replacement from ``weights``
+    (WeightedRandomSampler, train_multimodal.py:385-387).  Every rank draws the SAME sequence from
+    a common seed and keeps its strided share, so the union over ranks is one reference epoch."""
+    g = torch.Generator()
+    g.manual_seed(seed * 1000003 + epoch)
+    idx = torch.multinomial(torch.as_tensor(weights, dtype=torch.double), num_samples, replacement=True, generator=g)
+    return idx[rank::world].tolist()
+
+
+def reduce_metrics(values: torch.Tensor, group=None):
+    """SUM a small tensor of running metrics (loss sum, TP/FP/FN/TN counts) over ranks -- replaces
+    the reference's per-sample ``.item()`` bookkeeping (train_multimodal.py:269-275)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
+    return values

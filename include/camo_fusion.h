@@ -148,6 +148,26 @@ int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, const floa
                     float max_norm, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int32_t step, void* stream);
 
+/* ---- testing hooks ---------------------------------------------------------
+ * Not part of the operator surface; used by tests/ to check kernels in isolation.
+ * camo_debug_gemm: one problem of the grouped GEMM,
+ *   C[M,N] (+)= epi(A.B + bias) (+res), flags = GF_* bits of csrc/gemm.h
+ *   (1 relu, 4 atomic accumulate, 64 A k-major, 128 B k-major).
+ * camo_debug_ws_offset: byte offset of a named saved activation inside the
+ *   workspace (names: R G Q KV2 KV Q2 P P2 O O2 U U2 Y Y2 H1 H2 comb fused), or -1. */
+int camo_debug_gemm(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
+                    const float* bias, const float* res, int32_t ldr, float* bias_grad,
+                    int32_t M, int32_t N, int32_t K, int32_t flags, int32_t precision, void* stream);
+int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int32_t Nk, const char* name);
+
+/* Opt-in launch timing for bench.py's roofline leg: between camo_prof_begin and camo_prof_end every
+ * launch of the grouped GEMM kernel (the dominant kernel: >= 98 % of the path's FLOPs) is bracketed
+ * by two HIP events recorded on the launch stream.  camo_prof_end synchronises on them and returns
+ * the summed kernel time, the number of launches and the FLOPs those launches executed.  This is the
+ * one piece of process-global state in the library: single-threaded use, not for production loops. */
+int camo_prof_begin(int32_t max_launches);
+int camo_prof_end(double* gemm_ms, int32_t* gemm_launches, double* gemm_flops);
+
 #ifdef __cplusplus
 }
 #endif
