@@ -279,7 +279,7 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
   g.nt(G, H, P[CAMO_P_A2_IN_W], H, P[CAMO_P_A2_IN_B], w.Q2, H, TK, H, H);
   CK(g.run(), "attention in-projections");
   CK(launch_attn_rg2kg_fwd(w.Q, w.KV, rg_offsets, w.P, w.O, attn_rg2kg, B, max_nr, H, nh, Nk, drop, st), "attn rg2kg fwd");
-  CK(launch_attn_kg2rg_fwd(w.Q2, w.KV2, rg_offsets, w.P2, w.O2, B, H, nh, Nk, drop, st), "attn kg2rg fwd");
+  CK(launch_attn_kg2rg_fwd(w.Q2, w.KV2, rg_offsets, w.P2, w.O2, B, max_nr, H, nh, Nk, drop, st), "attn kg2rg fwd");
   if (attn_kg2rg) CK(launch_attn_avg(w.P2, attn_kg2rg, T, nh, Nk, drop, st), "attn avg");
   // out-projection + residual (fusion_model.py:119,130), then LayerNorm
   set_res(g.nt(w.O, H, P[CAMO_P_A1_OUT_W], H, P[CAMO_P_A1_OUT_B], w.U, H, T, H, H), R, H);
@@ -387,7 +387,7 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
   g.tn(w.dU2, H, w.O2, H, Gr[CAMO_P_A2_OUT_W], H, Gr[CAMO_P_A2_OUT_B], H, H, TK);
   CK(g.run(), "out-projection bwd");
   CK(launch_attn_rg2kg_bwd(w.Q, w.KV, w.P, w.dO, rg_offsets, w.dQ, w.dKV, B, max_nr, H, nh, Nk, drop, st), "attn rg2kg bwd");
-  CK(launch_attn_kg2rg_bwd(w.Q2, w.KV2, w.P2, w.dO2, rg_offsets, w.dQ2, w.dKV2, w.dS2, B, H, nh, Nk, drop, st), "attn kg2rg bwd");
+  CK(launch_attn_kg2rg_bwd(w.Q2, w.KV2, w.P2, w.dO2, rg_offsets, w.dQ2, w.dKV2, w.dS2, B, max_nr, H, nh, Nk, drop, st), "attn kg2rg bwd");
   // in-projection weight gradients, and the gradients flowing into R and G
   const size_t HH = (size_t)H * H;
   g.tn(w.dQ, H, R, H, Gr[CAMO_P_A1_IN_W], H, Gr[CAMO_P_A1_IN_B], H, H, T);

@@ -38,29 +38,89 @@ constexpr int B_BF16 = BN * LDH;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float4 ld4(const float* __restrict__ p, int nvalid, bool vec) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (nvalid >= 4 && vec) {
-    v = *reinterpret_cast<const float4*>(p);
+// Branch-free guarded loads.  A divergent "load or zero" makes hipcc branch around every load and
+// wait vmcnt(0) per element (one full memory round trip each), so every load below is issued
+// unconditionally from an address clamped into the matrix and masked afterwards.
+struct Operand {
+  const float* p; int ld; bool kmajor; bool vec;
+  int outer;   // number of rows/cols (M or N)
+  int K;
+};
+
+// 4 consecutive k of one row/col (m-major source): element (r, k) at p[r*ld + k]
+__device__ __forceinline__ float4 load_mm(const Operand& o, int r, int k, int kend) {
+  const int rc = min(r, o.outer - 1);
+  const float* base = o.p + (size_t)rc * o.ld;
+  float4 v;
+  if (o.vec) {   // wave-uniform: ld % 4 == 0, 16-B aligned base, K % 4 == 0
+    const bool ok = (r < o.outer) && (k < kend);
+    v = *reinterpret_cast<const float4*>(base + min(k, o.K - 4));
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
   } else {
-    if (nvalid > 0) v.x = p[0];
-    if (nvalid > 1) v.y = p[1];
-    if (nvalid > 2) v.z = p[2];
-    if (nvalid > 3) v.w = p[3];
+    float t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = base[min(k + e, o.K - 1)];
+      t[e] = ((r < o.outer) && (k + e < kend)) ? x : 0.f;
+    }
+    v = make_float4(t[0], t[1], t[2], t[3]);
   }
   return v;
 }
 
-__device__ __forceinline__ int clamp4(int n) { return n < 0 ? 0 : (n > 4 ? 4 : n); }
+// 4 consecutive rows/cols at one k (k-major source): element (m, k) at p[k*ld + m]
+__device__ __forceinline__ float4 load_km(const Operand& o, int m, int k, int kend) {
+  const int kc = min(k, o.K - 1);
+  const float* base = o.p + (size_t)kc * o.ld;
+  float4 v;
+  if (o.vec) {   // ld % 4 == 0, aligned, outer % 4 == 0
+    const bool ok = (k < kend) && (m < o.outer);
+    v = *reinterpret_cast<const float4*>(base + min(m, o.outer - 4));
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    float t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = base[min(m + e, o.outer - 1)];
+      t[e] = ((k < kend) && (m + e < o.outer)) ? x : 0.f;
+    }
+    v = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  return v;
+}
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
-  // round-to-nearest-even; NaN stays NaN through the compiler's own cast path
-  __bf16 b = (__bf16)f;
+  __bf16 b = (__bf16)f;     // round-to-nearest-even, NaN stays NaN
   return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// value -> C with the problem's fused epilogue (v already holds acc + bias)
+__device__ __forceinline__ void epilogue_store(const GemmProb& P, const DropCfg& drop, float v, int row, int col) {
+  const int flags = P.flags;
+  if (flags & GF_RELU) v = fmaxf(v, 0.f);
+  if ((flags & GF_DROPOUT) && drop.p > 0.f)
+    v *= drop_mult(drop, P.drop_site, (uint32_t)row * (uint32_t)P.N + (uint32_t)col);
+  if (flags & GF_RELU_BWD) {
+    v *= (P.res[(size_t)row * P.ldr + col] > 0.f) ? P.aux_scale : 0.f;
+  } else if (P.res) {
+    if (flags & GF_RES_BCAST) {
+      int sb; float inv;
+      if (P.row_sample) { sb = P.row_sample[row]; inv = P.inv_nr[sb]; }
+      else { sb = row / P.uniform_n; inv = 1.0f / (float)P.uniform_n; }
+      v += P.res[(size_t)sb * P.ldr + col] * inv;
+    } else {
+      v += P.res[(size_t)row * P.ldr + col];
+    }
+  }
+  if (flags & GF_SIGMOID) v = 1.0f / (1.0f + __expf(-v));
+  float* dst = P.C + (size_t)row * P.ldc + col;
+  if (flags & GF_ATOMIC) atomicAdd(dst, v);
+  else *dst = v;
 }
 
 template <int PREC>
-__global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmBatch gb, int total_tiles) {
+__global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GemmBatch gb, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
   // ---- XCD-aware block remap (bijective): blocks that share an XCD (bid % 8) get a
@@ -85,8 +145,9 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmBatch gb, i
   const int kend = min(P.K, kbeg + P.kchunk);
   const int M = P.M, N = P.N;
   const bool akm = P.flags & GF_A_KMAJOR, bkm = P.flags & GF_B_KMAJOR;
-  const bool vecA = ((P.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.A) & 15) == 0);
-  const bool vecB = ((P.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.B) & 15) == 0);
+  Operand oa{P.A, P.lda, akm, false, M, P.K}, ob{P.B, P.ldb, bkm, false, N, P.K};
+  oa.vec = ((P.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.A) & 15) == 0) && (((akm ? M : P.K) & 3) == 0);
+  ob.vec = ((P.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.B) & 15) == 0) && (((bkm ? N : P.K) & 3) == 0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -94,40 +155,6 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmBatch gb, i
   const int l31 = lane & 31, h = lane >> 5;
 
   float4 ra[2], rb[4];
-
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int s = tid + 256 * i;
-      if (!akm) {
-        const int r = s >> 3, c4 = s & 7;
-        const int row = m0 + r, k = k0 + c4 * 4;
-        const int nv = row < M ? clamp4(kend - k) : 0;
-        ra[i] = ld4(P.A + (size_t)row * P.lda + k, nv, vecA);
-      } else {
-        const int kk = s >> 4, c4 = s & 15;
-        const int k = k0 + kk, m = m0 + c4 * 4;
-        const int nv = k < kend ? clamp4(M - m) : 0;
-        ra[i] = ld4(P.A + (size_t)k * P.lda + m, nv, vecA);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int s = tid + 256 * i;
-      if (!bkm) {
-        const int r = s >> 3, c4 = s & 7;
-        const int col = n0 + r, k = k0 + c4 * 4;
-        const int nv = col < N ? clamp4(kend - k) : 0;
-        rb[i] = ld4(P.B + (size_t)col * P.ldb + k, nv, vecB);
-      } else {
-        const int kk = s >> 5, c4 = s & 31;
-        const int k = k0 + kk, n = n0 + c4 * 4;
-        const int nv = k < kend ? clamp4(N - n) : 0;
-        rb[i] = ld4(P.B + (size_t)k * P.ldb + n, nv, vecB);
-      }
-    }
-  };
-
   f32x16 acc[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -139,6 +166,20 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmBatch gb, i
   if constexpr (PREC == 0) {
     float* As = reinterpret_cast<float*>(smem_raw);
     float* Bs = As + A_F32;
+    auto gload = [&](int k0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int s = tid + 256 * i;
+        ra[i] = !akm ? load_mm(oa, m0 + (s >> 3), k0 + (s & 7) * 4, kend)
+                     : load_km(oa, m0 + (s & 15) * 4, k0 + (s >> 4), kend);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s = tid + 256 * i;
+        rb[i] = !bkm ? load_mm(ob, n0 + (s >> 3), k0 + (s & 7) * 4, kend)
+                     : load_km(ob, n0 + (s & 31) * 4, k0 + (s >> 5), kend);
+      }
+    };
     auto sstore = [&]() {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -160,43 +201,39 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmBatch gb, i
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       const bool more = k0 + BK < kend;
       if (more) gload(k0 + BK);
-      float a[16], b[2][16];
-      if (!akm) {
-        const float* p = As + (wr * 32 + l31) * LDM + 16 * h;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float4 v = *reinterpret_cast<const float4*>(p + 4 * i);
-          a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
-        }
-      } else {
-        const float* p = As + (16 * h) * LDKA + wr * 32 + l31;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) a[s] = p[s * LDKA];
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c = wc * 64 + j * 32 + l31;
-        if (!bkm) {
-          const float* p = Bs + c * LDM + 16 * h;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(p + 4 * i);
-            b[j][4 * i] = v.x; b[j][4 * i + 1] = v.y; b[j][4 * i + 2] = v.z; b[j][4 * i + 3] = v.w;
-          }
-        } else {
-          const float* p = Bs + (16 * h) * LDKB + c;
-#pragma unroll
-          for (int s = 0; s < 16; ++s) b[j][s] = p[s * LDKB];
-        }
-      }
       if (do_bsum && tid < BM) {
 #pragma unroll 8
         for (int kk = 0; kk < BK; ++kk) bsum += As[kk * LDKA + tid];
       }
+      // lane half h of MFMA step s feeds k = 16h + s; four steps per group keep the fragments small
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[0][s], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[1][s], acc[1], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) {
+        float a[4], b[2][4];
+        if (!akm) {
+          const float4 v = *reinterpret_cast<const float4*>(As + (wr * 32 + l31) * LDM + 16 * h + 4 * g);
+          a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+        } else {
+          const float* p = As + (16 * h + 4 * g) * LDKA + wr * 32 + l31;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = p[e * LDKA];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = wc * 64 + j * 32 + l31;
+          if (!bkm) {
+            const float4 v = *reinterpret_cast<const float4*>(Bs + c * LDM + 16 * h + 4 * g);
+            b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+          } else {
+            const float* p = Bs + (16 * h + 4 * g) * LDKB + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[j][e] = p[e * LDKB];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[0][e], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[1][e], acc[1], 0, 0, 0);
+        }
       }
       __syncthreads();
       if (more) { sstore(); __syncthreads(); }
@@ -204,41 +241,59 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmBatch gb, i
   } else {
     unsigned short* As = reinterpret_cast<unsigned short*>(smem_raw);
     unsigned short* Bs = As + A_BF16;
-    // Staging to the bf16 [row][k] image.  m-major sources: a float4 is 4 consecutive k of one
-    // row -> one 8-B store.  k-major sources: the thread's float4s are 4 consecutive rows(m) at one
-    // k; slots tid+256*i walk k in steps (A: 16, B: 8), so element stores are 2-B scatters.
-    auto sstore = [&]() {
+    // bf16 image [row][k], 80-B rows.  m-major sources: a float4 is 4 consecutive k of one row -> one
+    // 8-B store.  k-major sources are transposed in registers: B: a thread loads a 4(k) x 4(n) block
+    // (k = 4q..4q+3) -> four 8-B stores; A: a 2(k) x 4(m) block -> four 4-B stores.
+    auto gload = [&](int k0) {
+      if (!akm) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int s = tid + 256 * i;
-        if (!akm) {
-          uint2 pk;
-          pk.x = (uint32_t)f2bf(ra[i].x) | ((uint32_t)f2bf(ra[i].y) << 16);
-          pk.y = (uint32_t)f2bf(ra[i].z) | ((uint32_t)f2bf(ra[i].w) << 16);
-          *reinterpret_cast<uint2*>(As + (s >> 3) * LDH + (s & 7) * 4) = pk;
-        } else {
-          const int kk = s >> 4, m = (s & 15) * 4;
-          As[(m + 0) * LDH + kk] = f2bf(ra[i].x);
-          As[(m + 1) * LDH + kk] = f2bf(ra[i].y);
-          As[(m + 2) * LDH + kk] = f2bf(ra[i].z);
-          As[(m + 3) * LDH + kk] = f2bf(ra[i].w);
+        for (int i = 0; i < 2; ++i) {
+          const int s = tid + 256 * i;
+          ra[i] = load_mm(oa, m0 + (s >> 3), k0 + (s & 7) * 4, kend);
         }
+      } else {
+        const int kq = 4 * (tid >> 5) + 2 * ((tid >> 4) & 1), m = m0 + (tid & 15) * 4;
+        ra[0] = load_km(oa, m, k0 + kq, kend);
+        ra[1] = load_km(oa, m, k0 + kq + 1, kend);
       }
+      if (!bkm) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int s = tid + 256 * i;
-        if (!bkm) {
-          uint2 pk;
-          pk.x = (uint32_t)f2bf(rb[i].x) | ((uint32_t)f2bf(rb[i].y) << 16);
-          pk.y = (uint32_t)f2bf(rb[i].z) | ((uint32_t)f2bf(rb[i].w) << 16);
-          *reinterpret_cast<uint2*>(Bs + (s >> 3) * LDH + (s & 7) * 4) = pk;
-        } else {
-          const int kk = s >> 5, n = (s & 31) * 4;
-          Bs[(n + 0) * LDH + kk] = f2bf(rb[i].x);
-          Bs[(n + 1) * LDH + kk] = f2bf(rb[i].y);
-          Bs[(n + 2) * LDH + kk] = f2bf(rb[i].z);
-          Bs[(n + 3) * LDH + kk] = f2bf(rb[i].w);
+        for (int i = 0; i < 4; ++i) {
+          const int s = tid + 256 * i;
+          rb[i] = load_mm(ob, n0 + (s >> 3), k0 + (s & 7) * 4, kend);
         }
+      } else {
+        const int kq = 4 * (tid >> 5), n = n0 + (tid & 31) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rb[e] = load_km(ob, n, k0 + kq + e, kend);
+      }
+    };
+    auto sstore = [&]() {
+      if (!akm) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int s = tid + 256 * i;
+          *reinterpret_cast<uint2*>(As + (s >> 3) * LDH + (s & 7) * 4) = make_uint2(pack2(ra[i].x, ra[i].y), pack2(ra[i].z, ra[i].w));
+        }
+      } else {
+        const int kq = 4 * (tid >> 5) + 2 * ((tid >> 4) & 1), m = (tid & 15) * 4;
+        *reinterpret_cast<uint32_t*>(As + (m + 0) * LDH + kq) = pack2(ra[0].x, ra[1].x);
+        *reinterpret_cast<uint32_t*>(As + (m + 1) * LDH + kq) = pack2(ra[0].y, ra[1].y);
+        *reinterpret_cast<uint32_t*>(As + (m + 2) * LDH + kq) = pack2(ra[0].z, ra[1].z);
+        *reinterpret_cast<uint32_t*>(As + (m + 3) * LDH + kq) = pack2(ra[0].w, ra[1].w);
+      }
+      if (!bkm) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int s = tid + 256 * i;
+          *reinterpret_cast<uint2*>(Bs + (s >> 3) * LDH + (s & 7) * 4) = make_uint2(pack2(rb[i].x, rb[i].y), pack2(rb[i].z, rb[i].w));
+        }
+      } else {
+        const int kq = 4 * (tid >> 5), n = (tid & 31) * 4;
+        *reinterpret_cast<uint2*>(Bs + (n + 0) * LDH + kq) = make_uint2(pack2(rb[0].x, rb[1].x), pack2(rb[2].x, rb[3].x));
+        *reinterpret_cast<uint2*>(Bs + (n + 1) * LDH + kq) = make_uint2(pack2(rb[0].y, rb[1].y), pack2(rb[2].y, rb[3].y));
+        *reinterpret_cast<uint2*>(Bs + (n + 2) * LDH + kq) = make_uint2(pack2(rb[0].z, rb[1].z), pack2(rb[2].z, rb[3].z));
+        *reinterpret_cast<uint2*>(Bs + (n + 3) * LDH + kq) = make_uint2(pack2(rb[0].w, rb[1].w), pack2(rb[2].w, rb[3].w));
       }
     };
 
@@ -279,7 +334,6 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmBatch gb, i
   if (do_bsum && tid < BM && m0 + tid < M) atomicAdd(P.bias_grad + m0 + tid, bsum);
 
   // ---- epilogue.  32x32 accumulator: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int flags = P.flags;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wc * 64 + j * 32 + l31;
@@ -289,26 +343,102 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmBatch gb, i
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (row >= M) continue;
-      float v = acc[j][r] + bv;
-      if (flags & GF_RELU) v = fmaxf(v, 0.f);
-      if ((flags & GF_DROPOUT) && gb.drop.p > 0.f)
-        v *= drop_mult(gb.drop, P.drop_site, (uint32_t)row * (uint32_t)N + (uint32_t)col);
-      if (flags & GF_RELU_BWD) {
-        v *= (P.res[(size_t)row * P.ldr + col] > 0.f) ? P.aux_scale : 0.f;
-      } else if (P.res) {
-        if (flags & GF_RES_BCAST) {
-          int sb; float inv;
-          if (P.row_sample) { sb = P.row_sample[row]; inv = P.inv_nr[sb]; }
-          else { sb = row / P.uniform_n; inv = 1.0f / (float)P.uniform_n; }
-          v += P.res[(size_t)sb * P.ldr + col] * inv;
-        } else {
-          v += P.res[(size_t)row * P.ldr + col];
-        }
-      }
-      if (flags & GF_SIGMOID) v = 1.0f / (1.0f + __expf(-v));
-      float* dst = P.C + (size_t)row * P.ldc + col;
-      if (flags & GF_ATOMIC) atomicAdd(dst, v);
-      else *dst = v;
+      epilogue_store(P, gb.drop, acc[j][r] + bv, row, col);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Skinny problems (the per-sample "tail" of the model: M = batch size B <= 64 rows, or a weight
+// gradient whose contraction runs over those B rows).  The 64x128 block tile above would spend
+// its K loop on empty rows and serialise it (~1 us per 32-deep step); here the unit of work is a
+// 16x16 output tile on v_mfma_f32_16x16x4_f32 (exact fp32), operands loaded straight from
+// global memory (they are KBs and L2-resident):
+//   * C = x.W^T / dy.W  (M <= 64): one block per tile, its 4 waves split K and combine through LDS;
+//   * dW += dy^T.x      (K <= 64): one wave per tile, 4 tiles per block.
+// Lane (x = lane & 15, q = lane >> 4) of MFMA step e within a 16-deep k block feeds k = 4q + e for
+// both operands, so a lane's four steps come from one 16-B load where the source is k-contiguous.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 4 consecutive k (stride ld) at one column of a k-major source: element (k, c) at p[k*ld + c]
+__device__ __forceinline__ float4 load_kstrided(const Operand& o, int c, int k, int kend) {
+  const int cc = min(c, o.outer - 1);
+  float t[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = o.p[(size_t)min(k + e, o.K - 1) * o.ld + cc];
+    t[e] = ((c < o.outer) && (k + e < kend)) ? x : 0.f;
+  }
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmBatch gb) {
+  __shared__ float red[3][4][64];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM_MAXP; ++i)
+    if (i < gb.n && (int)blockIdx.x >= gb.p[i].tile_begin) pi = i;
+  const GemmProb& P = gb.p[pi];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x = lane & 15, q = lane >> 4;
+  const bool akm = P.flags & GF_A_KMAJOR, bkm = P.flags & GF_B_KMAJOR;
+  const int M = P.M, N = P.N, K = P.K;
+  Operand oa{P.A, P.lda, akm, false, M, K}, ob{P.B, P.ldb, bkm, false, N, K};
+  oa.vec = !akm && ((P.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.A) & 15) == 0) && ((K & 3) == 0);
+  ob.vec = !bkm && ((P.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.B) & 15) == 0) && ((K & 3) == 0);
+  const int tiles_n = P.tiles_n;          // 16-wide column tiles
+  const int local = blockIdx.x - P.tile_begin;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int tile, kb0, kbstep;
+  if (akm) { tile = local * 4 + wave; kb0 = 0; kbstep = 1; }     // a wave per tile, whole K
+  else     { tile = local; kb0 = wave; kbstep = 4; }             // a block per tile, waves interleave K
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * 16, n0 = tn * 16;
+  const bool live = m0 < M;               // (only the a-wave-per-tile mode can run past the last tile)
+  float bsum = 0.f;
+  if (live) {
+    const int nkb = (K + 15) >> 4;
+    auto lda_ = [&](int kb) { const int k = kb * 16 + 4 * q; return akm ? load_kstrided(oa, m0 + x, k, K) : load_mm(oa, m0 + x, k, K); };
+    auto ldb_ = [&](int kb) { const int k = kb * 16 + 4 * q; return bkm ? load_kstrided(ob, n0 + x, k, K) : load_mm(ob, n0 + x, k, K); };
+    // two k blocks in flight: loads past K are address-clamped and masked to zero, so no branch
+    float4 a0 = lda_(kb0), b0 = ldb_(kb0), a1 = lda_(kb0 + kbstep), b1 = ldb_(kb0 + kbstep);
+    for (int kb = kb0; kb < nkb; kb += kbstep) {
+      const float4 a = a0, b = b0;
+      a0 = a1; b0 = b1;
+      a1 = lda_(kb + 2 * kbstep); b1 = ldb_(kb + 2 * kbstep);
+      bsum += (a.x + a.y) + (a.z + a.w);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    }
+  }
+  if (!akm) {
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += (red[0][r][lane] + red[1][r][lane]) + red[2][r][lane];
+  } else if (!live) {
+    return;
+  }
+  if (akm && P.bias_grad && tn == 0) {    // bias gradient: sum over k of A(m, k)
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (q == 0 && m0 + x < M) atomicAdd(P.bias_grad + m0 + x, bsum);
+  }
+  // 16x16 accumulator: col = lane & 15, row = 4*(lane >> 4) + reg
+  const int col = n0 + x;
+  if (col < N) {
+    const float bv = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 4 * q + r;
+      if (row < M) epilogue_store(P, gb.drop, acc[r] + bv, row, col);
     }
   }
 }
@@ -355,8 +485,32 @@ int gemm_prof_end(double* total_ms, int* launches, double* total_flops) {
   return 0;
 }
 
+static int launch_skinny(GemmBatch& gb, hipStream_t stream) {
+  int total = 0;
+  for (int i = 0; i < gb.n; ++i) {
+    GemmProb& p = gb.p[i];
+    p.tiles_n = (p.N + 15) / 16;
+    const int tiles = ((p.M + 15) / 16) * p.tiles_n;
+    p.ksplit = 1; p.kchunk = p.K;
+    p.tile_begin = total;
+    total += (p.flags & GF_A_KMAJOR) ? (tiles + 3) / 4 : tiles;
+  }
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(gemm_skinny_kernel, dim3(total), dim3(256), 0, stream, gb);
+  return (int)hipGetLastError();
+}
+
 int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
   if (gb.n <= 0) return 0;
+  if (precision == 0) {
+    // per-sample tail: every problem is skinny (few rows, or a contraction over few rows)
+    bool skinny = true;
+    for (int i = 0; i < gb.n; ++i) {
+      const GemmProb& p = gb.p[i];
+      skinny = skinny && (((p.flags & GF_A_KMAJOR) ? p.K : p.M) <= 64);
+    }
+    if (skinny) return launch_skinny(gb, stream);
+  }
   // tiles without split-K
   int base_tiles = 0;
   for (int i = 0; i < gb.n; ++i) {
@@ -369,12 +523,11 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
     GemmProb& p = gb.p[i];
     const int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
     int ksplit = 1;
-    if ((p.flags & GF_ATOMIC) && (p.flags & GF_A_KMAJOR) && p.K > 4 * BK) {
-      // weight-gradient GEMM: small output, long contraction -> split K to fill the chip
+    if ((p.flags & GF_ATOMIC) && (p.flags & GF_A_KMAJOR) && p.K > 16 * BK) {
+      // weight-gradient GEMM: small output, long contraction.  A block's K loop is serial
+      // (~1 us per 32-deep tile), so cap it at ~12 tiles and let the fp32 atomics merge the splits.
       const int ktiles = (p.K + BK - 1) / BK;
-      int want = (1024 + base_tiles - 1) / base_tiles;          // aim at ~1024 blocks per launch
-      const int max_split = (ktiles + 3) / 4;                      // keep >= 4 K-tiles per block
-      ksplit = want < 1 ? 1 : (want > max_split ? max_split : want);
+      ksplit = (ktiles + 11) / 12;
     }
     const int ktiles = (p.K + BK - 1) / BK;
     const int per = (ktiles + ksplit - 1) / ksplit;
