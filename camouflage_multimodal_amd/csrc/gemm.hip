@@ -38,55 +38,64 @@ constexpr int B_BF16 = BN * LDH;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-// Branch-free guarded loads.  A divergent "load or zero" makes hipcc branch around every load and
-// wait vmcnt(0) per element (one full memory round trip each), so every load below is issued
-// unconditionally from an address clamped into the matrix and masked afterwards.
+// Guarded loads, branch-free BY CONSTRUCTION.  hipcc turns "cond ? load : 0" into a branch around
+// the load plus a vmcnt(0) wait per element (one memory round trip each; the first version of this
+// kernel spent ~4 us per K step there).  So loading and masking are separate steps: raw_*() issues
+// every load unconditionally from an address clamped into the matrix, the staged registers are
+// pinned with an empty asm at the point of use, and only then mask_*() zeroes what lies outside.
 struct Operand {
   const float* p; int ld; bool kmajor; bool vec;
   int outer;   // number of rows/cols (M or N)
   int K;
 };
 
+__device__ __forceinline__ void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
+// VEC is a COMPILE-TIME switch: with a runtime (even wave-uniform) switch hipcc if-converts the two
+// paths into four dword loads with selected addresses, i.e. never emits global_load_dwordx4.
+// VEC requires ld % 4 == 0, a 16-B aligned base and the contiguous extent % 4 == 0.
 // 4 consecutive k of one row/col (m-major source): element (r, k) at p[r*ld + k]
-__device__ __forceinline__ float4 load_mm(const Operand& o, int r, int k, int kend) {
-  const int rc = min(r, o.outer - 1);
-  const float* base = o.p + (size_t)rc * o.ld;
-  float4 v;
-  if (o.vec) {   // wave-uniform: ld % 4 == 0, 16-B aligned base, K % 4 == 0
-    const bool ok = (r < o.outer) && (k < kend);
-    v = *reinterpret_cast<const float4*>(base + min(k, o.K - 4));
-    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+template <bool VEC>
+__device__ __forceinline__ float4 raw_mm(const Operand& o, int r, int k) {
+  const float* base = o.p + (size_t)min(r, o.outer - 1) * o.ld;
+  if constexpr (VEC) {
+    return *reinterpret_cast<const float4*>(base + min(k, o.K - 4));
   } else {
-    float t[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float x = base[min(k + e, o.K - 1)];
-      t[e] = ((r < o.outer) && (k + e < kend)) ? x : 0.f;
-    }
-    v = make_float4(t[0], t[1], t[2], t[3]);
+    const int km = o.K - 1;
+    return make_float4(base[min(k, km)], base[min(k + 1, km)], base[min(k + 2, km)], base[min(k + 3, km)]);
   }
+}
+__device__ __forceinline__ float4 mask_mm(const Operand& o, float4 v, int r, int k, int kend) {
+  const bool rok = r < o.outer;
+  v.x = (rok && k < kend) ? v.x : 0.f;     v.y = (rok && k + 1 < kend) ? v.y : 0.f;
+  v.z = (rok && k + 2 < kend) ? v.z : 0.f; v.w = (rok && k + 3 < kend) ? v.w : 0.f;
   return v;
 }
 
 // 4 consecutive rows/cols at one k (k-major source): element (m, k) at p[k*ld + m]
-__device__ __forceinline__ float4 load_km(const Operand& o, int m, int k, int kend) {
-  const int kc = min(k, o.K - 1);
-  const float* base = o.p + (size_t)kc * o.ld;
-  float4 v;
-  if (o.vec) {   // ld % 4 == 0, aligned, outer % 4 == 0
-    const bool ok = (k < kend) && (m < o.outer);
-    v = *reinterpret_cast<const float4*>(base + min(m, o.outer - 4));
-    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+template <bool VEC>
+__device__ __forceinline__ float4 raw_km(const Operand& o, int m, int k) {
+  const float* base = o.p + (size_t)min(k, o.K - 1) * o.ld;
+  if constexpr (VEC) {
+    return *reinterpret_cast<const float4*>(base + min(m, o.outer - 4));
   } else {
-    float t[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float x = base[min(m + e, o.outer - 1)];
-      t[e] = ((k < kend) && (m + e < o.outer)) ? x : 0.f;
-    }
-    v = make_float4(t[0], t[1], t[2], t[3]);
+    const int mm = o.outer - 1;
+    return make_float4(base[min(m, mm)], base[min(m + 1, mm)], base[min(m + 2, mm)], base[min(m + 3, mm)]);
   }
+}
+__device__ __forceinline__ float4 mask_km(const Operand& o, float4 v, int m, int k, int kend) {
+  const bool kok = k < kend;
+  v.x = (kok && m < o.outer) ? v.x : 0.f;     v.y = (kok && m + 1 < o.outer) ? v.y : 0.f;
+  v.z = (kok && m + 2 < o.outer) ? v.z : 0.f; v.w = (kok && m + 3 < o.outer) ? v.w : 0.f;
   return v;
+}
+
+// 4 consecutive k (stride ld) at one column of a k-major source: element (k, c) at p[k*ld + c]
+__device__ __forceinline__ float4 raw_ks(const Operand& o, int c, int k) {
+  const float* base = o.p + min(c, o.outer - 1);
+  const int km = o.K - 1;
+  return make_float4(base[(size_t)min(k, km) * o.ld], base[(size_t)min(k + 1, km) * o.ld],
+                     base[(size_t)min(k + 2, km) * o.ld], base[(size_t)min(k + 3, km) * o.ld]);
 }
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
@@ -119,35 +128,15 @@ __device__ __forceinline__ void epilogue_store(const GemmProb& P, const DropCfg&
   else *dst = v;
 }
 
-template <int PREC>
-__global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GemmBatch gb, int total_tiles) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+struct TileCtx {
+  int m0, n0, tn, kbeg, kend;
+};
 
-  // ---- XCD-aware block remap (bijective): blocks that share an XCD (bid % 8) get a
-  // contiguous run of tiles, so neighbouring N-tiles re-use the A row panel from that L2.
-  int bid = blockIdx.x;
-  {
-    const int nwg = total_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < GEMM_MAXP; ++i)
-    if (i < gb.n && bid >= gb.p[i].tile_begin) pi = i;
-  const GemmProb& P = gb.p[pi];
-
-  int t = bid - P.tile_begin;
-  const int ks = t % P.ksplit; t /= P.ksplit;
-  const int tn = t % P.tiles_n;
-  const int tm = t / P.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = ks * P.kchunk;
-  const int kend = min(P.K, kbeg + P.kchunk);
+template <int PREC, bool akm, bool bkm, bool VEC>
+__device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmProb& P, const TileCtx tc, char* smem_raw) {
+  const int m0 = tc.m0, n0 = tc.n0, tn = tc.tn, kbeg = tc.kbeg, kend = tc.kend;
   const int M = P.M, N = P.N;
-  const bool akm = P.flags & GF_A_KMAJOR, bkm = P.flags & GF_B_KMAJOR;
-  Operand oa{P.A, P.lda, akm, false, M, P.K}, ob{P.B, P.ldb, bkm, false, N, P.K};
-  oa.vec = ((P.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.A) & 15) == 0) && (((akm ? M : P.K) & 3) == 0);
-  ob.vec = ((P.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.B) & 15) == 0) && (((bkm ? N : P.K) & 3) == 0);
+  const Operand oa{P.A, P.lda, akm, VEC, M, P.K}, ob{P.B, P.ldb, bkm, VEC, N, P.K};
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -170,33 +159,35 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GemmBatch gb
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int s = tid + 256 * i;
-        ra[i] = !akm ? load_mm(oa, m0 + (s >> 3), k0 + (s & 7) * 4, kend)
-                     : load_km(oa, m0 + (s & 15) * 4, k0 + (s >> 4), kend);
+        ra[i] = !akm ? raw_mm<VEC>(oa, m0 + (s >> 3), k0 + (s & 7) * 4) : raw_km<VEC>(oa, m0 + (s & 15) * 4, k0 + (s >> 4));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int s = tid + 256 * i;
-        rb[i] = !bkm ? load_mm(ob, n0 + (s >> 3), k0 + (s & 7) * 4, kend)
-                     : load_km(ob, n0 + (s & 31) * 4, k0 + (s >> 5), kend);
+        rb[i] = !bkm ? raw_mm<VEC>(ob, n0 + (s >> 3), k0 + (s & 7) * 4) : raw_km<VEC>(ob, n0 + (s & 31) * 4, k0 + (s >> 5));
       }
     };
-    auto sstore = [&]() {
+    auto sstore = [&](int k0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) pin4(ra[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pin4(rb[i]);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int s = tid + 256 * i;
-        if (!akm) *reinterpret_cast<float4*>(As + (s >> 3) * LDM + (s & 7) * 4) = ra[i];
-        else      *reinterpret_cast<float4*>(As + (s >> 4) * LDKA + (s & 15) * 4) = ra[i];
+        if (!akm) *reinterpret_cast<float4*>(As + (s >> 3) * LDM + (s & 7) * 4) = mask_mm(oa, ra[i], m0 + (s >> 3), k0 + (s & 7) * 4, kend);
+        else      *reinterpret_cast<float4*>(As + (s >> 4) * LDKA + (s & 15) * 4) = mask_km(oa, ra[i], m0 + (s & 15) * 4, k0 + (s >> 4), kend);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int s = tid + 256 * i;
-        if (!bkm) *reinterpret_cast<float4*>(Bs + (s >> 3) * LDM + (s & 7) * 4) = rb[i];
-        else      *reinterpret_cast<float4*>(Bs + (s >> 5) * LDKB + (s & 31) * 4) = rb[i];
+        if (!bkm) *reinterpret_cast<float4*>(Bs + (s >> 3) * LDM + (s & 7) * 4) = mask_mm(ob, rb[i], n0 + (s >> 3), k0 + (s & 7) * 4, kend);
+        else      *reinterpret_cast<float4*>(Bs + (s >> 5) * LDKB + (s & 31) * 4) = mask_km(ob, rb[i], n0 + (s & 31) * 4, k0 + (s >> 5), kend);
       }
     };
 
     gload(kbeg);
-    sstore();
+    sstore(kbeg);
     __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       const bool more = k0 + BK < kend;
@@ -236,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GemmBatch gb
         }
       }
       __syncthreads();
-      if (more) { sstore(); __syncthreads(); }
+      if (more) { sstore(k0 + BK); __syncthreads(); }
     }
   } else {
     unsigned short* As = reinterpret_cast<unsigned short*>(smem_raw);
@@ -249,26 +240,45 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GemmBatch gb
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int s = tid + 256 * i;
-          ra[i] = load_mm(oa, m0 + (s >> 3), k0 + (s & 7) * 4, kend);
+          ra[i] = raw_mm<VEC>(oa, m0 + (s >> 3), k0 + (s & 7) * 4);
         }
       } else {
         const int kq = 4 * (tid >> 5) + 2 * ((tid >> 4) & 1), m = m0 + (tid & 15) * 4;
-        ra[0] = load_km(oa, m, k0 + kq, kend);
-        ra[1] = load_km(oa, m, k0 + kq + 1, kend);
+        ra[0] = raw_km<VEC>(oa, m, k0 + kq);
+        ra[1] = raw_km<VEC>(oa, m, k0 + kq + 1);
       }
       if (!bkm) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int s = tid + 256 * i;
-          rb[i] = load_mm(ob, n0 + (s >> 3), k0 + (s & 7) * 4, kend);
+          rb[i] = raw_mm<VEC>(ob, n0 + (s >> 3), k0 + (s & 7) * 4);
         }
       } else {
         const int kq = 4 * (tid >> 5), n = n0 + (tid & 31) * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) rb[e] = load_km(ob, n, k0 + kq + e, kend);
+        for (int e = 0; e < 4; ++e) rb[e] = raw_km<VEC>(ob, n, k0 + kq + e);
       }
     };
-    auto sstore = [&]() {
+    auto sstore = [&](int k0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) pin4(ra[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pin4(rb[i]);
+      if (!akm) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int s = tid + 256 * i; ra[i] = mask_mm(oa, ra[i], m0 + (s >> 3), k0 + (s & 7) * 4, kend); }
+      } else {
+        const int kq = 4 * (tid >> 5) + 2 * ((tid >> 4) & 1), m = m0 + (tid & 15) * 4;
+        ra[0] = mask_km(oa, ra[0], m, k0 + kq, kend); ra[1] = mask_km(oa, ra[1], m, k0 + kq + 1, kend);
+      }
+      if (!bkm) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int s = tid + 256 * i; rb[i] = mask_mm(ob, rb[i], n0 + (s >> 3), k0 + (s & 7) * 4, kend); }
+      } else {
+        const int kq = 4 * (tid >> 5), n = n0 + (tid & 31) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rb[e] = mask_km(ob, rb[e], n, k0 + kq + e, kend);
+      }
       if (!akm) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GemmBatch gb
     };
 
     gload(kbeg);
-    sstore();
+    sstore(kbeg);
     __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       const bool more = k0 + BK < kend;
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GemmBatch gb
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[1][s], acc[1], 0, 0, 0);
       }
       __syncthreads();
-      if (more) { sstore(); __syncthreads(); }
+      if (more) { sstore(k0 + BK); __syncthreads(); }
     }
   }
 
@@ -348,6 +358,47 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GemmBatch gb
   }
 }
 
+template <int PREC>
+__global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GemmBatch gb, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+  // ---- XCD-aware block remap (bijective): blocks that share an XCD (bid % 8) get a
+  // contiguous run of tiles, so neighbouring N-tiles re-use the A row panel from that L2.
+  int bid = blockIdx.x;
+  {
+    const int nwg = total_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM_MAXP; ++i)
+    if (i < gb.n && bid >= gb.p[i].tile_begin) pi = i;
+  const GemmProb& P = gb.p[pi];
+
+  int t = bid - P.tile_begin;
+  const int ks = t % P.ksplit; t /= P.ksplit;
+  TileCtx tc;
+  tc.tn = t % P.tiles_n;
+  tc.m0 = (t / P.tiles_n) * BM; tc.n0 = tc.tn * BN;
+  tc.kbeg = ks * P.kchunk;
+  tc.kend = min(P.K, tc.kbeg + P.kchunk);
+  const bool akm = P.flags & GF_A_KMAJOR, bkm = P.flags & GF_B_KMAJOR;
+  const bool vec = ((P.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.A) & 15) == 0) && (((akm ? P.M : P.K) & 3) == 0) &&
+                   ((P.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.B) & 15) == 0) && (((bkm ? P.N : P.K) & 3) == 0);
+  // block-uniform dispatch to a body compiled for this problem's operand layouts
+  if (vec) {
+    if (!akm && !bkm)      gemm_tile_body<PREC, false, false, true>(gb, P, tc, smem_raw);
+    else if (!akm && bkm)  gemm_tile_body<PREC, false, true, true>(gb, P, tc, smem_raw);
+    else if (akm && bkm)   gemm_tile_body<PREC, true, true, true>(gb, P, tc, smem_raw);
+    else                   gemm_tile_body<PREC, true, false, true>(gb, P, tc, smem_raw);
+  } else {
+    if (!akm && !bkm)      gemm_tile_body<PREC, false, false, false>(gb, P, tc, smem_raw);
+    else if (!akm && bkm)  gemm_tile_body<PREC, false, true, false>(gb, P, tc, smem_raw);
+    else if (akm && bkm)   gemm_tile_body<PREC, true, true, false>(gb, P, tc, smem_raw);
+    else                   gemm_tile_body<PREC, true, false, false>(gb, P, tc, smem_raw);
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Skinny problems (the per-sample "tail" of the model: M = batch size B <= 64 rows, or a weight
@@ -360,18 +411,6 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GemmBatch gb
 // Lane (x = lane & 15, q = lane >> 4) of MFMA step e within a 16-deep k block feeds k = 4q + e for
 // both operands, so a lane's four steps come from one 16-B load where the source is k-contiguous.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// 4 consecutive k (stride ld) at one column of a k-major source: element (k, c) at p[k*ld + c]
-__device__ __forceinline__ float4 load_kstrided(const Operand& o, int c, int k, int kend) {
-  const int cc = min(c, o.outer - 1);
-  float t[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float x = o.p[(size_t)min(k + e, o.K - 1) * o.ld + cc];
-    t[e] = ((c < o.outer) && (k + e < kend)) ? x : 0.f;
-  }
-  return make_float4(t[0], t[1], t[2], t[3]);
-}
 
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmBatch gb) {
   __shared__ float red[3][4][64];
@@ -399,14 +438,17 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmBatch gb) {
   float bsum = 0.f;
   if (live) {
     const int nkb = (K + 15) >> 4;
-    auto lda_ = [&](int kb) { const int k = kb * 16 + 4 * q; return akm ? load_kstrided(oa, m0 + x, k, K) : load_mm(oa, m0 + x, k, K); };
-    auto ldb_ = [&](int kb) { const int k = kb * 16 + 4 * q; return bkm ? load_kstrided(ob, n0 + x, k, K) : load_mm(ob, n0 + x, k, K); };
-    // two k blocks in flight: loads past K are address-clamped and masked to zero, so no branch
+    auto lda_ = [&](int kb) { const int k = kb * 16 + 4 * q; return akm ? raw_ks(oa, m0 + x, k) : (oa.vec ? raw_mm<true>(oa, m0 + x, k) : raw_mm<false>(oa, m0 + x, k)); };
+    auto ldb_ = [&](int kb) { const int k = kb * 16 + 4 * q; return bkm ? raw_ks(ob, n0 + x, k) : (ob.vec ? raw_mm<true>(ob, m0 * 0 + n0 + x, k) : raw_mm<false>(ob, n0 + x, k)); };
+    // two k blocks in flight; raw loads are address-clamped, masking happens at the point of use
     float4 a0 = lda_(kb0), b0 = ldb_(kb0), a1 = lda_(kb0 + kbstep), b1 = ldb_(kb0 + kbstep);
     for (int kb = kb0; kb < nkb; kb += kbstep) {
-      const float4 a = a0, b = b0;
+      float4 a = a0, b = b0;
       a0 = a1; b0 = b1;
       a1 = lda_(kb + 2 * kbstep); b1 = ldb_(kb + 2 * kbstep);
+      pin4(a); pin4(b);
+      a = mask_mm(oa, a, m0 + x, kb * 16 + 4 * q, K);     // (row/col, k) validity is layout-independent
+      b = mask_mm(ob, b, n0 + x, kb * 16 + 4 * q, K);
       bsum += (a.x + a.y) + (a.z + a.w);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);

@@ -1,0 +1,33 @@
+"""Developer aid: times camo_debug_gemm on a few shapes.  python tests/dev_gemm_bench.py"""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from camouflage_multimodal_amd import _lib
+L = _lib.lib()
+AKM, BKM, ATOMIC = 64, 128, 4
+p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+def bench(M, N, K, flags, prec, iters=20):
+    akm, bkm = bool(flags & AKM), bool(flags & BKM)
+    A = torch.randn((K, M) if akm else (M, K), device="cuda")
+    B = torch.randn((K, N) if bkm else (N, K), device="cuda")
+    Cm = torch.zeros(M, N, device="cuda")
+    run = lambda: _lib.check(L.camo_debug_gemm(p(A), A.shape[1], p(B), B.shape[1], p(Cm), N, None, None, 0, None, M, N, K, flags, prec, st()))
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    print(f"M={M:6d} N={N:5d} K={K:5d} flags={flags:3d} prec={'bf16' if prec else 'f32 '}: {us:9.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s")
+
+for prec in (1, 0):
+    bench(65, 128, 4096, 0, prec)          # 2 blocks, 128 k-tiles: per-iteration latency of a lone block
+    bench(65, 128, 256, 0, prec)
+    bench(64 * 256, 128, 4096, 0, prec)    # 256 blocks = one per CU
+    bench(64 * 512, 128, 4096, 0, prec)    # two per CU
+    bench(64 * 1024, 128, 4096, 0, prec)   # four per CU (2 resident)
+    bench(64 * 256, 128, 256, 0, prec)
+    bench(64 * 512, 128, 256, 0, prec)
