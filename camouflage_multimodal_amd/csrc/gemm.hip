@@ -343,17 +343,46 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
 
   if (do_bsum && tid < BM && m0 + tid < M) atomicAdd(P.bias_grad + m0 + tid, bsum);
 
-  // ---- epilogue.  32x32 accumulator: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // ---- epilogue.  32x32 accumulator: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // Executed once per block but 32 elements deep per lane, so it is kept lean: the common forms
+  // (store / relu / dropout / residual, and the atomic accumulate of a weight gradient) run in
+  // loops whose only per-element control flow is the row bound; the first version's fully generic
+  // per-element flag tests cost ~10 us per launch in straight-line code.
+  const int flags = P.flags;
+  const int rowb = m0 + wr * 32 + 4 * h;
+  const bool rare = flags & (GF_RELU_BWD | GF_RES_BCAST | GF_SIGMOID);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wc * 64 + j * 32 + l31;
     if (col >= N) continue;
     const float bv = P.bias ? P.bias[col] : 0.f;
+    float* cp = P.C + col;
+    if (flags & GF_ATOMIC) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row >= M) continue;
-      epilogue_store(P, gb.drop, acc[j][r] + bv, row, col);
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowb + (r & 3) + 8 * (r >> 2);
+        if (row < M) atomicAdd(cp + (size_t)row * P.ldc, acc[j][r] + bv);
+      }
+    } else if (rare) {
+#pragma unroll 4
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowb + (r & 3) + 8 * (r >> 2);
+        if (row < M) epilogue_store(P, gb.drop, acc[j][r] + bv, row, col);
+      }
+    } else {
+      const float floor_ = (flags & GF_RELU) ? 0.f : -INFINITY;
+      const bool dodrop = (flags & GF_DROPOUT) && gb.drop.p > 0.f;
+      const float* rp = P.res ? P.res + col : nullptr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowb + (r & 3) + 8 * (r >> 2);
+        if (row < M) {
+          float v = fmaxf(acc[j][r] + bv, floor_);
+          if (dodrop) v *= drop_mult(gb.drop, P.drop_site, (uint32_t)row * (uint32_t)N + (uint32_t)col);
+          if (rp) v += rp[(size_t)row * P.ldr];
+          cp[(size_t)row * P.ldc] = v;
+        }
+      }
     }
   }
 }

@@ -23,11 +23,12 @@ def bench(M, N, K, flags, prec, iters=20):
     us = e0.elapsed_time(e1) * 1e3 / iters
     print(f"M={M:6d} N={N:5d} K={K:5d} flags={flags:3d} prec={'bf16' if prec else 'f32 '}: {us:9.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s")
 
-for prec in (1, 0):
-    bench(65, 128, 4096, 0, prec)          # 2 blocks, 128 k-tiles: per-iteration latency of a lone block
-    bench(65, 128, 256, 0, prec)
-    bench(64 * 256, 128, 4096, 0, prec)    # 256 blocks = one per CU
-    bench(64 * 512, 128, 4096, 0, prec)    # two per CU
-    bench(64 * 1024, 128, 4096, 0, prec)   # four per CU (2 resident)
-    bench(64 * 256, 128, 256, 0, prec)
-    bench(64 * 512, 128, 256, 0, prec)
+for prec in (1,):
+    for K in (32, 64, 128, 256, 512, 1024):
+        bench(65, 128, K, 0, prec, 50)
+    for K in (32, 64, 128, 256, 512, 1024):
+        bench(64 * 256, 128, K, 0, prec, 50)
+    for K in (32, 128, 256, 512):
+        bench(64 * 128, 256, K, 0, prec, 50)
+    bench(7700, 256, 128, 0, prec, 50)
+    bench(7700, 768, 256, 0, prec, 50)
