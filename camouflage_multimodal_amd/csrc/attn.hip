@@ -485,6 +485,8 @@ int attn_supported(int H, int nh, int Nk) {
 
 int launch_attn_rg2kg_fwd(const float* Q, const float* KV, const int* offs, float* P, float* O, float* attn_avg,
                           int B, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
+  if (attn_mfma_ok(H, nh, Nk, max_nr, false))
+    return launch_rg2kg_fwd_mfma(Q, KV, offs, P, O, attn_avg, B, max_nr, H, nh, Nk, drop, stream);
   if (attn_fast_ok(H, nh, Nk, max_nr, false, false))
     return launch_rg2kg_fwd32(Q, KV, offs, P, O, attn_avg, B, max_nr, H, nh, Nk, drop, stream);
   const int RB = rg2kg_rows(H, nh, Nk, false);
@@ -499,6 +501,8 @@ int launch_attn_rg2kg_fwd(const float* Q, const float* KV, const int* offs, floa
 int launch_attn_rg2kg_bwd(const float* Q, const float* KV, const float* P, const float* dO, const int* offs,
                           float* dQ, float* dKV, int B, int max_nr, int H, int nh, int Nk, DropCfg drop,
                           hipStream_t stream) {
+  if (attn_mfma_ok(H, nh, Nk, max_nr, false))
+    return launch_rg2kg_bwd_mfma(Q, KV, P, dO, offs, dQ, dKV, B, max_nr, H, nh, Nk, drop, stream);
   if (attn_fast_ok(H, nh, Nk, max_nr, false, true))
     return launch_rg2kg_bwd32(Q, KV, P, dO, offs, dQ, dKV, B, max_nr, H, nh, Nk, drop, stream);
   const int RB = rg2kg_rows(H, nh, Nk, true);
@@ -512,6 +516,8 @@ int launch_attn_rg2kg_bwd(const float* Q, const float* KV, const float* P, const
 
 int launch_attn_kg2rg_fwd(const float* Q2, const float* KV2, const int* offs, float* P2, float* O2,
                           int B, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
+  if (attn_mfma_ok(H, nh, Nk, max_nr, true))
+    return launch_kg2rg_fwd_mfma(Q2, KV2, offs, P2, O2, B, H, nh, Nk, drop, stream);
   if (attn_fast_ok(H, nh, Nk, max_nr, true, false))
     return launch_kg2rg_fwd32(Q2, KV2, offs, P2, O2, B, max_nr, H, nh, Nk, drop, stream);
   const dim3 grid(nh, B);
@@ -525,6 +531,8 @@ int launch_attn_kg2rg_fwd(const float* Q2, const float* KV2, const int* offs, fl
 int launch_attn_kg2rg_bwd(const float* Q2, const float* KV2, const float* P2, const float* dO2, const int* offs,
                           float* dQ2, float* dKV2, float* dS2, int B, int max_nr, int H, int nh, int Nk, DropCfg drop,
                           hipStream_t stream) {
+  if (attn_mfma_ok(H, nh, Nk, max_nr, true))
+    return launch_kg2rg_bwd_mfma(Q2, KV2, P2, dO2, offs, dQ2, dKV2, B, H, nh, Nk, drop, stream);
   if (attn_fast_ok(H, nh, Nk, max_nr, true, true))
     return launch_kg2rg_bwd32(Q2, KV2, P2, dO2, offs, dQ2, dKV2, B, max_nr, H, nh, Nk, drop, stream);
   const dim3 grid(nh, B);

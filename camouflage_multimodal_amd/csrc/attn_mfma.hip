@@ -1,0 +1,456 @@
+// Cross-attention cores on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32), head_dim = 32.
+//
+// Both attention directions have one tiny dimension (Nk = 13 KG rows, padded to one 16-wide
+// MFMA tile) and one long one (the RG nodes of the sample), so every product is a chain of
+// 16x16 tiles over 16-node slices.  Lane coordinates: x = lane & 15, q = lane >> 4.
+//
+//   * "row fragment" of a row-major matrix X: lane (x,q) holds X[x][8q .. 8q+7] (two 16-B loads).
+//     As the A operand it supplies rows of A, as the B operand rows of B^T; MFMA step e of the
+//     8-step K=32 chain feeds k = 8q + e from BOTH fragments, so C = A.B^T needs no shuffles.
+//   * an accumulator tile D (col = x, rows 4q..4q+3 in the 4 registers) is, unchanged, the A
+//     operand of the next product that contracts over D's ROW index: step e feeds k = 4q + e
+//     and the B operand supplies B[4q+e][col].  So scores are always produced with the index to
+//     be contracted next on the rows:  S^T = K.Q^T (keys x nodes) feeds O = P.V and dQ = dS.K;
+//     the other orientation (nodes x keys) is recomputed with one more 8-MFMA chain where a
+//     gradient contracts over nodes (dK = dS^T.Q, dV = P^T.dO) -- cheaper than a transpose.
+//   * softmax reductions run over the 4 registers and the 4 lane groups (xor 16, 32) only.
+//
+// Numerics: fp32 FMA chains in k order, same math as attn.hip; dropout masks from the shared
+// counter hash.  Conditions: head_dim == 32, Nk <= 16; kg2rg additionally Nr <= 16*4*MAXT.
+#include "attn.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int DH = 32;
+constexpr int MAXT = 12;   // key tiles per wave in the kg2rg kernels (4 waves => Nr <= 768)
+
+struct Frag8 { float4 lo, hi; };
+
+__device__ __forceinline__ Frag8 load_row8(const float* __restrict__ row, int q, bool valid) {
+  Frag8 f;
+  f.lo = *reinterpret_cast<const float4*>(row + 8 * q);
+  f.hi = *reinterpret_cast<const float4*>(row + 8 * q + 4);
+  if (!valid) { f.lo = make_float4(0.f, 0.f, 0.f, 0.f); f.hi = f.lo; }
+  return f;
+}
+__device__ __forceinline__ Frag8 scale8(Frag8 f, float s) {
+  f.lo.x *= s; f.lo.y *= s; f.lo.z *= s; f.lo.w *= s; f.hi.x *= s; f.hi.y *= s; f.hi.z *= s; f.hi.w *= s;
+  return f;
+}
+
+// C += A.B^T, K = 32: a = row fragment of A (lane x = row of C), b = row fragment of B (lane x = col of C)
+__device__ __forceinline__ f4 mma_nt32(const Frag8& a, const Frag8& b, f4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.x, b.lo.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.y, b.lo.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.z, b.lo.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.w, b.lo.w, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.x, b.hi.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.y, b.hi.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.z, b.hi.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.w, b.hi.w, c, 0, 0, 0);
+  return c;
+}
+// C += A.B, K = 16: a = an accumulator tile whose ROWS are the contraction index (a[e] <-> k = 4q+e),
+// b[e] = B[4q+e][col x]
+__device__ __forceinline__ f4 mma_acc16(const f4& a, const f4& b, f4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+  return c;
+}
+// b[e] = X[(row0 + 4q + e) * ld + col] for e = 0..3, rows clamped to [.., row_max] (finite filler;
+// the matching A entries are zero there)
+__device__ __forceinline__ f4 load_col4(const float* __restrict__ X, size_t ld, int row0, int q, int row_max, int col) {
+  f4 b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b[e] = X[(size_t)min(row0 + 4 * q + e, row_max) * ld + col];
+  return b;
+}
+__device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+// ------------------------------------------------------------------ rg2kg forward
+// one wave = one 16-node tile of sample blockIdx.y, all heads; 4 tiles per block
+__global__ __launch_bounds__(256) void rg2kg_fwd_mfma_kernel(
+    const float* __restrict__ Q, const float* __restrict__ KV, const int* __restrict__ offs,
+    float* __restrict__ P, float* __restrict__ O, float* __restrict__ attn_avg,
+    int H, int nh, int Nk, float scale, DropCfg drop) {
+  const int b = blockIdx.y;
+  const int r0 = offs[b], nr = offs[b + 1] - r0;
+  const int lane = threadIdx.x & 63, x = lane & 15, q = lane >> 4;
+  const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  if (t0 >= nr) return;
+  const int node = r0 + min(t0 + x, nr - 1);            // this lane's node as a COLUMN of S^T
+  const bool node_ok = t0 + x < nr;
+  const float* kvb = KV + (size_t)b * Nk * 2 * H;
+  f4 avg = {0.f, 0.f, 0.f, 0.f};
+  for (int h = 0; h < nh; ++h) {
+    const Frag8 qf = load_row8(Q + (size_t)node * H + h * DH, q, true);
+    const Frag8 kf = load_row8(kvb + (size_t)min(x, Nk - 1) * 2 * H + h * DH, q, x < Nk);
+    f4 s = mma_nt32(kf, qf, f4{0.f, 0.f, 0.f, 0.f});     // S^T: rows = keys 4q+r, col = node x
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[r] = (4 * q + r < Nk) ? s[r] * scale : -INFINITY; m = fmaxf(m, s[r]); }
+    m = group_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - m); sum += s[r]; }
+    sum = group_sum(sum);
+    const float inv = 1.0f / sum;
+    const size_t pbase = ((size_t)node * nh + h) * Nk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 4 * q + r;
+      float p = s[r] * inv;
+      if (key < Nk) {
+        if (node_ok) P[pbase + key] = p;
+        if (drop.p > 0.f) p *= drop_mult(drop, SITE_ATTN_RG2KG, (uint32_t)(pbase + key));
+      }
+      s[r] = p;
+      avg[r] += p;
+    }
+#pragma unroll
+    for (int d0 = 0; d0 < DH; d0 += 16) {
+      const f4 vb = load_col4(kvb + H + h * DH + d0, (size_t)2 * H, 0, q, Nk - 1, x);
+      const f4 o = mma_acc16(s, vb, f4{0.f, 0.f, 0.f, 0.f});   // rows = nodes 4q+r, col = d0 + x
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (t0 + 4 * q + r < nr) O[(size_t)(r0 + t0 + 4 * q + r) * H + h * DH + d0 + x] = o[r];
+    }
+  }
+  if (attn_avg && node_ok) {
+    const float invh = 1.0f / (float)nh;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * q + r < Nk) attn_avg[(size_t)node * Nk + 4 * q + r] = avg[r] * invh;
+  }
+}
+
+// ------------------------------------------------------------------ rg2kg backward
+// grid (chunks, nh, B); one wave = TPW consecutive 16-node tiles of (sample, head); dK/dV partials in
+// accumulator tiles, one atomicAdd per element per wave.
+constexpr int TPW = 4;
+__global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
+    const float* __restrict__ Q, const float* __restrict__ KV, const float* __restrict__ P,
+    const float* __restrict__ dO, const int* __restrict__ offs,
+    float* __restrict__ dQ, float* __restrict__ dKV,
+    int H, int nh, int Nk, float scale, DropCfg drop) {
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int r0 = offs[b], nr = offs[b + 1] - r0;
+  const int lane = threadIdx.x & 63, x = lane & 15, q = lane >> 4;
+  const int tfirst = (blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW;
+  if (tfirst * 16 >= nr) return;
+  const float* kvb = KV + (size_t)b * Nk * 2 * H;
+  const Frag8 kf = load_row8(kvb + (size_t)min(x, Nk - 1) * 2 * H + h * DH, q, x < Nk);
+  const Frag8 vf = load_row8(kvb + (size_t)min(x, Nk - 1) * 2 * H + H + h * DH, q, x < Nk);
+  f4 kb[2], dKa[2], dVa[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    kb[n] = load_col4(kvb + h * DH + 16 * n, (size_t)2 * H, 0, q, Nk - 1, x);   // K_h[key 4q+e][16n + x]
+    dKa[n] = f4{0.f, 0.f, 0.f, 0.f}; dVa[n] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int t0 = (tfirst + tt) * 16;
+    if (t0 >= nr) break;
+    const int node = r0 + min(t0 + x, nr - 1);
+    const bool node_ok = t0 + x < nr;
+    const Frag8 qf = load_row8(Q + (size_t)node * H + h * DH, q, true);
+    const Frag8 gf = load_row8(dO + (size_t)node * H + h * DH, q, true);
+    // ---- orientation T: rows = keys 4q+r, col = node x
+    f4 dpT = mma_nt32(vf, gf, f4{0.f, 0.f, 0.f, 0.f});
+    const size_t pbase = ((size_t)node * nh + h) * Nk;
+    f4 pT;
+    float dot = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 4 * q + r;
+      const bool ok = key < Nk && node_ok;
+      pT[r] = ok ? P[pbase + min(key, Nk - 1)] : 0.f;
+      const float m = (ok && drop.p > 0.f) ? drop_mult(drop, SITE_ATTN_RG2KG, (uint32_t)(pbase + key)) : 1.0f;
+      dpT[r] *= m;
+      dot = fmaf(pT[r], dpT[r], dot);
+    }
+    dot = group_sum(dot);                                  // row-dot of node x
+    f4 dsT;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dsT[r] = pT[r] * (dpT[r] - dot) * scale;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const f4 dq = mma_acc16(dsT, kb[n], f4{0.f, 0.f, 0.f, 0.f});     // rows = nodes 4q+r, col = 16n + x
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (t0 + 4 * q + r < nr) dQ[(size_t)(r0 + t0 + 4 * q + r) * H + h * DH + 16 * n + x] = dq[r];
+    }
+    // ---- orientation N: rows = nodes 4q+r, col = key x
+    f4 dpN = mma_nt32(gf, vf, f4{0.f, 0.f, 0.f, 0.f});
+    f4 dsN, pdN;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int nd = t0 + 4 * q + r;
+      const bool ok = x < Nk && nd < nr;
+      const size_t pb = ((size_t)(r0 + min(nd, nr - 1)) * nh + h) * Nk;
+      const float p = ok ? P[pb + min(x, Nk - 1)] : 0.f;
+      const float m = (ok && drop.p > 0.f) ? drop_mult(drop, SITE_ATTN_RG2KG, (uint32_t)(pb + x)) : 1.0f;
+      const float dotn = __shfl(dot, 4 * q + r, 64);       // row-dot of node 4q+r lives in lane x' = 4q+r
+      dsN[r] = p * (dpN[r] * m - dotn) * scale;
+      pdN[r] = p * m;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const f4 qb = load_col4(Q + (size_t)r0 * H + h * DH + 16 * n, (size_t)H, t0, q, nr - 1, x);
+      const f4 gb = load_col4(dO + (size_t)r0 * H + h * DH + 16 * n, (size_t)H, t0, q, nr - 1, x);
+      dKa[n] = mma_acc16(dsN, qb, dKa[n]);                 // rows = keys 4q+r, col = 16n + x
+      dVa[n] = mma_acc16(pdN, gb, dVa[n]);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 4 * q + r;
+      if (key < Nk) {
+        float* dst = dKV + (size_t)(b * Nk + key) * 2 * H + h * DH + 16 * n + x;
+        atomicAdd(dst, dKa[n][r]);
+        atomicAdd(dst + H, dVa[n][r]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------ kg2rg forward, grid (nh, B)
+// wave w owns key tiles w, w+4, ...; scores S2^T (rows = keys 4q+r, col = query x) stay in registers.
+__global__ __launch_bounds__(256) void kg2rg_fwd_mfma_kernel(
+    const float* __restrict__ Q2, const float* __restrict__ KV2, const int* __restrict__ offs,
+    float* __restrict__ P2, float* __restrict__ O2, int H, int nh, int Nk, float scale, DropCfg drop) {
+  __shared__ float red[4][16];
+  __shared__ float ored[3][2][4][64];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int r0 = offs[b], nr = offs[b + 1] - r0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
+  const int ntiles = (nr + 15) >> 4;
+  const float* kv = KV2 + (size_t)r0 * 2 * H;
+  const Frag8 q2f = scale8(load_row8(Q2 + (size_t)(b * Nk + min(x, Nk - 1)) * H + h * DH, q, x < Nk), scale);
+  f4 s[MAXT];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t0 = (wave + 4 * i) * 16;
+    s[i] = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (wave + 4 * i < ntiles) {
+      const Frag8 kf = load_row8(kv + (size_t)min(t0 + x, nr - 1) * 2 * H + h * DH, q, true);
+      s[i] = mma_nt32(kf, q2f, f4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { if (t0 + 4 * q + r >= nr) s[i][r] = -INFINITY; m = fmaxf(m, s[i][r]); }
+    }
+  }
+  m = group_max(m);
+  if (q == 0) red[wave][x] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0][x], red[1][x]), fmaxf(red[2][x], red[3][x]));
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[i][r] = __expf(s[i][r] - m); sum += s[i][r]; }
+  sum = group_sum(sum);
+  if (q == 0) red[wave][x] = sum;
+  __syncthreads();
+  const float inv = 1.0f / ((red[0][x] + red[1][x]) + (red[2][x] + red[3][x]));
+  f4 o[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t0 = (wave + 4 * i) * 16;
+    if (wave + 4 * i < ntiles) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = t0 + 4 * q + r;
+        float p = s[i][r] * inv;
+        if (t < nr && x < Nk) {
+          const size_t idx = ((size_t)(r0 + t) * nh + h) * Nk + x;
+          P2[idx] = p;
+          if (drop.p > 0.f) p *= drop_mult(drop, SITE_ATTN_KG2RG, (uint32_t)idx);
+        } else {
+          p = 0.f;
+        }
+        s[i][r] = p;
+      }
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const f4 vb = load_col4(kv + H + h * DH + 16 * n, (size_t)2 * H, t0, q, nr - 1, x);
+        o[n] = mma_acc16(s[i], vb, o[n]);                  // rows = queries 4q+r, col = 16n + x
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ored[wave - 1][n][r][lane] = o[n][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = o[n][r] + (ored[0][n][r][lane] + ored[1][n][r][lane]) + ored[2][n][r][lane];
+        if (4 * q + r < Nk) O2[(size_t)(b * Nk + 4 * q + r) * H + h * DH + 16 * n + x] = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------ kg2rg backward, grid (nh, B)
+__global__ __launch_bounds__(256) void kg2rg_bwd_mfma_kernel(
+    const float* __restrict__ Q2, const float* __restrict__ KV2, const float* __restrict__ P2,
+    const float* __restrict__ dO2, const int* __restrict__ offs,
+    float* __restrict__ dQ2, float* __restrict__ dKV2, int H, int nh, int Nk, float scale, DropCfg drop) {
+  __shared__ float red[4][16];
+  __shared__ float ored[3][2][4][64];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int r0 = offs[b], nr = offs[b + 1] - r0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
+  const int ntiles = (nr + 15) >> 4;
+  const float* kv = KV2 + (size_t)r0 * 2 * H;
+  const float* q2p = Q2 + (size_t)b * Nk * H + h * DH;
+  const float* g2p = dO2 + (size_t)b * Nk * H + h * DH;
+  const Frag8 g2f = load_row8(g2p + (size_t)min(x, Nk - 1) * H, q, x < Nk);
+  // ---- phase 1, orientation T (rows = keys 4q+r, col = query x): dP, row-dots, dS, dQ2
+  f4 ds[MAXT], pT[MAXT];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t0 = (wave + 4 * i) * 16;
+    ds[i] = f4{0.f, 0.f, 0.f, 0.f}; pT[i] = f4{0.f, 0.f, 0.f, 0.f};
+    if (wave + 4 * i < ntiles) {
+      const Frag8 vf = load_row8(kv + (size_t)min(t0 + x, nr - 1) * 2 * H + H + h * DH, q, true);
+      ds[i] = mma_nt32(vf, g2f, f4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = t0 + 4 * q + r;
+        const bool ok = t < nr && x < Nk;
+        const size_t idx = ((size_t)(r0 + min(t, nr - 1)) * nh + h) * Nk + min(x, Nk - 1);
+        pT[i][r] = ok ? P2[idx] : 0.f;
+        const float mk = (ok && drop.p > 0.f) ? drop_mult(drop, SITE_ATTN_KG2RG, (uint32_t)idx) : 1.0f;
+        ds[i][r] *= mk;
+        dot = fmaf(pT[i][r], ds[i][r], dot);
+      }
+    }
+  }
+  dot = group_sum(dot);
+  if (q == 0) red[wave][x] = dot;
+  __syncthreads();
+  dot = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);   // row-dot of query x
+  f4 dq[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t0 = (wave + 4 * i) * 16;
+    if (wave + 4 * i < ntiles) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[i][r] = pT[i][r] * (ds[i][r] - dot) * scale;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const f4 kb = load_col4(kv + h * DH + 16 * n, (size_t)2 * H, t0, q, nr - 1, x);
+        dq[n] = mma_acc16(ds[i], kb, dq[n]);               // rows = queries 4q+r, col = 16n + x
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ored[wave - 1][n][r][lane] = dq[n][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = dq[n][r] + (ored[0][n][r][lane] + ored[1][n][r][lane]) + ored[2][n][r][lane];
+        if (4 * q + r < Nk) dQ2[(size_t)(b * Nk + 4 * q + r) * H + h * DH + 16 * n + x] = v;
+      }
+  }
+  // ---- phase 2, orientation N (rows = queries 4q+r, col = key x): dK2, dV2 of every key tile
+  f4 q2b[2], g2b[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    q2b[n] = load_col4(q2p + 16 * n, (size_t)H, 0, q, Nk - 1, x);   // Q2_h[query 4q+e][16n + x]
+    g2b[n] = load_col4(g2p + 16 * n, (size_t)H, 0, q, Nk - 1, x);
+  }
+  float dotq[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dotq[r] = __shfl(dot, 4 * q + r, 64);  // row-dot of query 4q+r
+  for (int i = 0; i < MAXT; ++i) {
+    const int t0 = (wave + 4 * i) * 16;
+    if (wave + 4 * i >= ntiles) break;
+    const int key = min(t0 + x, nr - 1);
+    const bool key_ok = t0 + x < nr;
+    const Frag8 vf = load_row8(kv + (size_t)key * 2 * H + H + h * DH, q, true);
+    const f4 dpN = mma_nt32(g2f, vf, f4{0.f, 0.f, 0.f, 0.f});
+    const size_t pb = ((size_t)(r0 + key) * nh + h) * Nk;
+    f4 dsN, pdN;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qi = 4 * q + r;
+      const bool ok = key_ok && qi < Nk;
+      const float p = ok ? P2[pb + min(qi, Nk - 1)] : 0.f;
+      const float mk = (ok && drop.p > 0.f) ? drop_mult(drop, SITE_ATTN_KG2RG, (uint32_t)(pb + qi)) : 1.0f;
+      dsN[r] = p * (dpN[r] * mk - dotq[r]) * scale;
+      pdN[r] = p * mk;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const f4 dk = mma_acc16(dsN, q2b[n], f4{0.f, 0.f, 0.f, 0.f});  // rows = keys 4q+r, col = 16n + x
+      const f4 dv = mma_acc16(pdN, g2b[n], f4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = t0 + 4 * q + r;
+        if (t < nr) {
+          float* dst = dKV2 + (size_t)(r0 + t) * 2 * H + h * DH + 16 * n + x;
+          dst[0] = dk[r];
+          dst[H] = dv[r];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ launchers
+int attn_mfma_ok(int H, int nh, int Nk, int max_nr, bool kg2rg) {
+  if (nh < 1 || H != nh * DH || Nk < 1 || Nk > 16) return 0;
+  if (kg2rg && max_nr > 16 * 4 * MAXT) return 0;
+  return 1;
+}
+
+int launch_rg2kg_fwd_mfma(const float* Q, const float* KV, const int* offs, float* P, float* O, float* attn_avg,
+                          int B, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
+  hipLaunchKernelGGL(rg2kg_fwd_mfma_kernel, dim3((max_nr + 63) / 64, B), dim3(256), 0, stream, Q, KV, offs, P, O, attn_avg,
+                     H, nh, Nk, 1.0f / sqrtf((float)DH), drop);
+  return (int)hipGetLastError();
+}
+
+int launch_rg2kg_bwd_mfma(const float* Q, const float* KV, const float* P, const float* dO, const int* offs, float* dQ,
+                          float* dKV, int B, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
+  const int tiles = (max_nr + 15) / 16;
+  hipLaunchKernelGGL(rg2kg_bwd_mfma_kernel, dim3((tiles + 4 * TPW - 1) / (4 * TPW), nh, B), dim3(256), 0, stream, Q, KV, P, dO,
+                     offs, dQ, dKV, H, nh, Nk, 1.0f / sqrtf((float)DH), drop);
+  return (int)hipGetLastError();
+}
+
+int launch_kg2rg_fwd_mfma(const float* Q2, const float* KV2, const int* offs, float* P2, float* O2, int B, int H, int nh,
+                          int Nk, DropCfg drop, hipStream_t stream) {
+  hipLaunchKernelGGL(kg2rg_fwd_mfma_kernel, dim3(nh, B), dim3(256), 0, stream, Q2, KV2, offs, P2, O2, H, nh, Nk,
+                     1.0f / sqrtf((float)DH), drop);
+  return (int)hipGetLastError();
+}
+
+int launch_kg2rg_bwd_mfma(const float* Q2, const float* KV2, const float* P2, const float* dO2, const int* offs, float* dQ2,
+                          float* dKV2, int B, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
+  hipLaunchKernelGGL(kg2rg_bwd_mfma_kernel, dim3(nh, B), dim3(256), 0, stream, Q2, KV2, P2, dO2, offs, dQ2, dKV2, H, nh, Nk,
+                     1.0f / sqrtf((float)DH), drop);
+  return (int)hipGetLastError();
+}
