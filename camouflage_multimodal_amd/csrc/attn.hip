@@ -484,9 +484,9 @@ int attn_supported(int H, int nh, int Nk) {
   } while (0)
 
 int launch_attn_rg2kg_fwd(const float* Q, const float* KV, const int* offs, float* P, float* O, float* attn_avg,
-                          int B, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
+                          int B, int T, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
   if (attn_mfma_ok(H, nh, Nk, max_nr, false))
-    return launch_rg2kg_fwd_mfma(Q, KV, offs, P, O, attn_avg, B, max_nr, H, nh, Nk, drop, stream);
+    return launch_rg2kg_fwd_mfma(Q, KV, offs, P, O, attn_avg, B, T, max_nr, H, nh, Nk, drop, stream);
   if (attn_fast_ok(H, nh, Nk, max_nr, false, false))
     return launch_rg2kg_fwd32(Q, KV, offs, P, O, attn_avg, B, max_nr, H, nh, Nk, drop, stream);
   const int RB = rg2kg_rows(H, nh, Nk, false);

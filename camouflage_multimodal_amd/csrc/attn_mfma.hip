@@ -23,7 +23,8 @@ namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int DH = 32;
-constexpr int MAXT = 12;   // key tiles per wave in the kg2rg kernels (4 waves => Nr <= 768)
+constexpr int NW = 8;      // waves per block in the kg2rg kernels
+constexpr int MAXT = 6;    // key tiles per wave there (8 waves x 6 tiles x 16 keys => Nr <= 768)
 
 struct Frag8 { float4 lo, hi; };
 
@@ -72,76 +73,86 @@ __device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v,
 __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
 // ------------------------------------------------------------------ rg2kg forward
-// one wave = one 16-node tile of sample blockIdx.y, all heads; 4 tiles per block
+// one wave = one (16-node tile, head) pair of sample blockIdx.y: tile-major, head fastest, so the 4 waves
+// of a block share Q rows.  The head-averaged map (inference only) is a separate pass over P.
 __global__ __launch_bounds__(256) void rg2kg_fwd_mfma_kernel(
     const float* __restrict__ Q, const float* __restrict__ KV, const int* __restrict__ offs,
-    float* __restrict__ P, float* __restrict__ O, float* __restrict__ attn_avg,
-    int H, int nh, int Nk, float scale, DropCfg drop) {
+    float* __restrict__ P, float* __restrict__ O, int H, int nh, int Nk, float scale, DropCfg drop) {
   const int b = blockIdx.y;
   const int r0 = offs[b], nr = offs[b + 1] - r0;
   const int lane = threadIdx.x & 63, x = lane & 15, q = lane >> 4;
-  const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int h = task % nh, t0 = (task / nh) * 16;
   if (t0 >= nr) return;
   const int node = r0 + min(t0 + x, nr - 1);            // this lane's node as a COLUMN of S^T
   const bool node_ok = t0 + x < nr;
   const float* kvb = KV + (size_t)b * Nk * 2 * H;
-  f4 avg = {0.f, 0.f, 0.f, 0.f};
-  for (int h = 0; h < nh; ++h) {
-    const Frag8 qf = load_row8(Q + (size_t)node * H + h * DH, q, true);
-    const Frag8 kf = load_row8(kvb + (size_t)min(x, Nk - 1) * 2 * H + h * DH, q, x < Nk);
-    f4 s = mma_nt32(kf, qf, f4{0.f, 0.f, 0.f, 0.f});     // S^T: rows = keys 4q+r, col = node x
-    float m = -INFINITY;
+  const Frag8 qf = load_row8(Q + (size_t)node * H + h * DH, q, true);
+  const Frag8 kf = load_row8(kvb + (size_t)min(x, Nk - 1) * 2 * H + h * DH, q, x < Nk);
+  f4 vb[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { s[r] = (4 * q + r < Nk) ? s[r] * scale : -INFINITY; m = fmaxf(m, s[r]); }
-    m = group_max(m);
-    float sum = 0.f;
+  for (int n = 0; n < 2; ++n) vb[n] = load_col4(kvb + H + h * DH + 16 * n, (size_t)2 * H, 0, q, Nk - 1, x);
+  f4 s = mma_nt32(kf, qf, f4{0.f, 0.f, 0.f, 0.f});       // S^T: rows = keys 4q+r, col = node x
+  float m = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - m); sum += s[r]; }
-    sum = group_sum(sum);
-    const float inv = 1.0f / sum;
-    const size_t pbase = ((size_t)node * nh + h) * Nk;
+  for (int r = 0; r < 4; ++r) { s[r] = (4 * q + r < Nk) ? s[r] * scale : -INFINITY; m = fmaxf(m, s[r]); }
+  m = group_max(m);
+  float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = 4 * q + r;
-      float p = s[r] * inv;
-      if (key < Nk) {
-        if (node_ok) P[pbase + key] = p;
-        if (drop.p > 0.f) p *= drop_mult(drop, SITE_ATTN_RG2KG, (uint32_t)(pbase + key));
-      }
-      s[r] = p;
-      avg[r] += p;
+  for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - m); sum += s[r]; }
+  sum = group_sum(sum);
+  const float inv = 1.0f / sum;
+  const size_t pbase = ((size_t)node * nh + h) * Nk;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int key = 4 * q + r;
+    float p = s[r] * inv;
+    if (key < Nk) {
+      if (node_ok) P[pbase + key] = p;
+      if (drop.p > 0.f) p *= drop_mult(drop, SITE_ATTN_RG2KG, (uint32_t)(pbase + key));
     }
-#pragma unroll
-    for (int d0 = 0; d0 < DH; d0 += 16) {
-      const f4 vb = load_col4(kvb + H + h * DH + d0, (size_t)2 * H, 0, q, Nk - 1, x);
-      const f4 o = mma_acc16(s, vb, f4{0.f, 0.f, 0.f, 0.f});   // rows = nodes 4q+r, col = d0 + x
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (t0 + 4 * q + r < nr) O[(size_t)(r0 + t0 + 4 * q + r) * H + h * DH + d0 + x] = o[r];
-    }
+    s[r] = p;
   }
-  if (attn_avg && node_ok) {
-    const float invh = 1.0f / (float)nh;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const f4 o = mma_acc16(s, vb[n], f4{0.f, 0.f, 0.f, 0.f});   // rows = nodes 4q+r, col = 16n + x
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (4 * q + r < Nk) attn_avg[(size_t)node * Nk + 4 * q + r] = avg[r] * invh;
+      if (t0 + 4 * q + r < nr) O[(size_t)(r0 + t0 + 4 * q + r) * H + h * DH + 16 * n + x] = o[r];
   }
+}
+
+// head-average of the (dropped) probabilities: out[t][j] = mean_h drop(P[t,h,j])
+__global__ void attn_avg_site_kernel(const float* __restrict__ Pm, float* __restrict__ out, int T, int nh, int Nk,
+                                     uint32_t site, DropCfg drop) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * Nk) return;
+  const int t = i / Nk, j = i - t * Nk;
+  float a = 0.f;
+  for (int h = 0; h < nh; ++h) {
+    const size_t idx = ((size_t)t * nh + h) * Nk + j;
+    float p = Pm[idx];
+    if (drop.p > 0.f) p *= drop_mult(drop, site, (uint32_t)idx);
+    a += p;
+  }
+  out[i] = a / (float)nh;
 }
 
 // ------------------------------------------------------------------ rg2kg backward
 // grid (chunks, nh, B); one wave = TPW consecutive 16-node tiles of (sample, head); dK/dV partials in
 // accumulator tiles, one atomicAdd per element per wave.
-constexpr int TPW = 4;
+constexpr int TPW = 2;
 __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
     const float* __restrict__ Q, const float* __restrict__ KV, const float* __restrict__ P,
     const float* __restrict__ dO, const int* __restrict__ offs,
     float* __restrict__ dQ, float* __restrict__ dKV,
     int H, int nh, int Nk, float scale, DropCfg drop) {
+  __shared__ float comb[3][16][64];
   const int b = blockIdx.z, h = blockIdx.y;
   const int r0 = offs[b], nr = offs[b + 1] - r0;
-  const int lane = threadIdx.x & 63, x = lane & 15, q = lane >> 4;
-  const int tfirst = (blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW;
-  if (tfirst * 16 >= nr) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
+  if ((int)blockIdx.x * 4 * TPW * 16 >= nr) return;      // whole block past the sample (uniform)
+  const int tfirst = (blockIdx.x * 4 + wave) * TPW;
   const float* kvb = KV + (size_t)b * Nk * 2 * H;
   const Frag8 kf = load_row8(kvb + (size_t)min(x, Nk - 1) * 2 * H + h * DH, q, x < Nk);
   const Frag8 vf = load_row8(kvb + (size_t)min(x, Nk - 1) * 2 * H + H + h * DH, q, x < Nk);
@@ -151,9 +162,10 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
     kb[n] = load_col4(kvb + h * DH + 16 * n, (size_t)2 * H, 0, q, Nk - 1, x);   // K_h[key 4q+e][16n + x]
     dKa[n] = f4{0.f, 0.f, 0.f, 0.f}; dVa[n] = f4{0.f, 0.f, 0.f, 0.f};
   }
+#pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
     const int t0 = (tfirst + tt) * 16;
-    if (t0 >= nr) break;
+    if (t0 >= nr) continue;
     const int node = r0 + min(t0 + x, nr - 1);
     const bool node_ok = t0 + x < nr;
     const Frag8 qf = load_row8(Q + (size_t)node * H + h * DH, q, true);
@@ -205,26 +217,36 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
       dVa[n] = mma_acc16(pdN, gb, dVa[n]);
     }
   }
+  // combine the block's four partial tiles in LDS, then one atomicAdd per element per block
+  if (wave > 0) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { comb[wave - 1][n * 4 + r][lane] = dKa[n][r]; comb[wave - 1][8 + n * 4 + r][lane] = dVa[n][r]; }
+  }
+  __syncthreads();
+  if (wave > 0) return;
 #pragma unroll
   for (int n = 0; n < 2; ++n)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = 4 * q + r;
       if (key < Nk) {
+        const int i = n * 4 + r;
         float* dst = dKV + (size_t)(b * Nk + key) * 2 * H + h * DH + 16 * n + x;
-        atomicAdd(dst, dKa[n][r]);
-        atomicAdd(dst + H, dVa[n][r]);
+        atomicAdd(dst, dKa[n][r] + (comb[0][i][lane] + comb[1][i][lane]) + comb[2][i][lane]);
+        atomicAdd(dst + H, dVa[n][r] + (comb[0][8 + i][lane] + comb[1][8 + i][lane]) + comb[2][8 + i][lane]);
       }
     }
 }
 
 // ------------------------------------------------------------------ kg2rg forward, grid (nh, B)
 // wave w owns key tiles w, w+4, ...; scores S2^T (rows = keys 4q+r, col = query x) stay in registers.
-__global__ __launch_bounds__(256) void kg2rg_fwd_mfma_kernel(
+__global__ __launch_bounds__(64 * NW) void kg2rg_fwd_mfma_kernel(
     const float* __restrict__ Q2, const float* __restrict__ KV2, const int* __restrict__ offs,
     float* __restrict__ P2, float* __restrict__ O2, int H, int nh, int Nk, float scale, DropCfg drop) {
-  __shared__ float red[4][16];
-  __shared__ float ored[3][2][4][64];
+  __shared__ float red[NW][16];
+  __shared__ float ored[NW - 1][2][4][64];
   const int h = blockIdx.x, b = blockIdx.y;
   const int r0 = offs[b], nr = offs[b + 1] - r0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
@@ -235,9 +257,9 @@ __global__ __launch_bounds__(256) void kg2rg_fwd_mfma_kernel(
   float m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
-    const int t0 = (wave + 4 * i) * 16;
+    const int t0 = (wave + NW * i) * 16;
     s[i] = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    if (wave + 4 * i < ntiles) {
+    if (wave + NW * i < ntiles) {
       const Frag8 kf = load_row8(kv + (size_t)min(t0 + x, nr - 1) * 2 * H + h * DH, q, true);
       s[i] = mma_nt32(kf, q2f, f4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
@@ -247,7 +269,10 @@ __global__ __launch_bounds__(256) void kg2rg_fwd_mfma_kernel(
   m = group_max(m);
   if (q == 0) red[wave][x] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red[0][x], red[1][x]), fmaxf(red[2][x], red[3][x]));
+  { float mm = red[0][x];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red[w][x]);
+    m = mm; }
   __syncthreads();
   float sum = 0.f;
 #pragma unroll
@@ -257,12 +282,15 @@ __global__ __launch_bounds__(256) void kg2rg_fwd_mfma_kernel(
   sum = group_sum(sum);
   if (q == 0) red[wave][x] = sum;
   __syncthreads();
-  const float inv = 1.0f / ((red[0][x] + red[1][x]) + (red[2][x] + red[3][x]));
+  float tot = red[0][x];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) tot += red[w][x];
+  const float inv = 1.0f / tot;
   f4 o[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
-    const int t0 = (wave + 4 * i) * 16;
-    if (wave + 4 * i < ntiles) {
+    const int t0 = (wave + NW * i) * 16;
+    if (wave + NW * i < ntiles) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int t = t0 + 4 * q + r;
@@ -295,19 +323,21 @@ __global__ __launch_bounds__(256) void kg2rg_fwd_mfma_kernel(
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = o[n][r] + (ored[0][n][r][lane] + ored[1][n][r][lane]) + ored[2][n][r][lane];
+        float v = o[n][r];
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w) v += ored[w][n][r][lane];
         if (4 * q + r < Nk) O2[(size_t)(b * Nk + 4 * q + r) * H + h * DH + 16 * n + x] = v;
       }
   }
 }
 
 // ------------------------------------------------------------------ kg2rg backward, grid (nh, B)
-__global__ __launch_bounds__(256) void kg2rg_bwd_mfma_kernel(
+__global__ __launch_bounds__(64 * NW) void kg2rg_bwd_mfma_kernel(
     const float* __restrict__ Q2, const float* __restrict__ KV2, const float* __restrict__ P2,
     const float* __restrict__ dO2, const int* __restrict__ offs,
     float* __restrict__ dQ2, float* __restrict__ dKV2, int H, int nh, int Nk, float scale, DropCfg drop) {
-  __shared__ float red[4][16];
-  __shared__ float ored[3][2][4][64];
+  __shared__ float red[NW][16];
+  __shared__ float ored[NW - 1][2][4][64];
   const int h = blockIdx.x, b = blockIdx.y;
   const int r0 = offs[b], nr = offs[b + 1] - r0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
@@ -321,9 +351,9 @@ __global__ __launch_bounds__(256) void kg2rg_bwd_mfma_kernel(
   float dot = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
-    const int t0 = (wave + 4 * i) * 16;
+    const int t0 = (wave + NW * i) * 16;
     ds[i] = f4{0.f, 0.f, 0.f, 0.f}; pT[i] = f4{0.f, 0.f, 0.f, 0.f};
-    if (wave + 4 * i < ntiles) {
+    if (wave + NW * i < ntiles) {
       const Frag8 vf = load_row8(kv + (size_t)min(t0 + x, nr - 1) * 2 * H + H + h * DH, q, true);
       ds[i] = mma_nt32(vf, g2f, f4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
@@ -341,12 +371,15 @@ __global__ __launch_bounds__(256) void kg2rg_bwd_mfma_kernel(
   dot = group_sum(dot);
   if (q == 0) red[wave][x] = dot;
   __syncthreads();
-  dot = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);   // row-dot of query x
+  { float tot = red[0][x];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) tot += red[w][x];
+    dot = tot; }                                             // row-dot of query x
   f4 dq[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
-    const int t0 = (wave + 4 * i) * 16;
-    if (wave + 4 * i < ntiles) {
+    const int t0 = (wave + NW * i) * 16;
+    if (wave + NW * i < ntiles) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) ds[i][r] = pT[i][r] * (ds[i][r] - dot) * scale;
 #pragma unroll
@@ -368,7 +401,9 @@ __global__ __launch_bounds__(256) void kg2rg_bwd_mfma_kernel(
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = dq[n][r] + (ored[0][n][r][lane] + ored[1][n][r][lane]) + ored[2][n][r][lane];
+        float v = dq[n][r];
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w) v += ored[w][n][r][lane];
         if (4 * q + r < Nk) dQ2[(size_t)(b * Nk + 4 * q + r) * H + h * DH + 16 * n + x] = v;
       }
   }
@@ -383,8 +418,8 @@ __global__ __launch_bounds__(256) void kg2rg_bwd_mfma_kernel(
 #pragma unroll
   for (int r = 0; r < 4; ++r) dotq[r] = __shfl(dot, 4 * q + r, 64);  // row-dot of query 4q+r
   for (int i = 0; i < MAXT; ++i) {
-    const int t0 = (wave + 4 * i) * 16;
-    if (wave + 4 * i >= ntiles) break;
+    const int t0 = (wave + NW * i) * 16;
+    if (wave + NW * i >= ntiles) break;
     const int key = min(t0 + x, nr - 1);
     const bool key_ok = t0 + x < nr;
     const Frag8 vf = load_row8(kv + (size_t)key * 2 * H + H + h * DH, q, true);
@@ -422,14 +457,20 @@ __global__ __launch_bounds__(256) void kg2rg_bwd_mfma_kernel(
 // ------------------------------------------------------------------ launchers
 int attn_mfma_ok(int H, int nh, int Nk, int max_nr, bool kg2rg) {
   if (nh < 1 || H != nh * DH || Nk < 1 || Nk > 16) return 0;
-  if (kg2rg && max_nr > 16 * 4 * MAXT) return 0;
+  if (kg2rg && max_nr > 16 * NW * MAXT) return 0;
   return 1;
 }
 
 int launch_rg2kg_fwd_mfma(const float* Q, const float* KV, const int* offs, float* P, float* O, float* attn_avg,
-                          int B, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
-  hipLaunchKernelGGL(rg2kg_fwd_mfma_kernel, dim3((max_nr + 63) / 64, B), dim3(256), 0, stream, Q, KV, offs, P, O, attn_avg,
+                          int B, int T, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
+  const int tasks = ((max_nr + 15) / 16) * nh;
+  hipLaunchKernelGGL(rg2kg_fwd_mfma_kernel, dim3((tasks + 3) / 4, B), dim3(256), 0, stream, Q, KV, offs, P, O,
                      H, nh, Nk, 1.0f / sqrtf((float)DH), drop);
+  if (attn_avg) {
+    const int n = T * Nk;
+    hipLaunchKernelGGL(attn_avg_site_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, P, attn_avg, T, nh, Nk,
+                       (uint32_t)SITE_ATTN_RG2KG, drop);
+  }
   return (int)hipGetLastError();
 }
 
@@ -443,14 +484,14 @@ int launch_rg2kg_bwd_mfma(const float* Q, const float* KV, const float* P, const
 
 int launch_kg2rg_fwd_mfma(const float* Q2, const float* KV2, const int* offs, float* P2, float* O2, int B, int H, int nh,
                           int Nk, DropCfg drop, hipStream_t stream) {
-  hipLaunchKernelGGL(kg2rg_fwd_mfma_kernel, dim3(nh, B), dim3(256), 0, stream, Q2, KV2, offs, P2, O2, H, nh, Nk,
+  hipLaunchKernelGGL(kg2rg_fwd_mfma_kernel, dim3(nh, B), dim3(64 * NW), 0, stream, Q2, KV2, offs, P2, O2, H, nh, Nk,
                      1.0f / sqrtf((float)DH), drop);
   return (int)hipGetLastError();
 }
 
 int launch_kg2rg_bwd_mfma(const float* Q2, const float* KV2, const float* P2, const float* dO2, const int* offs, float* dQ2,
                           float* dKV2, int B, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
-  hipLaunchKernelGGL(kg2rg_bwd_mfma_kernel, dim3(nh, B), dim3(256), 0, stream, Q2, KV2, P2, dO2, offs, dQ2, dKV2, H, nh, Nk,
+  hipLaunchKernelGGL(kg2rg_bwd_mfma_kernel, dim3(nh, B), dim3(64 * NW), 0, stream, Q2, KV2, P2, dO2, offs, dQ2, dKV2, H, nh, Nk,
                      1.0f / sqrtf((float)DH), drop);
   return (int)hipGetLastError();
 }

@@ -278,7 +278,7 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
   g.nt(G, H, P[CAMO_P_A1_IN_W] + (size_t)H * H, H, P[CAMO_P_A1_IN_B] + H, w.KV, 2 * H, TK, 2 * H, H);
   g.nt(G, H, P[CAMO_P_A2_IN_W], H, P[CAMO_P_A2_IN_B], w.Q2, H, TK, H, H);
   CK(g.run(), "attention in-projections");
-  CK(launch_attn_rg2kg_fwd(w.Q, w.KV, rg_offsets, w.P, w.O, attn_rg2kg, B, max_nr, H, nh, Nk, drop, st), "attn rg2kg fwd");
+  CK(launch_attn_rg2kg_fwd(w.Q, w.KV, rg_offsets, w.P, w.O, attn_rg2kg, B, T, max_nr, H, nh, Nk, drop, st), "attn rg2kg fwd");
   CK(launch_attn_kg2rg_fwd(w.Q2, w.KV2, rg_offsets, w.P2, w.O2, B, max_nr, H, nh, Nk, drop, st), "attn kg2rg fwd");
   if (attn_kg2rg) CK(launch_attn_avg(w.P2, attn_kg2rg, T, nh, Nk, drop, st), "attn avg");
   // out-projection + residual (fusion_model.py:119,130), then LayerNorm
