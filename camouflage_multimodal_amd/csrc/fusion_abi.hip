@@ -49,8 +49,8 @@ struct Carver {
 };
 
 struct Ws {
-  // maps
-  int* row_sample; float* inv_nr;
+  // zeroed once per forward: [ means | dfused | dKV ] (accumulated into by atomics)
+  float* zero_base; size_t zero_bytes;
   // forward (saved for backward)
   float *R, *G, *Q, *KV2, *KV, *Q2, *P, *P2, *O, *O2, *U, *U2, *st1, *st2, *Y, *Y2, *H1, *H2;
   float *means, *Ymean, *H1mean, *Y2mean, *H2mean; size_t means_n;
@@ -67,7 +67,6 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
   const size_t H = d.hidden_dim, TK = (size_t)B * Nk, nh = d.num_heads, Wd = 2 * d.num_classes + 2;
   if (d.fusion_type == CAMO_FUSION_CROSS_ATTENTION) {
     const size_t Fh = H / 2;
-    w.row_sample = c.take<int>(T); w.inv_nr = c.take<float>(B);
     w.R = c.take<float>(T * H); w.G = c.take<float>(TK * H);
     w.Q = c.take<float>(T * H); w.KV2 = c.take<float>(T * 2 * H);
     w.KV = c.take<float>(TK * 2 * H); w.Q2 = c.take<float>(TK * H);
@@ -78,31 +77,42 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
     w.Y = c.take<float>(T * H); w.Y2 = c.take<float>(TK * H);
     w.H1 = c.take<float>(T * 2 * H); w.H2 = c.take<float>(TK * 2 * H);
     w.means_n = (size_t)B * 6 * H;
-    w.means = c.take<float>(w.means_n);
+    {   // one contiguous block so a single memset clears every atomically-accumulated buffer
+      const size_t nz = w.means_n + (size_t)B * H + TK * 2 * H;
+      float* z = c.take<float>(nz);
+      w.zero_base = z; w.zero_bytes = nz * sizeof(float);
+      w.means = z; w.dfused = z ? z + w.means_n : nullptr; w.dKV = z ? w.dfused + (size_t)B * H : nullptr;
+    }
     if (w.means) { w.Ymean = w.means; w.H1mean = w.Ymean + B * H; w.Y2mean = w.H1mean + B * 2 * H; w.H2mean = w.Y2mean + B * H; }
     w.comb = c.take<float>(B * 2 * H); w.F1 = c.take<float>(B * H); w.fused = c.take<float>(B * H);
     w.hid = c.take<float>(B * 4 * Fh);
-    w.dlog = c.take<float>(B * Wd); w.dhid = c.take<float>(B * 4 * Fh); w.dfused = c.take<float>(B * H);
+    w.dlog = c.take<float>(B * Wd); w.dhid = c.take<float>(B * 4 * Fh);
     w.dF1 = c.take<float>(B * H); w.dcomb = c.take<float>(B * 2 * H);
     w.dHm1 = c.take<float>(B * 2 * H); w.dHm2 = c.take<float>(B * 2 * H);
     w.dH1 = c.take<float>(T * 2 * H); w.dH2 = c.take<float>(TK * 2 * H);
     w.dY = c.take<float>(T * H); w.dY2 = c.take<float>(TK * H);
     w.dU = c.take<float>(T * H); w.dU2 = c.take<float>(TK * H);
     w.dO = c.take<float>(T * H); w.dO2 = c.take<float>(TK * H);
-    w.dQ = c.take<float>(T * H); w.dKV = c.take<float>(TK * 2 * H);
+    w.dQ = c.take<float>(T * H);
     w.dQ2 = c.take<float>(TK * H); w.dKV2 = c.take<float>(T * 2 * H);
     w.dS2 = c.take<float>(T * nh * Nk);
     w.dR = c.take<float>(T * H); w.dG = c.take<float>(TK * H);
   } else {
     const size_t F = H / 2, Fh = F / 2, Dc = (size_t)d.rg_dim + d.kg_dim;
     w.means_n = (size_t)B * Dc;
-    w.comb = c.take<float>(w.means_n);         // [B, rg_dim+kg_dim] = the two means, zeroed then accumulated
+    {
+      const size_t nz = w.means_n + (size_t)B * F;
+      float* z = c.take<float>(nz);
+      w.zero_base = z; w.zero_bytes = nz * sizeof(float);
+      w.comb = z;                                // [B, rg_dim+kg_dim] = the two means, zeroed then accumulated
+      w.dfused = z ? z + w.means_n : nullptr;
+    }
     w.means = w.comb;
     w.F1 = c.take<float>(B * H);               // a1
     w.a2 = c.take<float>(B * F);
     w.fused = c.take<float>(B * F);
     w.hid = c.take<float>(B * 4 * Fh);
-    w.dlog = c.take<float>(B * Wd); w.dhid = c.take<float>(B * 4 * Fh); w.dfused = c.take<float>(B * F);
+    w.dlog = c.take<float>(B * Wd); w.dhid = c.take<float>(B * 4 * Fh);
     w.da2 = c.take<float>(B * F); w.dF1 = c.take<float>(B * H);
   }
   c.off = (c.off + 255) & ~size_t(255);
@@ -198,17 +208,18 @@ int heads_forward(const camo_dims_t& d, const float* const* hp /*16 pointers*/, 
 
 // d_outs -> dfused (w.dfused, zeroed here) and the 16 head-parameter gradients
 int heads_backward(const camo_dims_t& d, const float* const* hp, float* const* hg, const Ws& w, int B, int F,
-                   const float* outs, const float* d_outs, const DropCfg& drop, hipStream_t st) {
+                   const float* outs, const float* d_outs, int pre_activation, const DropCfg& drop, hipStream_t st) {
   const int prec = CAMO_PREC_F32;
   const int Fh = F / 2, C = d.num_classes, Wd = 2 * C + 2;
   const int nout[4] = {C, C, 1, 1}, coff[4] = {0, C, 2 * C, 2 * C + 1};
-  CK((int)hipMemsetAsync(w.dfused, 0, sizeof(float) * (size_t)B * F, st), "memset dfused");
-  CK(launch_head_out_grad(outs, d_outs, w.dlog, B, Wd, st), "head_out_grad");
+  // (w.dfused was zeroed by the forward's memset of the workspace's zero block)
+  const float* dlog = d_outs;
+  if (!pre_activation) { CK(launch_head_out_grad(outs, d_outs, w.dlog, B, Wd, st), "head_out_grad"); dlog = w.dlog; }
   GB g(drop, prec, st);
   for (int x = 0; x < 4; ++x) {
-    GemmProb& p = g.nn(w.dlog + coff[x], Wd, hp[4 * x + 2], Fh, w.dhid + x * Fh, 4 * Fh, B, Fh, nout[x]);
+    GemmProb& p = g.nn(dlog + coff[x], Wd, hp[4 * x + 2], Fh, w.dhid + x * Fh, 4 * Fh, B, Fh, nout[x]);
     set_relu_bwd(p, w.hid + x * Fh, 4 * Fh, drop.scale);
-    g.tn(w.dlog + coff[x], Wd, w.hid + x * Fh, 4 * Fh, hg[4 * x + 2], Fh, hg[4 * x + 3], nout[x], Fh, B);
+    g.tn(dlog + coff[x], Wd, w.hid + x * Fh, 4 * Fh, hg[4 * x + 2], Fh, hg[4 * x + 3], nout[x], Fh, B);
   }
   CK(g.run(), "heads out bwd");
   for (int x = 0; x < 4; ++x) {
@@ -231,12 +242,20 @@ size_t camo_workspace_bytes(const camo_dims_t* dims, int32_t B, int32_t T, int32
   return carve(*dims, B, T, Nk, nullptr).bytes;
 }
 
+int camo_prepare_batch(const int32_t* rg_offsets, int32_t B, int32_t max_nr, int32_t* row_sample, float* inv_nr, void* stream) {
+  if (!rg_offsets || !row_sample || !inv_nr || B < 1 || max_nr < 1) return fail(CAMO_E_ARG, "bad prepare_batch arguments");
+  CK(launch_rowmap(rg_offsets, row_sample, inv_nr, B, max_nr, static_cast<hipStream_t>(stream)), "rowmap");
+  return 0;
+}
+
 int camo_forward(const camo_dims_t* dims, const float* const* params, const float* rg, const int32_t* rg_offsets,
+                 const int32_t* row_sample, const float* inv_nr,
                  const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace,
                  size_t workspace_bytes, float* outs, float* attn_rg2kg, float* attn_kg2rg, int32_t training,
                  uint64_t seed, int32_t precision, void* stream) {
   if (int e = check_dims(dims, B, T, Nk)) return e;
-  if (!params || !rg || !rg_offsets || !kg || !workspace || !outs) return fail(CAMO_E_ARG, "null pointer argument");
+  if (!params || !rg || !rg_offsets || !row_sample || !inv_nr || !kg || !workspace || !outs)
+    return fail(CAMO_E_ARG, "null pointer argument");
   if (max_nr < 1 || max_nr > T) return fail(CAMO_E_ARG, "max_nr out of range");
   if (precision != CAMO_PREC_F32 && precision != CAMO_PREC_BF16) return fail(CAMO_E_ARG, "unknown precision");
   const camo_dims_t& d = *dims;
@@ -248,11 +267,12 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
   const float* const* P = params;
   GB g(drop, precision, st);
   GB gt(drop, CAMO_PREC_F32, st);   // per-sample (B-row) GEMMs
+  // one memset for everything this step accumulates into with atomics (means now, dfused/dKV in backward)
+  CK((int)hipMemsetAsync(w.zero_base, 0, w.zero_bytes, st), "memset zero block");
 
   if (d.fusion_type == CAMO_FUSION_LATE) {
     // LateFusion.forward, fusion_model.py:164-171
     const int F = H / 2, Dc = D + Dk;
-    CK((int)hipMemsetAsync(w.means, 0, sizeof(float) * w.means_n, st), "memset means");
     SegMean sm[2] = {{rg, D, D, rg_offsets, 0, w.comb, Dc}, {kg, Dk, Dk, nullptr, Nk, w.comb + D, Dc}};
     CK(launch_seg_mean(sm, 2, B, max_nr > Nk ? max_nr : Nk, st), "late means");
     set_drop(gt.nt(w.comb, Dc, P[CAMO_PL_W0], Dc, P[CAMO_PL_B0], w.F1, H, B, H, Dc, GF_RELU), SITE_LATE0);
@@ -265,7 +285,6 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
   }
 
   // ---- CrossAttentionFusion.forward, fusion_model.py:75-146
-  CK(launch_rowmap(rg_offsets, w.row_sample, w.inv_nr, B, max_nr, st), "rowmap");
   const float* R = rg; const float* G = kg;
   if (P[CAMO_P_RG_PROJ_W]) { g.nt(rg, D, P[CAMO_P_RG_PROJ_W], D, P[CAMO_P_RG_PROJ_B], w.R, H, T, H, D); R = w.R; }
   else if (D != H) return fail(CAMO_E_ARG, "rg_proj weight missing but rg_dim != hidden_dim");
@@ -295,7 +314,6 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
   set_drop(g.nt(w.Y2, H, P[CAMO_P_F2_W0], H, P[CAMO_P_F2_B0], w.H2, 2 * H, TK, 2 * H, H, GF_RELU), SITE_FFN_KG);
   CK(g.run(), "ffn layer 0");
   // per-sample means of Y and H1d, then the second FFN layer on the means (mean-pool linearity)
-  CK((int)hipMemsetAsync(w.means, 0, sizeof(float) * w.means_n, st), "memset means");
   {
     SegMean sm[4] = {{w.Y, H, H, rg_offsets, 0, w.Ymean, H}, {w.H1, 2 * H, 2 * H, rg_offsets, 0, w.H1mean, 2 * H},
                      {w.Y2, H, H, nullptr, Nk, w.Y2mean, H}, {w.H2, 2 * H, 2 * H, nullptr, Nk, w.H2mean, 2 * H}};
@@ -313,11 +331,12 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
 }
 
 int camo_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
-                  const int32_t* rg_offsets, const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr,
-                  void* workspace, size_t workspace_bytes, const float* outs, const float* d_outs,
-                  int32_t training, uint64_t seed, int32_t precision, void* stream) {
+                  const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr, const float* kg, int32_t B,
+                  int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes, const float* outs,
+                  const float* d_outs, int32_t d_outs_pre_activation, int32_t training, uint64_t seed, int32_t precision,
+                  void* stream) {
   if (int e = check_dims(dims, B, T, Nk)) return e;
-  if (!params || !grads || !rg || !rg_offsets || !kg || !workspace || !outs || !d_outs)
+  if (!params || !grads || !rg || !rg_offsets || !row_sample || !inv_nr || !kg || !workspace || !outs || !d_outs)
     return fail(CAMO_E_ARG, "null pointer argument");
   if (max_nr < 1 || max_nr > T) return fail(CAMO_E_ARG, "max_nr out of range");
   if (precision != CAMO_PREC_F32 && precision != CAMO_PREC_BF16) return fail(CAMO_E_ARG, "unknown precision");
@@ -334,7 +353,7 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
 
   if (d.fusion_type == CAMO_FUSION_LATE) {
     const int F = H / 2, Dc = D + Dk;
-    if (int e = heads_backward(d, P + CAMO_PL_HEADS, Gr + CAMO_PL_HEADS, w, B, F, outs, d_outs, drop, st)) return e;
+    if (int e = heads_backward(d, P + CAMO_PL_HEADS, Gr + CAMO_PL_HEADS, w, B, F, outs, d_outs, d_outs_pre_activation, drop, st)) return e;
     set_relu_bwd(gt.nn(w.dfused, F, P[CAMO_PL_W6], F, w.da2, F, B, F, F), w.a2, F, drop.scale);
     gt.tn(w.dfused, F, w.a2, F, Gr[CAMO_PL_W6], F, Gr[CAMO_PL_B6], F, F, B);
     CK(gt.run(), "late fc6 bwd");
@@ -349,8 +368,7 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
   const bool has_rgp = P[CAMO_P_RG_PROJ_W] != nullptr, has_kgp = P[CAMO_P_KG_PROJ_W] != nullptr;
   const float* R = has_rgp ? w.R : rg;
   const float* G = has_kgp ? w.G : kg;
-  if (int e = heads_backward(d, P + CAMO_P_HEADS, Gr + CAMO_P_HEADS, w, B, H, outs, d_outs, drop, st)) return e;
-  CK((int)hipMemsetAsync(w.dKV, 0, sizeof(float) * (size_t)TK * 2 * H, st), "memset dKV");
+  if (int e = heads_backward(d, P + CAMO_P_HEADS, Gr + CAMO_P_HEADS, w, B, H, outs, d_outs, d_outs_pre_activation, drop, st)) return e;
   // fusion layer
   set_relu_bwd(gt.nn(w.dfused, H, P[CAMO_P_FU_W3], H, w.dF1, H, B, H, H), w.F1, H, drop.scale);
   gt.tn(w.dfused, H, w.F1, H, Gr[CAMO_P_FU_W3], H, Gr[CAMO_P_FU_B3], H, H, B);
@@ -365,12 +383,12 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
   gt.tn(w.dcomb + H, 2 * H, w.H2mean, 2 * H, Gr[CAMO_P_F2_W3], 2 * H, Gr[CAMO_P_F2_B3], H, 2 * H, B);
   CK(gt.run(), "ffn layer 3 bwd (pooled)");
   {
-    BcastSeg s0{w.H1, w.dHm1, 2 * H, w.row_sample, w.inv_nr, 0, w.dH1, T};
+    BcastSeg s0{w.H1, w.dHm1, 2 * H, row_sample, inv_nr, 0, w.dH1, T};
     BcastSeg s1{w.H2, w.dHm2, 2 * H, nullptr, nullptr, Nk, w.dH2, TK};
     CK(launch_relu_bcast_bwd(s0, s1, 2 * H, drop.scale, st), "relu bcast bwd");
   }
   // first FFN layer: dY = bcast(dpool)/n + dH1.W1 ; dW1 += dH1^T.Y
-  set_bcast(g.nn(w.dH1, 2 * H, P[CAMO_P_F1_W0], H, w.dY, H, T, H, 2 * H), w.dcomb, 2 * H, w.row_sample, w.inv_nr, 0);
+  set_bcast(g.nn(w.dH1, 2 * H, P[CAMO_P_F1_W0], H, w.dY, H, T, H, 2 * H), w.dcomb, 2 * H, row_sample, inv_nr, 0);
   set_bcast(g.nn(w.dH2, 2 * H, P[CAMO_P_F2_W0], H, w.dY2, H, TK, H, 2 * H), w.dcomb + H, 2 * H, nullptr, nullptr, Nk);
   g.tn(w.dH1, 2 * H, w.Y, H, Gr[CAMO_P_F1_W0], H, Gr[CAMO_P_F1_B0], 2 * H, H, T);
   g.tn(w.dH2, 2 * H, w.Y2, H, Gr[CAMO_P_F2_W0], H, Gr[CAMO_P_F2_B0], 2 * H, H, TK);
@@ -407,10 +425,10 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
 }
 
 int camo_loss(const float* outs, const int64_t* y, const float* e, const float* s, int32_t B, int32_t num_classes,
-              float* loss_terms, float* d_outs, int32_t* pred, void* stream) {
-  if (!outs || !y || !e || !s || !loss_terms || !d_outs) return fail(CAMO_E_ARG, "null pointer argument");
+              float* loss_terms, float* d_outs, float* d_pre, int32_t* pred, void* stream) {
+  if (!outs || !y || !e || !s || !loss_terms) return fail(CAMO_E_ARG, "null pointer argument");
   if (B < 1 || num_classes < 2) return fail(CAMO_E_ARG, "need B >= 1 and num_classes >= 2");
-  CK(launch_loss(outs, reinterpret_cast<const long long*>(y), e, s, B, num_classes, loss_terms, d_outs, pred,
+  CK(launch_loss(outs, reinterpret_cast<const long long*>(y), e, s, B, num_classes, loss_terms, d_outs, d_pre, pred,
                  static_cast<hipStream_t>(stream)), "loss");
   return 0;
 }
@@ -421,11 +439,11 @@ int camo_grad_sumsq(const float* g, size_t n, float* sumsq, void* stream) {
   return 0;
 }
 
-int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, const float* sumsq, float max_norm, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sumsq, float max_norm, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int32_t step, int32_t zero_grads, void* stream) {
   if (!p || !g || !m || !v || !sumsq || n == 0) return fail(CAMO_E_ARG, "null pointer or empty buffer");
   if (step < 1) return fail(CAMO_E_ARG, "step is 1-based");
-  CK(launch_clip_adamw(p, g, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step,
+  CK(launch_clip_adamw(p, g, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step, zero_grads,
                        static_cast<hipStream_t>(stream)), "clip+adamw");
   return 0;
 }

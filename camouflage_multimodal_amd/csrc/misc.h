@@ -18,7 +18,7 @@ int launch_seg_mean(const SegMean* segs, int nseg, int B, int max_rows, hipStrea
 int launch_relu_bcast_bwd(const BcastSeg& s0, const BcastSeg& s1, int C, float scale, hipStream_t stream);
 int launch_head_out_grad(const float* outs, const float* d_outs, float* d_logits, int B, int W, hipStream_t stream);
 int launch_loss(const float* outs, const long long* y, const float* e, const float* s, int B, int C,
-                float* terms, float* d_outs, int* pred, hipStream_t stream);
+                float* terms, float* d_outs, float* d_pre, int* pred, hipStream_t stream);
 int launch_sumsq(const float* g, size_t n, float* out, hipStream_t stream);
-int launch_clip_adamw(float* p, float* g, float* m, float* v, size_t n, const float* sumsq, float max_norm,
-                      float lr, float b1, float b2, float eps, float wd, int step, hipStream_t stream);
+int launch_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sumsq, float max_norm,
+                      float lr, float b1, float b2, float eps, float wd, int step, int zero_grads, hipStream_t stream);

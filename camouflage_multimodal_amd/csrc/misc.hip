@@ -156,12 +156,17 @@ __global__ void head_out_grad_kernel(const float* __restrict__ outs, const float
 // (train_multimodal.py:29-57, 256-268), each at batch size 1.
 __global__ void loss_kernel(const float* __restrict__ outs, const long long* __restrict__ y,
                             const float* __restrict__ e, const float* __restrict__ s, int B, int C,
-                            float* __restrict__ terms, float* __restrict__ d_outs, int* __restrict__ pred) {
+                            float* __restrict__ terms, float* __restrict__ d_outs, float* __restrict__ d_pre,
+                            int* __restrict__ pred) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int W = 2 * C + 2;
   const float* o = outs + (size_t)b * W;
-  float* d = d_outs + (size_t)b * W;
+  const float sc = o[W - 1];
+  auto put = [&](int k, float val) {        // gradient w.r.t. output k; d_pre: score column w.r.t. the pre-sigmoid value
+    if (d_outs) d_outs[(size_t)b * W + k] = val;
+    if (d_pre) d_pre[(size_t)b * W + k] = (k == W - 1) ? val * sc * (1.0f - sc) : val;
+  };
   const int yb = (int)y[b];
   // focal on mask logits
   {
@@ -177,7 +182,7 @@ __global__ void loss_kernel(const float* __restrict__ outs, const long long* __r
     const float dl_dpt = at * (-3.0f * om * om * ce - om * om * om / pt);
     for (int k = 0; k < C; ++k) {
       const float pk = expf(o[k] - mx) / z;
-      d[k] = 3.0f * dl_dpt * pt * ((k == yb ? 1.0f : 0.0f) - pk);
+      put(k, 3.0f * dl_dpt * pt * ((k == yb ? 1.0f : 0.0f) - pk));
     }
     if (pred) pred[b] = am;
   }
@@ -189,23 +194,24 @@ __global__ void loss_kernel(const float* __restrict__ outs, const long long* __r
     float z = 0.f;
     for (int k = 0; k < C; ++k) z += expf(oi[k] - mx);
     terms[4 * b + 1] = -(oi[yb] - mx - logf(z));
-    for (int k = 0; k < C; ++k) d[C + k] = expf(oi[k] - mx) / z - (k == yb ? 1.0f : 0.0f);
+    for (int k = 0; k < C; ++k) put(C + k, expf(oi[k] - mx) / z - (k == yb ? 1.0f : 0.0f));
   }
   // BCE with logits on edge
   {
     const float x = o[2 * C], t = e[b];
     terms[4 * b + 2] = 0.5f * (fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))));
-    d[2 * C] = 0.5f * (1.0f / (1.0f + expf(-x)) - t);
+    put(2 * C, 0.5f * (1.0f / (1.0f + expf(-x)) - t));
   }
   // MSE on the (post-sigmoid) score
   {
     const float x = o[2 * C + 1], t = s[b];
     terms[4 * b + 3] = 0.3f * (x - t) * (x - t);
-    d[2 * C + 1] = 0.6f * (x - t);
+    put(2 * C + 1, 0.6f * (x - t));
   }
 }
 
 // ---------------------------------------------------------------- optimizer
+constexpr int SUMSQ_BLOCKS = 256;
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ out) {
   __shared__ float red[4];
   float acc = 0.f;
@@ -220,30 +226,46 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+  if (threadIdx.x == 0) out[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // clip_grad_norm_(max_norm) then AdamW (torch semantics: decoupled decay first,
 // denom = sqrt(v)/sqrt(bc2) + eps, p -= lr/bc1 * m/denom)
 __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, size_t n,
-                                                         const float* __restrict__ sumsq, float max_norm, float lr,
+                                                         float* __restrict__ sumsq, float max_norm, float lr,
                                                          float b1, float b2, float eps, float wd,
-                                                         float inv_bc1, float inv_sqrt_bc2) {
-  const float norm = sqrtf(*sumsq);
-  const float coef = fminf(1.0f, max_norm / (norm + 1e-6f));
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const float gi = g[i] * coef;
-    g[i] = gi;
-    float pi = p[i] * (1.0f - lr * wd);
-    const float mi = m[i] * b1 + gi * (1.0f - b1);
-    const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    pi -= lr * inv_bc1 * (mi / denom);
-    p[i] = pi;
+                                                         float inv_bc1, float inv_sqrt_bc2, int zero_grads) {
+  __shared__ float red[4];
+  {
+    const float part = wave_sum(sumsq[1 + threadIdx.x]);      // SUMSQ_BLOCKS == blockDim.x partials
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
   }
+  const float total = (red[0] + red[1]) + (red[2] + red[3]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) sumsq[0] = total;
+  const float coef = fminf(1.0f, max_norm / (sqrtf(total) + 1e-6f));
+  const float decay = 1.0f - lr * wd, step = lr * inv_bc1, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                    reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  const size_t n4 = al ? n / 4 : 0;
+  float4* p4 = reinterpret_cast<float4*>(p); float4* g4 = reinterpret_cast<float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
+  auto upd = [&](float& pi, float& gi, float& mi, float& vi) {
+    gi *= coef;
+    pi *= decay;
+    mi = mi * b1 + gi * omb1;
+    vi = vi * b2 + gi * gi * omb2;
+    pi -= step * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    if (zero_grads) gi = 0.f;
+  };
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+    upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+    p4[i] = pp; g4[i] = gg; m4[i] = mm; v4[i] = vv;
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) upd(p[i], g[i], m[i], v[i]);
 }
 
 }  // namespace
@@ -295,28 +317,23 @@ int launch_head_out_grad(const float* outs, const float* d_outs, float* d_logits
 }
 
 int launch_loss(const float* outs, const long long* y, const float* e, const float* s, int B, int C,
-                float* terms, float* d_outs, int* pred, hipStream_t stream) {
-  hipLaunchKernelGGL(loss_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, outs, y, e, s, B, C, terms, d_outs, pred);
+                float* terms, float* d_outs, float* d_pre, int* pred, hipStream_t stream) {
+  hipLaunchKernelGGL(loss_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, outs, y, e, s, B, C, terms, d_outs, d_pre, pred);
   return (int)hipGetLastError();
 }
 
 int launch_sumsq(const float* g, size_t n, float* out, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
-  size_t nb = (n / 4 + 255) / 256;
-  if (nb < 1) nb = 1;
-  if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, stream, g, n, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, g, n, out);
   return (int)hipGetLastError();
 }
 
-int launch_clip_adamw(float* p, float* g, float* m, float* v, size_t n, const float* sumsq, float max_norm,
-                      float lr, float b1, float b2, float eps, float wd, int step, hipStream_t stream) {
+int launch_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sumsq, float max_norm,
+                      float lr, float b1, float b2, float eps, float wd, int step, int zero_grads, hipStream_t stream) {
   const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
-  size_t nb = (n + 255) / 256;
+  size_t nb = (n / 4 + 255) / 256;
   if (nb < 1) nb = 1;
-  if (nb > 2048) nb = 2048;
+  if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(clip_adamw_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p, g, m, v, n, sumsq, max_norm, lr,
-                     b1, b2, eps, wd, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+                     b1, b2, eps, wd, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), zero_grads);
   return (int)hipGetLastError();
 }

@@ -37,10 +37,10 @@ def _ptr(t):
 
 class Batch:
     """A packed minibatch on the device, ready for the C ABI."""
-    __slots__ = ("rg", "kg", "offsets", "nrs", "B", "T", "Nk", "max_nr")
+    __slots__ = ("rg", "kg", "offsets", "row_sample", "inv_nr", "nrs", "B", "T", "Nk", "max_nr")
 
-    def __init__(self, rg, kg, offsets, nrs):
-        self.rg, self.kg, self.offsets, self.nrs = rg, kg, offsets, nrs
+    def __init__(self, rg, kg, offsets, row_sample, inv_nr, nrs):
+        self.rg, self.kg, self.offsets, self.row_sample, self.inv_nr, self.nrs = rg, kg, offsets, row_sample, inv_nr, nrs
         self.B, self.T, self.Nk, self.max_nr = len(nrs), rg.shape[0], kg.shape[1], max(nrs)
 
 
@@ -147,15 +147,21 @@ class FusionEngine:
         rg_packed = rg_packed.detach().to(torch.float32).contiguous()
         kg = kg.detach().to(torch.float32).contiguous()
         key = tuple(nrs)
-        offs = self._offsets_cache.get(key)
-        if offs is None:
-            if len(self._offsets_cache) > 4096:
+        desc = self._offsets_cache.get(key)
+        if desc is None:
+            # batch descriptor (row offsets, row -> sample map, 1/Nr): built once per distinct shape tuple
+            if len(self._offsets_cache) > 1024:
                 self._offsets_cache.clear()
             host = torch.zeros(B + 1, dtype=torch.int32)
             host[1:] = torch.tensor(nrs, dtype=torch.int32).cumsum(0)
             offs = host.to(rg_packed.device, non_blocking=False)
-            self._offsets_cache[key] = offs
-        return Batch(rg_packed, kg, offs, nrs)
+            row_sample = torch.empty(sum(nrs), dtype=torch.int32, device=rg_packed.device)
+            inv_nr = torch.empty(B, dtype=torch.float32, device=rg_packed.device)
+            _lib.check(_lib.lib().camo_prepare_batch(_ptr(offs), B, max(nrs), _ptr(row_sample), _ptr(inv_nr), _stream_ptr()),
+                       "camo_prepare_batch")
+            desc = (offs, row_sample, inv_nr)
+            self._offsets_cache[key] = desc
+        return Batch(rg_packed, kg, desc[0], desc[1], desc[2], nrs)
 
     def workspace(self, batch, private=False):
         need = _lib.lib().camo_workspace_bytes(C.byref(self.dims), batch.B, batch.T, batch.Nk)
@@ -180,17 +186,18 @@ class FusionEngine:
         if want_attention and self.cross:
             a1 = torch.empty(batch.T, batch.Nk, dtype=torch.float32, device=batch.rg.device)
             a2 = torch.empty(batch.T, batch.Nk, dtype=torch.float32, device=batch.rg.device)
-        rc = _lib.lib().camo_forward(C.byref(self.dims), self._ptab, _ptr(batch.rg), _ptr(batch.offsets), _ptr(batch.kg),
-                                     batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs),
+        rc = _lib.lib().camo_forward(C.byref(self.dims), self._ptab, _ptr(batch.rg), _ptr(batch.offsets),
+                                     _ptr(batch.row_sample), _ptr(batch.inv_nr), _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs),
                                      _ptr(a1), _ptr(a2), int(bool(training)), seed, _PREC[mod.precision], _stream_ptr())
         _lib.check(rc, "camo_forward")
         return outs, ((a1, a2) if a1 is not None else None)
 
-    def backward_raw(self, batch, ws, outs, d_outs, training, seed, gtab):
+    def backward_raw(self, batch, ws, outs, d_outs, training, seed, gtab, pre_activation=False):
         mod = self.module()
         rc = _lib.lib().camo_backward(C.byref(self.dims), self._ptab, gtab, _ptr(batch.rg), _ptr(batch.offsets),
-                                      _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(),
-                                      _ptr(outs), _ptr(d_outs), int(bool(training)), seed, _PREC[mod.precision],
+                                      _ptr(batch.row_sample), _ptr(batch.inv_nr), _ptr(batch.kg), batch.B, batch.T,
+                                      batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs), _ptr(d_outs),
+                                      int(bool(pre_activation)), int(bool(training)), seed, _PREC[mod.precision],
                                       _stream_ptr())
         _lib.check(rc, "camo_backward")
 

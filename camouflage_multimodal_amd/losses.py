@@ -20,9 +20,11 @@ from .engine import _ptr, _stream_ptr
 LOSS_WEIGHTS = dict(mask=3.0, instance=1.0, edge=0.5, score=0.3)   # train_multimodal.py:257,260,263,266
 
 
-def multitask_loss(outs, mask_label, edge_label, score_label, num_classes=2, want_pred=True):
+def multitask_loss(outs, mask_label, edge_label, score_label, num_classes=2, want_pred=True, pre_activation=False):
     """outs [B, 2C+2] (as FusionEngine.forward_raw returns them); labels: int64 [B], float [B], float [B].
-    Returns (loss_terms [B,4] weighted, d_outs [B,2C+2], pred int32 [B])."""
+    Returns (loss_terms [B,4] weighted, d_outs [B,2C+2], pred int32 [B]).  With ``pre_activation`` the
+    score column of d_outs is taken w.r.t. the score head's pre-sigmoid value (what
+    ``FusionEngine.backward_raw(..., pre_activation=True)`` expects)."""
     _lib.require_device(outs, "outs")
     B = outs.shape[0]
     dev = outs.device
@@ -32,7 +34,8 @@ def multitask_loss(outs, mask_label, edge_label, score_label, num_classes=2, wan
     terms = torch.empty(B, 4, dtype=torch.float32, device=dev)
     d_outs = torch.empty_like(outs)
     pred = torch.empty(B, dtype=torch.int32, device=dev) if want_pred else None
-    rc = _lib.lib().camo_loss(_ptr(outs), _ptr(y), _ptr(e), _ptr(s), B, num_classes, _ptr(terms), _ptr(d_outs),
+    rc = _lib.lib().camo_loss(_ptr(outs), _ptr(y), _ptr(e), _ptr(s), B, num_classes, _ptr(terms),
+                              _ptr(None if pre_activation else d_outs), _ptr(d_outs if pre_activation else None),
                               _ptr(pred), _stream_ptr())
     _lib.check(rc, "camo_loss")
     return terms, d_outs, pred

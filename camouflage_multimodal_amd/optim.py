@@ -39,7 +39,7 @@ class FusedClipAdamW:
         if self._m is None or self._m.data_ptr() == 0 or self._m.device != p.device or self._m.numel() != p.numel():
             self._m = torch.zeros_like(p)
             self._v = torch.zeros_like(p)
-            self._sumsq = torch.zeros(1, dtype=torch.float32, device=p.device)
+            self._sumsq = torch.zeros(_lib.SUMSQ_FLOATS, dtype=torch.float32, device=p.device)
         return self._m, self._v, self._sumsq
 
     def zero_grad(self):
@@ -49,9 +49,11 @@ class FusedClipAdamW:
         self.lr = cosine_warm_restarts_lr(self.base_lr, epoch, T_0, T_mult)
         return self.lr
 
-    def step(self, allreduce=None):
+    def step(self, allreduce=None, zero_grads=False):
         """``allreduce``: optional callable applied to the flat gradient buffer before the norm
-        (data-parallel SUM, see ddp.py).  Returns nothing; ``grad_norm()`` reads the norm lazily."""
+        (data-parallel SUM, see ddp.py).  ``zero_grads``: clear the gradient buffer in the same pass
+        (the next minibatch's ``zero_grad()`` fused in) instead of leaving the clipped gradients in
+        it.  Returns nothing; ``grad_norm()`` reads the norm lazily."""
         eng = self.engine
         _lib.require_device(eng.flat_params, "model parameters")
         g = eng.ensure_flat_grads()
@@ -64,11 +66,11 @@ class FusedClipAdamW:
         _lib.check(L.camo_grad_sumsq(_ptr(g), g.numel(), _ptr(ss), st), "camo_grad_sumsq")
         _lib.check(L.camo_clip_adamw(_ptr(eng.flat_params), _ptr(g), _ptr(m), _ptr(v), g.numel(), _ptr(ss),
                                      self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
-                                     self.weight_decay, self.step_count, st), "camo_clip_adamw")
+                                     self.weight_decay, self.step_count, int(bool(zero_grads)), st), "camo_clip_adamw")
 
     def grad_norm(self):
         """Pre-clip global gradient norm of the last step (device tensor)."""
-        return self._state()[2].sqrt()
+        return self._state()[2][:1].sqrt()
 
     # ---- checkpoint interchange with torch.optim.AdamW (train_multimodal.py:467) -------------------
     def state_dict(self):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CAMO_ABI_VERSION 1
+#define CAMO_ABI_VERSION 2
 
 enum {
   CAMO_OK = 0,
@@ -93,6 +93,8 @@ size_t camo_workspace_bytes(const camo_dims_t* dims, int32_t B, int32_t T, int32
  * (:86-105, done by the host).
  *   rg          [T, rg_dim]           packed RG node embeddings
  *   rg_offsets  int32 [B+1]           device; rg_offsets[0]=0, rg_offsets[B]=T, every Nr_b >= 1
+ *   row_sample  int32 [T]             device; sample index of every packed RG row  } derived from rg_offsets by
+ *   inv_nr      float [B]             device; 1 / Nr_b                             } camo_prepare_batch()
  *   kg          [B*Nk, kg_dim]
  *   max_nr      host value: max_b Nr_b (grid sizing only)
  *   outs        [B, 2*num_classes+2]  = mask logits | instance logits | edge logit | sigmoid(score)
@@ -102,9 +104,12 @@ size_t camo_workspace_bytes(const camo_dims_t* dims, int32_t B, int32_t T, int32
  *   training    0: eval (no dropout); 1: train, dropout p = dims->dropout with the
  *               counter-based mask of (seed, site, element index)
  */
+int camo_prepare_batch(const int32_t* rg_offsets, int32_t B, int32_t max_nr,
+                       int32_t* row_sample, float* inv_nr, void* stream);
+
 int camo_forward(const camo_dims_t* dims, const float* const* params,
-                 const float* rg, const int32_t* rg_offsets, const float* kg,
-                 int32_t B, int32_t T, int32_t Nk, int32_t max_nr,
+                 const float* rg, const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr,
+                 const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr,
                  void* workspace, size_t workspace_bytes,
                  float* outs, float* attn_rg2kg, float* attn_kg2rg,
                  int32_t training, uint64_t seed, int32_t precision, void* stream);
@@ -115,12 +120,14 @@ int camo_forward(const camo_dims_t* dims, const float* const* params,
  * (the reference sums gradients over the samples of a minibatch,
  * train_multimodal.py:239-279).  Inputs carry no gradient in the reference, so
  * none is produced.  Arguments as camo_forward; `workspace` is the one that
- * call filled. */
+ * call filled.  d_outs is d(loss)/d(outs); with d_outs_pre_activation = 1 its last
+ * column is instead taken w.r.t. the score head's pre-sigmoid value (what camo_loss's
+ * d_pre output holds), which saves the conversion pass. */
 int camo_backward(const camo_dims_t* dims, const float* const* params, float* const* grads,
-                  const float* rg, const int32_t* rg_offsets, const float* kg,
-                  int32_t B, int32_t T, int32_t Nk, int32_t max_nr,
+                  const float* rg, const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr,
+                  const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr,
                   void* workspace, size_t workspace_bytes,
-                  const float* outs, const float* d_outs,
+                  const float* outs, const float* d_outs, int32_t d_outs_pre_activation,
                   int32_t training, uint64_t seed, int32_t precision, void* stream);
 
 /* ---- loss ----------------------------------------------------------------
@@ -129,24 +136,28 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
  * + 1.0*cross_entropy(instance, y) + 0.5*BCEWithLogits(edge, e) + 0.3*MSE(score, s)
  * each evaluated at batch size 1 as the reference loop does, so the batch loss is
  * the SUM over samples.  Writes loss_terms [B,4] (already weighted), d_outs
- * [B, 2C+2] = d(sum of losses)/d(outs) and pred [B] = argmax(mask logits) (:273).
- *   y int64 [B]; e, s float [B]. */
+ * [B, 2C+2] = d(sum of losses)/d(outs), optionally d_pre (same, but the score column taken
+ * w.r.t. the pre-sigmoid value) and pred [B] = argmax(mask logits) (:273).
+ *   y int64 [B]; e, s float [B]; d_outs, d_pre, pred may each be NULL. */
 int camo_loss(const float* outs, const int64_t* y, const float* e, const float* s,
               int32_t B, int32_t num_classes,
-              float* loss_terms, float* d_outs, int32_t* pred, void* stream);
+              float* loss_terms, float* d_outs, float* d_pre, int32_t* pred, void* stream);
 
 /* ---- optimizer -----------------------------------------------------------
  * clip_grad_norm_(params, 1.0) + AdamW.step (train_multimodal.py:278-279,
  * :403-407) over flat buffers of n floats.
- * camo_grad_sumsq: *sumsq = sum(g*g) (overwrites).  Between the two calls a
- * data-parallel caller all-reduces g (SUM) -- see ddp.py.
- * camo_clip_adamw: coef = min(1, max_norm/(sqrt(*sumsq)+1e-6)); g <- g*coef (in place, as
- * the reference leaves clipped grads behind); decoupled weight decay; Adam moments;
- * bias correction with `step` (1-based). */
+ * `sumsq` is a caller-owned buffer of CAMO_SUMSQ_FLOATS floats.
+ * camo_grad_sumsq: per-block partial sums of g*g into sumsq[1..] (plain stores: no memset, no
+ *   atomics, deterministic).  A data-parallel caller all-reduces g (SUM) BEFORE this call -- see ddp.py.
+ * camo_clip_adamw: norm = sqrt(sum of the partials) (also written to sumsq[0] for the host);
+ *   coef = min(1, max_norm/(norm+1e-6)); g <- g*coef in place, as the reference leaves clipped
+ *   grads behind -- or g <- 0 when zero_grads != 0 (the next minibatch's zero_grad() fused in);
+ *   decoupled weight decay; Adam moments; bias correction with `step` (1-based). */
+#define CAMO_SUMSQ_FLOATS 257
 int camo_grad_sumsq(const float* g, size_t n, float* sumsq, void* stream);
-int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, const float* sumsq,
+int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sumsq,
                     float max_norm, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, int32_t step, void* stream);
+                    float weight_decay, int32_t step, int32_t zero_grads, void* stream);
 
 /* ---- testing hooks ---------------------------------------------------------
  * Not part of the operator surface; used by tests/ to check kernels in isolation.

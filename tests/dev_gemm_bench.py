@@ -23,12 +23,16 @@ def bench(M, N, K, flags, prec, iters=20):
     us = e0.elapsed_time(e1) * 1e3 / iters
     print(f"M={M:6d} N={N:5d} K={K:5d} flags={flags:3d} prec={'bf16' if prec else 'f32 '}: {us:9.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s")
 
+import sys
 for prec in (1,):
-    for K in (32, 64, 128, 256, 512, 1024):
-        bench(65, 128, K, 0, prec, 50)
-    for K in (32, 64, 128, 256, 512, 1024):
-        bench(64 * 256, 128, K, 0, prec, 50)
-    for K in (32, 128, 256, 512):
-        bench(64 * 128, 256, K, 0, prec, 50)
-    bench(7700, 256, 128, 0, prec, 50)
-    bench(7700, 768, 256, 0, prec, 50)
+    bench(7700, 256, 128, 0, prec, 20)
+    bench(7700, 768, 256, 0, prec, 20)
+    bench(7700, 256, 256, 0, prec, 20)
+    bench(7700, 512, 256, 0, prec, 20)
+    bench(7700, 256, 512, BKM, prec, 20)
+    bench(7700, 256, 256, BKM, prec, 20)
+    bench(512, 256, 7700, AKM | BKM | ATOMIC, prec, 20)
+    bench(256, 256, 7700, AKM | BKM | ATOMIC, prec, 20)
+    bench(256, 128, 7700, AKM | BKM | ATOMIC, prec, 20)
+    bench(64 * 254, 128, 32, 0, prec, 20)
+    bench(64 * 254, 128, 64, 0, prec, 20)

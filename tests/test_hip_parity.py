@@ -86,7 +86,7 @@ def _native_replay(name, precision="f32", steps=2):
     from camouflage_multimodal_amd import NativeTrainer
     cfg, seed, nrs, nk, kg_fixed, full = train_case(name)
     m = make_model(cfg, seed, precision).train()
-    tr = NativeTrainer(m, lr=5e-4, weight_decay=1e-4)
+    tr = NativeTrainer(m, lr=5e-4, weight_decay=1e-4, keep_grads=True)
     orc = FO.FusionOracle(cfg, OP.make_params(cfg, seed))
     oopt = FO.AdamW(orc.p, lr=5e-4, weight_decay=1e-4)
     real = {}
@@ -169,7 +169,7 @@ def test_train_mode_dropout_matches_oracle_masks(name):
     cfg, seed, nrs, nk, kg_fixed, _ = train_case(name)
     cfg = dict(cfg, dropout=0.3)
     m = make_model(cfg, seed).train()
-    tr = NativeTrainer(m)
+    tr = NativeTrainer(m, keep_grads=True)
     orc = FO.FusionOracle(cfg, OP.make_params(cfg, seed))
     rg, kg, y, e, s = train_batch(cfg, seed, nrs, nk, kg_fixed, 0)
     dseed = 0x0123456789ABCDEF
@@ -271,7 +271,7 @@ def test_bf16_training_step_close_to_oracle():
     from camouflage_multimodal_amd import NativeTrainer
     cfg, seed, nrs, nk, kg_fixed, _ = train_case("default")
     m = make_model(cfg, seed, "bf16").train()
-    tr = NativeTrainer(m)
+    tr = NativeTrainer(m, keep_grads=True)
     orc = FO.FusionOracle(cfg, OP.make_params(cfg, seed))
     rg, kg, y, e, s = train_batch(cfg, seed, nrs, nk, kg_fixed, 0)
     ref = FO.train_step(orc, FO.AdamW(orc.p), rg, kg, y, e, s, training=True)
