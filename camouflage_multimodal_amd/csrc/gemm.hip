@@ -132,7 +132,37 @@ struct TileCtx {
   int m0, n0, tn, kbeg, kend;
 };
 
-template <int PREC, bool akm, bool bkm, bool VEC>
+// K loop shared by both precisions: tile t sits in LDS buffer t & 1; while it is multiplied, tile
+// t+1 (loaded PIPE-1 iterations ago into stage (t+1) % PIPE) is converted into the other buffer and
+// that stage is refilled with tile t+1+PIPE.  One barrier per tile.
+#define PIPELINE_LOOP                                                                         \
+  _Pragma("unroll") for (int j = 0; j < PIPE; ++j)                                            \
+    if (j < nt) gload(st[j], kbeg + j * BK);                                                  \
+  sstore(st[0], kbeg, 0);                                                                     \
+  if (PIPE < nt) gload(st[0], kbeg + PIPE * BK);                                              \
+  __syncthreads();                                                                            \
+  for (int t = 0; t < nt; t += PIPE) {                                                        \
+    _Pragma("unroll") for (int j = 0; j < PIPE; ++j) {                                        \
+      const int tt = t + j;                                                                   \
+      if (tt < nt) {                                                                          \
+        if (tt + 1 < nt) {                                                                    \
+          sstore(st[(j + 1) % PIPE], kbeg + (tt + 1) * BK, (j + 1) & 1);                      \
+          if (tt + 1 + PIPE < nt) gload(st[(j + 1) % PIPE], kbeg + (tt + 1 + PIPE) * BK);     \
+        }                                                                                     \
+        compute(j & 1);                                                                       \
+        __syncthreads();                                                                      \
+      }                                                                                       \
+    }                                                                                         \
+  }
+
+// Register stages of the global->LDS pipeline: PIPE (template parameter) K-tiles are in flight per block (their loads
+// were issued PIPE-1 iterations before they are converted and written to LDS).  In a training step
+// the operands were just written by the previous kernel, usually on another XCD, so they are served
+// from the Infinity Cache / HBM (~1.5 us per dependent round trip): with one tile in flight the K
+// loop ran at that latency per 32-deep step.
+struct Stage { float4 a[2], b[4]; };
+
+template <int PREC, int PIPE, bool akm, bool bkm, bool VEC>
 __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmProb& P, const TileCtx tc, char* smem_raw) {
   const int m0 = tc.m0, n0 = tc.n0, tn = tc.tn, kbeg = tc.kbeg, kend = tc.kend;
   const int M = P.M, N = P.N;
@@ -143,7 +173,6 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
 
-  float4 ra[2], rb[4];
   f32x16 acc[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -151,47 +180,86 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   float bsum = 0.f;   // bias-gradient partial (A k-major, first N tile)
   const bool do_bsum = (P.bias_grad != nullptr) && akm && (tn == 0);
+  const int nt = (kend - kbeg + BK - 1) / BK;
+  Stage st[PIPE];
+
+  // thread -> staging slot maps.  f32: slot s = tid + 256 i; m-major (row s>>3, k4 s&7), k-major
+  // (k s>>4 | s>>5, m4 s&15 | s&31).  bf16 k-major sources are transposed in registers, so there a
+  // thread loads a 2(k) x 4(m) block of A and a 4(k) x 4(n) block of B.
+  auto gload = [&](Stage& r, int k0) {
+    if constexpr (PREC == 0 || !akm) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int s = tid + 256 * i;
+        r.a[i] = !akm ? raw_mm<VEC>(oa, m0 + (s >> 3), k0 + (s & 7) * 4) : raw_km<VEC>(oa, m0 + (s & 15) * 4, k0 + (s >> 4));
+      }
+    } else {
+      const int kq = 4 * (tid >> 5) + 2 * ((tid >> 4) & 1), m = m0 + (tid & 15) * 4;
+      r.a[0] = raw_km<VEC>(oa, m, k0 + kq);
+      r.a[1] = raw_km<VEC>(oa, m, k0 + kq + 1);
+    }
+    if constexpr (PREC == 0 || !bkm) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s = tid + 256 * i;
+        r.b[i] = !bkm ? raw_mm<VEC>(ob, n0 + (s >> 3), k0 + (s & 7) * 4) : raw_km<VEC>(ob, n0 + (s & 31) * 4, k0 + (s >> 5));
+      }
+    } else {
+      const int kq = 4 * (tid >> 5), n = n0 + (tid & 31) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r.b[e] = raw_km<VEC>(ob, n, k0 + kq + e);
+    }
+  };
+  // pin the staged registers (forces the loads above to stay unconditional), then mask
+  auto mask_stage = [&](Stage& r, int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) pin4(r.a[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pin4(r.b[i]);
+    if constexpr (PREC == 0 || !akm) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int s = tid + 256 * i;
+        r.a[i] = !akm ? mask_mm(oa, r.a[i], m0 + (s >> 3), k0 + (s & 7) * 4, kend) : mask_km(oa, r.a[i], m0 + (s & 15) * 4, k0 + (s >> 4), kend);
+      }
+    } else {
+      const int kq = 4 * (tid >> 5) + 2 * ((tid >> 4) & 1), m = m0 + (tid & 15) * 4;
+      r.a[0] = mask_km(oa, r.a[0], m, k0 + kq, kend); r.a[1] = mask_km(oa, r.a[1], m, k0 + kq + 1, kend);
+    }
+    if constexpr (PREC == 0 || !bkm) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s = tid + 256 * i;
+        r.b[i] = !bkm ? mask_mm(ob, r.b[i], n0 + (s >> 3), k0 + (s & 7) * 4, kend) : mask_km(ob, r.b[i], n0 + (s & 31) * 4, k0 + (s >> 5), kend);
+      }
+    } else {
+      const int kq = 4 * (tid >> 5), n = n0 + (tid & 31) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r.b[e] = mask_km(ob, r.b[e], n, k0 + kq + e, kend);
+    }
+  };
 
   if constexpr (PREC == 0) {
-    float* As = reinterpret_cast<float*>(smem_raw);
-    float* Bs = As + A_F32;
-    auto gload = [&](int k0) {
+    float* Abuf = reinterpret_cast<float*>(smem_raw);               // [2][A_F32]
+    float* Bbuf = Abuf + 2 * A_F32;                                  // [2][B_F32]
+    auto sstore = [&](Stage& r, int k0, int buf) {
+      mask_stage(r, k0);
+      float* As = Abuf + buf * A_F32; float* Bs = Bbuf + buf * B_F32;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int s = tid + 256 * i;
-        ra[i] = !akm ? raw_mm<VEC>(oa, m0 + (s >> 3), k0 + (s & 7) * 4) : raw_km<VEC>(oa, m0 + (s & 15) * 4, k0 + (s >> 4));
+        if (!akm) *reinterpret_cast<float4*>(As + (s >> 3) * LDM + (s & 7) * 4) = r.a[i];
+        else      *reinterpret_cast<float4*>(As + (s >> 4) * LDKA + (s & 15) * 4) = r.a[i];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int s = tid + 256 * i;
-        rb[i] = !bkm ? raw_mm<VEC>(ob, n0 + (s >> 3), k0 + (s & 7) * 4) : raw_km<VEC>(ob, n0 + (s & 31) * 4, k0 + (s >> 5));
+        if (!bkm) *reinterpret_cast<float4*>(Bs + (s >> 3) * LDM + (s & 7) * 4) = r.b[i];
+        else      *reinterpret_cast<float4*>(Bs + (s >> 5) * LDKB + (s & 31) * 4) = r.b[i];
       }
     };
-    auto sstore = [&](int k0) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) pin4(ra[i]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pin4(rb[i]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int s = tid + 256 * i;
-        if (!akm) *reinterpret_cast<float4*>(As + (s >> 3) * LDM + (s & 7) * 4) = mask_mm(oa, ra[i], m0 + (s >> 3), k0 + (s & 7) * 4, kend);
-        else      *reinterpret_cast<float4*>(As + (s >> 4) * LDKA + (s & 15) * 4) = mask_km(oa, ra[i], m0 + (s & 15) * 4, k0 + (s >> 4), kend);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int s = tid + 256 * i;
-        if (!bkm) *reinterpret_cast<float4*>(Bs + (s >> 3) * LDM + (s & 7) * 4) = mask_mm(ob, rb[i], n0 + (s >> 3), k0 + (s & 7) * 4, kend);
-        else      *reinterpret_cast<float4*>(Bs + (s >> 5) * LDKB + (s & 31) * 4) = mask_km(ob, rb[i], n0 + (s & 31) * 4, k0 + (s >> 5), kend);
-      }
-    };
-
-    gload(kbeg);
-    sstore(kbeg);
-    __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      const bool more = k0 + BK < kend;
-      if (more) gload(k0 + BK);
+    auto compute = [&](int buf) {
+      const float* As = Abuf + buf * A_F32; const float* Bs = Bbuf + buf * B_F32;
       if (do_bsum && tid < BM) {
 #pragma unroll 8
         for (int kk = 0; kk < BK; ++kk) bsum += As[kk * LDKA + tid];
@@ -226,93 +294,45 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[1][e], acc[1], 0, 0, 0);
         }
       }
-      __syncthreads();
-      if (more) { sstore(k0 + BK); __syncthreads(); }
-    }
-  } else {
-    unsigned short* As = reinterpret_cast<unsigned short*>(smem_raw);
-    unsigned short* Bs = As + A_BF16;
-    // bf16 image [row][k], 80-B rows.  m-major sources: a float4 is 4 consecutive k of one row -> one
-    // 8-B store.  k-major sources are transposed in registers: B: a thread loads a 4(k) x 4(n) block
-    // (k = 4q..4q+3) -> four 8-B stores; A: a 2(k) x 4(m) block -> four 4-B stores.
-    auto gload = [&](int k0) {
-      if (!akm) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int s = tid + 256 * i;
-          ra[i] = raw_mm<VEC>(oa, m0 + (s >> 3), k0 + (s & 7) * 4);
-        }
-      } else {
-        const int kq = 4 * (tid >> 5) + 2 * ((tid >> 4) & 1), m = m0 + (tid & 15) * 4;
-        ra[0] = raw_km<VEC>(oa, m, k0 + kq);
-        ra[1] = raw_km<VEC>(oa, m, k0 + kq + 1);
-      }
-      if (!bkm) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int s = tid + 256 * i;
-          rb[i] = raw_mm<VEC>(ob, n0 + (s >> 3), k0 + (s & 7) * 4);
-        }
-      } else {
-        const int kq = 4 * (tid >> 5), n = n0 + (tid & 31) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rb[e] = raw_km<VEC>(ob, n, k0 + kq + e);
-      }
     };
-    auto sstore = [&](int k0) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) pin4(ra[i]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pin4(rb[i]);
-      if (!akm) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { const int s = tid + 256 * i; ra[i] = mask_mm(oa, ra[i], m0 + (s >> 3), k0 + (s & 7) * 4, kend); }
-      } else {
-        const int kq = 4 * (tid >> 5) + 2 * ((tid >> 4) & 1), m = m0 + (tid & 15) * 4;
-        ra[0] = mask_km(oa, ra[0], m, k0 + kq, kend); ra[1] = mask_km(oa, ra[1], m, k0 + kq + 1, kend);
-      }
-      if (!bkm) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const int s = tid + 256 * i; rb[i] = mask_mm(ob, rb[i], n0 + (s >> 3), k0 + (s & 7) * 4, kend); }
-      } else {
-        const int kq = 4 * (tid >> 5), n = n0 + (tid & 31) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rb[e] = mask_km(ob, rb[e], n, k0 + kq + e, kend);
-      }
+    PIPELINE_LOOP
+  } else {
+    unsigned short* Abuf = reinterpret_cast<unsigned short*>(smem_raw);   // [2][A_BF16]
+    unsigned short* Bbuf = Abuf + 2 * A_BF16;                              // [2][B_BF16]
+    // bf16 image [row][k], 80-B rows.  m-major sources: a float4 is 4 consecutive k of one row -> one
+    // 8-B store.  k-major sources: B 4(k) x 4(n) block -> four 8-B stores; A 2(k) x 4(m) -> four 4-B stores.
+    auto sstore = [&](Stage& r, int k0, int buf) {
+      mask_stage(r, k0);
+      unsigned short* As = Abuf + buf * A_BF16; unsigned short* Bs = Bbuf + buf * B_BF16;
       if (!akm) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int s = tid + 256 * i;
-          *reinterpret_cast<uint2*>(As + (s >> 3) * LDH + (s & 7) * 4) = make_uint2(pack2(ra[i].x, ra[i].y), pack2(ra[i].z, ra[i].w));
+          *reinterpret_cast<uint2*>(As + (s >> 3) * LDH + (s & 7) * 4) = make_uint2(pack2(r.a[i].x, r.a[i].y), pack2(r.a[i].z, r.a[i].w));
         }
       } else {
         const int kq = 4 * (tid >> 5) + 2 * ((tid >> 4) & 1), m = (tid & 15) * 4;
-        *reinterpret_cast<uint32_t*>(As + (m + 0) * LDH + kq) = pack2(ra[0].x, ra[1].x);
-        *reinterpret_cast<uint32_t*>(As + (m + 1) * LDH + kq) = pack2(ra[0].y, ra[1].y);
-        *reinterpret_cast<uint32_t*>(As + (m + 2) * LDH + kq) = pack2(ra[0].z, ra[1].z);
-        *reinterpret_cast<uint32_t*>(As + (m + 3) * LDH + kq) = pack2(ra[0].w, ra[1].w);
+        *reinterpret_cast<uint32_t*>(As + (m + 0) * LDH + kq) = pack2(r.a[0].x, r.a[1].x);
+        *reinterpret_cast<uint32_t*>(As + (m + 1) * LDH + kq) = pack2(r.a[0].y, r.a[1].y);
+        *reinterpret_cast<uint32_t*>(As + (m + 2) * LDH + kq) = pack2(r.a[0].z, r.a[1].z);
+        *reinterpret_cast<uint32_t*>(As + (m + 3) * LDH + kq) = pack2(r.a[0].w, r.a[1].w);
       }
       if (!bkm) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int s = tid + 256 * i;
-          *reinterpret_cast<uint2*>(Bs + (s >> 3) * LDH + (s & 7) * 4) = make_uint2(pack2(rb[i].x, rb[i].y), pack2(rb[i].z, rb[i].w));
+          *reinterpret_cast<uint2*>(Bs + (s >> 3) * LDH + (s & 7) * 4) = make_uint2(pack2(r.b[i].x, r.b[i].y), pack2(r.b[i].z, r.b[i].w));
         }
       } else {
         const int kq = 4 * (tid >> 5), n = (tid & 31) * 4;
-        *reinterpret_cast<uint2*>(Bs + (n + 0) * LDH + kq) = make_uint2(pack2(rb[0].x, rb[1].x), pack2(rb[2].x, rb[3].x));
-        *reinterpret_cast<uint2*>(Bs + (n + 1) * LDH + kq) = make_uint2(pack2(rb[0].y, rb[1].y), pack2(rb[2].y, rb[3].y));
-        *reinterpret_cast<uint2*>(Bs + (n + 2) * LDH + kq) = make_uint2(pack2(rb[0].z, rb[1].z), pack2(rb[2].z, rb[3].z));
-        *reinterpret_cast<uint2*>(Bs + (n + 3) * LDH + kq) = make_uint2(pack2(rb[0].w, rb[1].w), pack2(rb[2].w, rb[3].w));
+        *reinterpret_cast<uint2*>(Bs + (n + 0) * LDH + kq) = make_uint2(pack2(r.b[0].x, r.b[1].x), pack2(r.b[2].x, r.b[3].x));
+        *reinterpret_cast<uint2*>(Bs + (n + 1) * LDH + kq) = make_uint2(pack2(r.b[0].y, r.b[1].y), pack2(r.b[2].y, r.b[3].y));
+        *reinterpret_cast<uint2*>(Bs + (n + 2) * LDH + kq) = make_uint2(pack2(r.b[0].z, r.b[1].z), pack2(r.b[2].z, r.b[3].z));
+        *reinterpret_cast<uint2*>(Bs + (n + 3) * LDH + kq) = make_uint2(pack2(r.b[0].w, r.b[1].w), pack2(r.b[2].w, r.b[3].w));
       }
     };
-
-    gload(kbeg);
-    sstore(kbeg);
-    __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      const bool more = k0 + BK < kend;
-      if (more) gload(k0 + BK);
+    auto compute = [&](int buf) {
+      const unsigned short* As = Abuf + buf * A_BF16; const unsigned short* Bs = Bbuf + buf * B_BF16;
       bf16x8 a[2], b[2][2];
       {
         const unsigned short* p = As + (wr * 32 + l31) * LDH + 8 * h;
@@ -336,9 +356,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[0][s], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[1][s], acc[1], 0, 0, 0);
       }
-      __syncthreads();
-      if (more) { sstore(k0 + BK); __syncthreads(); }
-    }
+    };
+    PIPELINE_LOOP
   }
 
   if (do_bsum && tid < BM && m0 + tid < M) atomicAdd(P.bias_grad + m0 + tid, bsum);
@@ -387,8 +406,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
   }
 }
 
-template <int PREC>
-__global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GemmBatch gb, int total_tiles) {
+// PIPE = 2 at two blocks per CU for launches with more tiles than the chip holds at once; PIPE = 4
+// (one block per CU, ~170 VGPRs) for the launches of ~one tile per CU, which are pure latency.
+template <int PREC, int PIPE>
+__global__ __launch_bounds__(256, (PIPE <= 2 ? 2 : 1)) void gemm_grouped_kernel(const GemmBatch gb, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
   // ---- XCD-aware block remap (bijective): blocks that share an XCD (bid % 8) get a
@@ -416,15 +437,15 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GemmBatch gb
                    ((P.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.B) & 15) == 0) && (((bkm ? P.N : P.K) & 3) == 0);
   // block-uniform dispatch to a body compiled for this problem's operand layouts
   if (vec) {
-    if (!akm && !bkm)      gemm_tile_body<PREC, false, false, true>(gb, P, tc, smem_raw);
-    else if (!akm && bkm)  gemm_tile_body<PREC, false, true, true>(gb, P, tc, smem_raw);
-    else if (akm && bkm)   gemm_tile_body<PREC, true, true, true>(gb, P, tc, smem_raw);
-    else                   gemm_tile_body<PREC, true, false, true>(gb, P, tc, smem_raw);
+    if (!akm && !bkm)      gemm_tile_body<PREC, PIPE, false, false, true>(gb, P, tc, smem_raw);
+    else if (!akm && bkm)  gemm_tile_body<PREC, PIPE, false, true, true>(gb, P, tc, smem_raw);
+    else if (akm && bkm)   gemm_tile_body<PREC, PIPE, true, true, true>(gb, P, tc, smem_raw);
+    else                   gemm_tile_body<PREC, PIPE, true, false, true>(gb, P, tc, smem_raw);
   } else {
-    if (!akm && !bkm)      gemm_tile_body<PREC, false, false, false>(gb, P, tc, smem_raw);
-    else if (!akm && bkm)  gemm_tile_body<PREC, false, true, false>(gb, P, tc, smem_raw);
-    else if (akm && bkm)   gemm_tile_body<PREC, true, true, false>(gb, P, tc, smem_raw);
-    else                   gemm_tile_body<PREC, true, false, false>(gb, P, tc, smem_raw);
+    if (!akm && !bkm)      gemm_tile_body<PREC, PIPE, false, false, false>(gb, P, tc, smem_raw);
+    else if (!akm && bkm)  gemm_tile_body<PREC, PIPE, false, true, false>(gb, P, tc, smem_raw);
+    else if (akm && bkm)   gemm_tile_body<PREC, PIPE, true, true, false>(gb, P, tc, smem_raw);
+    else                   gemm_tile_body<PREC, PIPE, true, false, false>(gb, P, tc, smem_raw);
   }
 }
 
@@ -583,11 +604,9 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
     if (skinny) return launch_skinny(gb, stream);
   }
   // tiles without split-K
-  int base_tiles = 0;
   for (int i = 0; i < gb.n; ++i) {
     GemmProb& p = gb.p[i];
     p.tiles_n = (p.N + BN - 1) / BN;
-    base_tiles += ((p.M + BM - 1) / BM) * p.tiles_n;
   }
   int total = 0;
   for (int i = 0; i < gb.n; ++i) {
@@ -609,7 +628,7 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
     total += tiles * p.ksplit;
   }
   if (total == 0) return 0;
-  const size_t lds = precision == 0 ? (size_t)(A_F32 + B_F32) * 4 : (size_t)(A_BF16 + B_BF16) * 2;
+  const size_t lds = precision == 0 ? (size_t)2 * (A_F32 + B_F32) * 4 : (size_t)2 * (A_BF16 + B_BF16) * 2;
   const bool prof = g_prof.on && 2 * (g_prof.used + 1) <= g_prof.ev.size();
   if (prof) {
     double fl = 0.0;
@@ -617,10 +636,14 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
     g_prof.flops.push_back(fl);
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used], stream);
   }
-  if (precision == 0)
-    hipLaunchKernelGGL(gemm_grouped_kernel<0>, dim3(total), dim3(256), lds, stream, gb, total);
-  else
-    hipLaunchKernelGGL(gemm_grouped_kernel<1>, dim3(total), dim3(256), lds, stream, gb, total);
+  const bool deep = total <= 320;
+  if (precision == 0) {
+    if (deep) hipLaunchKernelGGL((gemm_grouped_kernel<0, 4>), dim3(total), dim3(256), lds, stream, gb, total);
+    else      hipLaunchKernelGGL((gemm_grouped_kernel<0, 2>), dim3(total), dim3(256), lds, stream, gb, total);
+  } else {
+    if (deep) hipLaunchKernelGGL((gemm_grouped_kernel<1, 4>), dim3(total), dim3(256), lds, stream, gb, total);
+    else      hipLaunchKernelGGL((gemm_grouped_kernel<1, 2>), dim3(total), dim3(256), lds, stream, gb, total);
+  }
   if (prof) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], stream);
     ++g_prof.used;
