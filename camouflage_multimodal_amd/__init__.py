@@ -7,13 +7,18 @@ Public surface = the reference's operator API for this path:
 ``libcamo_fusion.so`` (hand-written HIP, C ABI in include/camo_fusion.h); there is no CPU
 fallback.
 """
+from .embedding_matcher import DeviceResidentDataset, EmbeddingMatcher  # noqa: F401
 from .fusion_model import (CrossAttentionFusion, LateFusion, MultimodalCamouflageDetector,  # noqa: F401
                            build_multimodal_model)
 from .losses import AggressiveFocalLoss, multitask_loss  # noqa: F401
 from .optim import FusedClipAdamW, cosine_warm_restarts_lr  # noqa: F401
+from .test_multimodal import (build_ordered_kg_tensor, load_multimodal_model, predict_embedding_directory,  # noqa: F401
+                              predict_from_embeddings)
 from .train_multimodal import (NativeTrainer, calculate_f1_score, collate_fn, fit, pack_samples,  # noqa: F401
                                train_epoch_fixed, validate_fixed)
 
 __all__ = ["build_multimodal_model", "MultimodalCamouflageDetector", "CrossAttentionFusion", "LateFusion",
            "AggressiveFocalLoss", "multitask_loss", "FusedClipAdamW", "cosine_warm_restarts_lr", "NativeTrainer",
-           "calculate_f1_score", "collate_fn", "fit", "pack_samples", "train_epoch_fixed", "validate_fixed"]
+           "calculate_f1_score", "collate_fn", "fit", "pack_samples", "train_epoch_fixed", "validate_fixed",
+           "EmbeddingMatcher", "DeviceResidentDataset", "load_multimodal_model", "build_ordered_kg_tensor",
+           "predict_from_embeddings", "predict_embedding_directory"]

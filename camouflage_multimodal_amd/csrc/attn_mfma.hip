@@ -154,7 +154,6 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
   if ((int)blockIdx.x * 4 * TPW * 16 >= nr) return;      // whole block past the sample (uniform)
   const int tfirst = (blockIdx.x * 4 + wave) * TPW;
   const float* kvb = KV + (size_t)b * Nk * 2 * H;
-  const Frag8 kf = load_row8(kvb + (size_t)min(x, Nk - 1) * 2 * H + h * DH, q, x < Nk);
   const Frag8 vf = load_row8(kvb + (size_t)min(x, Nk - 1) * 2 * H + H + h * DH, q, x < Nk);
   f4 kb[2], dKa[2], dVa[2];
 #pragma unroll
@@ -168,7 +167,6 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
     if (t0 >= nr) continue;
     const int node = r0 + min(t0 + x, nr - 1);
     const bool node_ok = t0 + x < nr;
-    const Frag8 qf = load_row8(Q + (size_t)node * H + h * DH, q, true);
     const Frag8 gf = load_row8(dO + (size_t)node * H + h * DH, q, true);
     // ---- orientation T: rows = keys 4q+r, col = node x
     f4 dpT = mma_nt32(vf, gf, f4{0.f, 0.f, 0.f, 0.f});

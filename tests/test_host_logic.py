@@ -1,0 +1,190 @@
+"""Host-side mirror of the reference API, checked on CPU (no compute calls: the product path has
+no CPU fallback and must say so)."""
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import params as OP
+
+
+def test_shared_library_exports_every_declared_symbol():
+    from camouflage_multimodal_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "camo_fusion.h")).read()
+    declared = set(re.findall(r"\b(camo_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m camouflage_multimodal_amd.build` first"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for s in declared:
+        assert hasattr(L, s), s
+    L.camo_abi_version.restype = ctypes.c_int
+    assert L.camo_abi_version() == _lib.ABI_VERSION
+    assert f"#define CAMO_ABI_VERSION {_lib.ABI_VERSION}" in hdr
+    assert f"#define CAMO_SUMSQ_FLOATS {_lib.SUMSQ_FLOATS}" in hdr
+
+
+def test_argument_validation_without_a_gpu():
+    """Size/argument checks run on the host before any launch: exercise them through the ABI."""
+    from camouflage_multimodal_amd import _lib
+    L = _lib.lib()
+    d = _lib.CamoDims(128, 128, 256, 8, 2, _lib.FUSION_CROSS_ATTENTION, 0.3)
+    n = L.camo_workspace_bytes(ctypes.byref(d), 16, 7700, 13)
+    assert 100e6 < n < 400e6
+    assert L.camo_workspace_bytes(ctypes.byref(d), 1, 1, 1) > 0
+    assert L.camo_workspace_bytes(ctypes.byref(d), 0, 10, 13) == 0 and b"B >= 1" in L.camo_last_error()
+    bad = _lib.CamoDims(128, 128, 250, 8, 2, 0, 0.3)
+    assert L.camo_workspace_bytes(ctypes.byref(bad), 4, 100, 13) == 0 and b"divisible" in L.camo_last_error()
+    assert L.camo_workspace_bytes(ctypes.byref(d), 4, 100, 100) == 0 and b"attention kernels" in L.camo_last_error()
+    late = _lib.CamoDims(128, 128, 256, 8, 2, _lib.FUSION_LATE, 0.3)
+    assert 0 < L.camo_workspace_bytes(ctypes.byref(late), 16, 7700, 13) < 1e6
+    assert L.camo_forward(ctypes.byref(d), None, None, None, None, None, None, 4, 100, 13, 50, None, 0, None, None, None,
+                          0, 0, 0, None) == -1
+    assert L.camo_loss(None, None, None, None, 4, 2, None, None, None, None, None) == -1
+
+
+def test_module_surface_matches_reference():
+    from camouflage_multimodal_amd import MultimodalCamouflageDetector, build_multimodal_model
+    m = build_multimodal_model({})
+    assert [k for k, _ in OP.param_specs()] == list(m.state_dict().keys())
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: s for k, s in OP.param_specs()}
+    assert sum(p.numel() for p in m.parameters()) == 1448710
+    for cfg in (dict(fusion_type="late"), dict(rg_dim=64, kg_dim=64, hidden_dim=64, num_heads=2), dict(num_classes=5)):
+        mm = build_multimodal_model(cfg)
+        assert [k for k, _ in OP.param_specs(cfg)] == list(mm.state_dict().keys())
+    assert m.config == dict(rg_dim=128, kg_dim=128, hidden_dim=256, num_heads=8, fusion_type="cross_attention",
+                            num_classes=2, dropout=0.3)
+    with pytest.raises(ValueError, match="Unknown fusion_type: nope"):
+        MultimodalCamouflageDetector(fusion_type="nope")
+    # state_dict round trip (strict) keeps the flat buffer coherent
+    sd = {k: torch.from_numpy(v) for k, v in OP.make_params({}, 3).items()}
+    m.load_state_dict(sd, strict=True)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k])
+    flat = m._engine.flat_params
+    for p in m.parameters():
+        assert flat.data_ptr() <= p.data_ptr() < flat.data_ptr() + 4 * flat.numel() and p.data_ptr() % 16 == 0
+    # torch's default initialisation of the corresponding reference modules
+    fresh = build_multimodal_model({})
+    assert float(fresh.fusion.cross_attn_rg2kg.in_proj_bias.detach().abs().max()) == 0.0
+    assert float(fresh.fusion.cross_attn_rg2kg.out_proj.bias.detach().abs().max()) == 0.0
+    assert torch.equal(fresh.fusion.ln_rg.weight, torch.ones(256))
+    bound = np.sqrt(6.0 / (256 + 768))
+    assert float(fresh.fusion.cross_attn_kg2rg.in_proj_weight.detach().abs().max()) <= bound + 1e-6
+
+
+def test_no_cpu_fallback_and_reference_errors():
+    from camouflage_multimodal_amd import NativeTrainer, build_multimodal_model
+    from camouflage_multimodal_amd._lib import CamoError
+    m = build_multimodal_model({})
+    with pytest.raises(CamoError, match="no CPU fallback"):
+        m(torch.zeros(1, 5, 128), torch.zeros(1, 13, 128))
+    with pytest.raises(ValueError, match="rg_embeddings must be 2D/3D/4D tensor"):
+        m(torch.zeros(1, 1, 1, 5, 128), torch.zeros(1, 13, 128))
+    with pytest.raises(ValueError, match="kg_embeddings must be 2D/3D/4D tensor"):
+        m(torch.zeros(1, 5, 128), torch.zeros(13))
+    with pytest.raises(CamoError, match="no CPU fallback"):
+        NativeTrainer(m).step(torch.zeros(5, 128), [5], torch.zeros(1, 13, 128), torch.zeros(1, dtype=torch.long),
+                              torch.zeros(1), torch.zeros(1))
+    # nothing under the package imports the oracle
+    pkg = os.path.join(ROOT, "camouflage_multimodal_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            assert "oracle" not in open(os.path.join(pkg, f)).read(), f
+
+
+def test_losses_metrics_and_schedule_against_golden():
+    from camouflage_multimodal_amd import AggressiveFocalLoss, calculate_f1_score, cosine_warm_restarts_lr
+    g = load_golden("loss")
+    x = torch.from_numpy(g["logits"]).requires_grad_(True)
+    l = AggressiveFocalLoss(0.75, 3.0)(x, torch.from_numpy(g["targets"]))
+    l.backward()
+    assert abs(float(l) - float(g["focal"])) < 1e-6
+    assert np.abs(x.grad.numpy() - g["focal_grad"]).max() < 1e-6
+    f = calculate_f1_score(torch.from_numpy(g["f1_pred"]), torch.from_numpy(g["f1_lab"]))
+    for k, v in f.items():
+        assert abs(float(v) - float(g[f"f1/{k}"])) < 1e-6, k
+    lrs = [cosine_warm_restarts_lr(5e-4, ep) for ep in range(35)]
+    assert np.abs(np.array(lrs) - g["lr_schedule"]).max() < 1e-9
+
+
+def test_pack_samples_and_embedding_matcher(kg_real):
+    from camouflage_multimodal_amd import EmbeddingMatcher, pack_samples
+    names = [str(n) for n in load_golden("kg_embeddings")["names"]]
+    kg = {n: torch.from_numpy(kg_real[i:i + 1].copy()) for i, n in enumerate(names)}
+    rg = {f"COD10K-CAM-1-Aquatic-{i}-{org}-{i}.jpg": {"node_embeddings": torch.from_numpy(OP.make_rg(5 + i, 128, seed=i)),
+                                                       "graph_embedding": torch.zeros(1, 128), "num_nodes": 5 + i}
+          for i, org in enumerate(["BatFish", "Bird", "Crab"])}
+    em = EmbeddingMatcher(rg_embeddings=rg, kg_embeddings=kg)
+    assert em.extract_category_from_filename("COD10K-CAM-1-Aquatic-1-BatFish-1.jpg") == "Fish"       # substring match
+    assert em.extract_category_from_filename("COD10K-CAM-2-Terrestrial-1-Bird-7.jpg") == "Bird"      # exact match
+    assert em.extract_category_from_filename("COD10K-CAM-1-Aquatic-3-Crab-3.jpg") is None
+    assert em.extract_category_from_filename("short-name.jpg") is None
+    matched = em.create_matched_dataset(use_all_kg_categories=True)
+    assert len(matched) == 3 and matched[0]["kg_embeddings"].shape == (13, 1, 128) and matched[2]["num_rg_nodes"] == 7
+    assert matched[0]["category_ids"] == list(range(13))
+    one = em.create_matched_dataset(use_all_kg_categories=False)
+    assert one[0]["kg_embeddings"].shape == (1, 1, 128) and one[0]["category_ids"] == [names.index("Fish")]
+    assert one[2]["category_ids"] == [0] and torch.allclose(one[2]["kg_embeddings"][0, 0], torch.from_numpy(kg_real).mean(0))
+    batch = [dict(rg_node_emb=s["rg_node_embeddings"], kg_emb=s["kg_embeddings"], mask_label=i % 2, edge_label=1.0,
+                  score_label=0.25 * i) for i, s in enumerate(matched)]
+    rgp, nrs, kgp, y, e, sc = pack_samples(batch, "cpu")
+    assert nrs == [5, 6, 7] and rgp.shape == (18, 128) and kgp.shape == (3, 13, 128)
+    assert torch.equal(rgp[5:11], matched[1]["rg_node_embeddings"]) and y.tolist() == [0, 1, 0] and sc.tolist() == [0.0, 0.25, 0.5]
+
+
+def test_device_resident_dataset_batches_on_cpu():
+    from camouflage_multimodal_amd import DeviceResidentDataset
+    samples = [dict(rg_node_emb=torch.from_numpy(OP.make_rg(3 + i, 128, seed=i)), kg_emb=torch.from_numpy(OP.make_kg(13, 128, seed=i))[:, None, :],
+                    mask_label=i % 2, edge_label=float(i % 2), score_label=0.1 * i) for i in range(5)]
+    ds = DeviceResidentDataset(samples, "cpu")
+    rg, nrs, kg, y, e, s = ds.batch([4, 1])
+    assert nrs == [7, 4] and rg.shape == (11, 128) and kg.shape == (2, 13, 128)
+    assert torch.equal(rg[:7], samples[4]["rg_node_emb"]) and torch.equal(rg[7:], samples[1]["rg_node_emb"])
+    assert y.tolist() == [0, 1] and abs(float(s[0]) - 0.4) < 1e-7
+    aug = DeviceResidentDataset(samples, "cpu", augment=True, seed=1)
+    diffs = [float((aug.batch([i])[0] - samples[i]["rg_node_emb"]).abs().max()) for i in range(5) for _ in range(4)]
+    assert any(d == 0.0 for d in diffs) and any(0 < d < 0.1 for d in diffs)      # noise with probability 1/2, sigma 0.01
+
+
+def test_checkpoint_format_interchanges_with_torch_adamw(tmp_path):
+    """The optimizer state this package writes loads into torch.optim.AdamW over the same parameter
+    list (what a reference user resuming from a checkpoint would do), and the checkpoint dict has the
+    reference's keys (train_multimodal.py:464-474)."""
+    from camouflage_multimodal_amd import FusedClipAdamW, build_multimodal_model, load_multimodal_model
+    from camouflage_multimodal_amd.train_multimodal import save_best_checkpoint
+
+    class T:  # minimal stand-in for NativeTrainer: the checkpoint writer only touches .opt
+        pass
+    cfg = {"model": dict(rg_dim=16, kg_dim=16, hidden_dim=32, num_heads=4), "learning_rate": 5e-4}
+    m = build_multimodal_model(cfg["model"])
+    t = T(); t.opt = FusedClipAdamW(m)
+    t.opt._state()[0].uniform_(-1, 1); t.opt._state()[1].uniform_(0, 1); t.opt.step_count = 7
+    path = os.path.join(tmp_path, "multimodal_best_fixed.pth")
+    save_best_checkpoint(path, m, t, 3, 0.5, {"f1_class_1": torch.tensor(0.75), "f1_avg": torch.tensor(0.7)}, 80.0, 60.0, cfg)
+    ck = torch.load(path, weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "val_loss", "val_f1_class_1", "val_f1_avg",
+                       "val_acc_0", "val_acc_1", "config"}
+    ref_opt = torch.optim.AdamW(build_multimodal_model(cfg["model"]).parameters(), lr=5e-4, weight_decay=1e-4)
+    ref_opt.load_state_dict(ck["optimizer_state_dict"])
+    st = ref_opt.state_dict()["state"]
+    assert len(st) == len(list(m.parameters())) and float(st[0]["step"]) == 7.0
+    m2, cfg2 = load_multimodal_model(path, "cpu")
+    assert cfg2 == cfg and all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    # and back: a torch AdamW state loads into the fused optimizer
+    o2 = FusedClipAdamW(m2); o2.load_state_dict(ref_opt.state_dict())
+    a, b = o2.state_dict()["state"], t.opt.state_dict()["state"]
+    assert o2.step_count == 7 and all(torch.equal(a[i]["exp_avg"], b[i]["exp_avg"]) and torch.equal(a[i]["exp_avg_sq"], b[i]["exp_avg_sq"]) for i in a)
+
+
+def test_build_ordered_kg_tensor():
+    from camouflage_multimodal_amd import build_ordered_kg_tensor
+    kg = {"b": torch.ones(1, 4), "a": torch.zeros(1, 4), "c": torch.full((1, 4), 2.0)}
+    t, od = build_ordered_kg_tensor(kg)
+    assert list(od) == ["a", "b", "c"] and t.shape == (3, 1, 4) and t[:, 0, 0].tolist() == [0.0, 1.0, 2.0]
+    t2, od2 = build_ordered_kg_tensor(torch.arange(6.0).view(3, 2))
+    assert list(od2) == ["cat_0", "cat_1", "cat_2"] and t2.shape == (3, 2)
