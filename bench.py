@@ -176,8 +176,17 @@ def main():
         gemm_s = ms.value * 1e-3
         achieved = alg / gemm_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
+        # HBM bytes of the same kernel from the PMC passes (profiles/summarize_pmc.py), per launch
+        traffic, tnote = None, None
+        pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pj):
+            with open(pj) as f:
+                pm = json.load(f)
+            traffic = round(pm["hbm_bytes_per_launch"])
+            tnote = {"hbm_bytes_per_step": round(pm["hbm_bytes_per_step"]), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                     "separate passes of this bench (profiles/pmc_traffic.json): " + pm["correction"]}
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 5), "traffic": None,
+                "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_note": tnote,
                 "kernel": "gemm_grouped_kernel<%s>" % ("bf16" if args.precision == "bf16" else "f32"),
                 "launches_per_step": round(n.value / k, 1),
                 "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
