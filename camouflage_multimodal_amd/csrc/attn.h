@@ -37,3 +37,4 @@ int launch_kg2rg_fwd_mfma(const float* Q2, const float* KV2, const int* offs, fl
                           int Nk, DropCfg drop, hipStream_t stream);
 int launch_kg2rg_bwd_mfma(const float* Q2, const float* KV2, const float* P2, const float* dO2, const int* offs, float* dQ2,
                           float* dKV2, int B, int H, int nh, int Nk, DropCfg drop, hipStream_t stream);
+int launch_attn_avg_site(const float* Pm, float* out, int T, int nh, int Nk, uint32_t site, DropCfg drop, hipStream_t stream);

@@ -493,3 +493,9 @@ int launch_kg2rg_bwd_mfma(const float* Q2, const float* KV2, const float* P2, co
                      1.0f / sqrtf((float)DH), drop);
   return (int)hipGetLastError();
 }
+
+int launch_attn_avg_site(const float* Pm, float* out, int T, int nh, int Nk, uint32_t site, DropCfg drop, hipStream_t stream) {
+  const int n = T * Nk;
+  hipLaunchKernelGGL(attn_avg_site_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, Pm, out, T, nh, Nk, site, drop);
+  return (int)hipGetLastError();
+}

@@ -18,7 +18,10 @@
 #include <string>
 
 #include "../../include/camo_fusion.h"
+#include <cstdlib>
+
 #include "attn.h"
+#include "fused.h"
 #include "gemm.h"
 #include "misc.h"
 
@@ -55,6 +58,8 @@ struct Ws {
   float *R, *G, *Q, *KV2, *KV, *Q2, *P, *P2, *O, *O2, *U, *U2, *st1, *st2, *Y, *Y2, *H1, *H2;
   float *means, *Ymean, *H1mean, *Y2mean, *H2mean; size_t means_n;
   float *comb, *F1, *fused, *hid, *a2;
+  // bf16 shadow copies of the node-level weights for the fused forward: Wrg | Wq | Wkv2 | Wo | W1
+  unsigned short *sWrg, *sWq, *sWkv2, *sWo, *sW1;
   // backward scratch
   float *dlog, *dhid, *dfused, *dF1, *dcomb, *dHm1, *dHm2, *da2;
   float *dH1, *dH2, *dY, *dY2, *dU, *dU2, *dO, *dO2, *dQ, *dKV, *dQ2, *dKV2, *dS2, *dR, *dG;
@@ -97,6 +102,8 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
     w.dQ2 = c.take<float>(TK * H); w.dKV2 = c.take<float>(T * 2 * H);
     w.dS2 = c.take<float>(T * nh * Nk);
     w.dR = c.take<float>(T * H); w.dG = c.take<float>(TK * H);
+    w.sWrg = c.take<unsigned short>(H * (size_t)d.rg_dim); w.sWq = c.take<unsigned short>(H * H);
+    w.sWkv2 = c.take<unsigned short>(2 * H * H); w.sWo = c.take<unsigned short>(H * H); w.sW1 = c.take<unsigned short>(2 * H * H);
   } else {
     const size_t F = H / 2, Fh = F / 2, Dc = (size_t)d.rg_dim + d.kg_dim;
     w.means_n = (size_t)B * Dc;
@@ -286,35 +293,67 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
 
   // ---- CrossAttentionFusion.forward, fusion_model.py:75-146
   const float* R = rg; const float* G = kg;
-  if (P[CAMO_P_RG_PROJ_W]) { g.nt(rg, D, P[CAMO_P_RG_PROJ_W], D, P[CAMO_P_RG_PROJ_B], w.R, H, T, H, D); R = w.R; }
-  else if (D != H) return fail(CAMO_E_ARG, "rg_proj weight missing but rg_dim != hidden_dim");
+  if (!P[CAMO_P_RG_PROJ_W] && D != H) return fail(CAMO_E_ARG, "rg_proj weight missing but rg_dim != hidden_dim");
+  if (!P[CAMO_P_KG_PROJ_W] && Dk != H) return fail(CAMO_E_ARG, "kg_proj weight missing but kg_dim != hidden_dim");
+  // Fused node-level forward (fused_fwd.hip): opt-in (CAMO_FUSED=1) -- measured at parity with the unfused
+  // schedule on MI355X (each stage inside the workgroup is as latency-bound as the separate launches were), so
+  // the general schedule below (any dims, exact-f32 mode) stays the default and the reference it is tested against.
+  const char* fenv = std::getenv("CAMO_FUSED");
+  const bool fused = fenv && fenv[0] == '1' && precision == CAMO_PREC_BF16 && P[CAMO_P_RG_PROJ_W] &&
+                     rg_fused_supported(D, H, nh, Nk);
+  const size_t HH2 = (size_t)H * H;
   if (P[CAMO_P_KG_PROJ_W]) { g.nt(kg, Dk, P[CAMO_P_KG_PROJ_W], Dk, P[CAMO_P_KG_PROJ_B], w.G, H, TK, H, Dk); G = w.G; }
-  else if (Dk != H) return fail(CAMO_E_ARG, "kg_proj weight missing but kg_dim != hidden_dim");
+  if (!fused && P[CAMO_P_RG_PROJ_W]) { g.nt(rg, D, P[CAMO_P_RG_PROJ_W], D, P[CAMO_P_RG_PROJ_B], w.R, H, T, H, D); R = w.R; }
   CK(g.run(), "input projections");
   // in-projections of both attention blocks (packed in_proj_weight: rows 0..H-1 = Wq, H..3H-1 = Wk|Wv)
-  g.nt(R, H, P[CAMO_P_A1_IN_W], H, P[CAMO_P_A1_IN_B], w.Q, H, T, H, H);
-  g.nt(R, H, P[CAMO_P_A2_IN_W] + (size_t)H * H, H, P[CAMO_P_A2_IN_B] + H, w.KV2, 2 * H, T, 2 * H, H);
-  g.nt(G, H, P[CAMO_P_A1_IN_W] + (size_t)H * H, H, P[CAMO_P_A1_IN_B] + H, w.KV, 2 * H, TK, 2 * H, H);
+  if (!fused) {
+    g.nt(R, H, P[CAMO_P_A1_IN_W], H, P[CAMO_P_A1_IN_B], w.Q, H, T, H, H);
+    g.nt(R, H, P[CAMO_P_A2_IN_W] + HH2, H, P[CAMO_P_A2_IN_B] + H, w.KV2, 2 * H, T, 2 * H, H);
+  }
+  g.nt(G, H, P[CAMO_P_A1_IN_W] + HH2, H, P[CAMO_P_A1_IN_B] + H, w.KV, 2 * H, TK, 2 * H, H);
   g.nt(G, H, P[CAMO_P_A2_IN_W], H, P[CAMO_P_A2_IN_B], w.Q2, H, TK, H, H);
   CK(g.run(), "attention in-projections");
-  CK(launch_attn_rg2kg_fwd(w.Q, w.KV, rg_offsets, w.P, w.O, attn_rg2kg, B, T, max_nr, H, nh, Nk, drop, st), "attn rg2kg fwd");
+  if (fused) {
+    const float* src[5] = {P[CAMO_P_RG_PROJ_W], P[CAMO_P_A1_IN_W], P[CAMO_P_A2_IN_W] + HH2, P[CAMO_P_A1_OUT_W], P[CAMO_P_F1_W0]};
+    unsigned short* dst[5] = {w.sWrg, w.sWq, w.sWkv2, w.sWo, w.sW1};
+    const int Ns[5] = {H, H, 2 * H, H, 2 * H}, Ks[5] = {D, H, H, H, H};
+    CK(launch_cast_tiled_bf16(src, dst, Ns, Ks, 5, st), "cast weights to tiled bf16");
+    RgFwdArgs fa{};
+    fa.X = rg; fa.D = D; fa.offs = rg_offsets;
+    fa.Wrg = w.sWrg; fa.Wq = w.sWq; fa.Wkv2 = w.sWkv2; fa.Wo = w.sWo; fa.W1 = w.sW1;
+    fa.brg = P[CAMO_P_RG_PROJ_B]; fa.bq = P[CAMO_P_A1_IN_B]; fa.bkv2 = P[CAMO_P_A2_IN_B] + H; fa.bo = P[CAMO_P_A1_OUT_B];
+    fa.b1 = P[CAMO_P_F1_B0]; fa.ln_g = P[CAMO_P_LN1_W]; fa.ln_b = P[CAMO_P_LN1_B];
+    fa.KV = w.KV;
+    fa.R = w.R; fa.Q = w.Q; fa.KV2 = w.KV2; fa.P = w.P; fa.O = w.O; fa.U = w.U; fa.stats = w.st1; fa.Y = w.Y; fa.H1 = w.H1;
+    fa.Ymean = w.Ymean; fa.H1mean = w.H1mean;
+    fa.Nk = Nk; fa.nh = nh; fa.scale = 1.0f / sqrtf((float)(H / nh)); fa.drop = drop;
+    { const char* ds = std::getenv("CAMO_FUSED_STOP"); fa.debug_stop = ds ? std::atoi(ds) : 0; }
+    CK(launch_rg_forward_fused(fa, B, max_nr, st), "fused node-level forward");
+    R = w.R;
+    if (attn_rg2kg) CK(launch_attn_avg_site(w.P, attn_rg2kg, T, nh, Nk, SITE_ATTN_RG2KG, drop, st), "attn avg rg2kg");
+  } else {
+    CK(launch_attn_rg2kg_fwd(w.Q, w.KV, rg_offsets, w.P, w.O, attn_rg2kg, B, T, max_nr, H, nh, Nk, drop, st), "attn rg2kg fwd");
+  }
   CK(launch_attn_kg2rg_fwd(w.Q2, w.KV2, rg_offsets, w.P2, w.O2, B, max_nr, H, nh, Nk, drop, st), "attn kg2rg fwd");
   if (attn_kg2rg) CK(launch_attn_avg(w.P2, attn_kg2rg, T, nh, Nk, drop, st), "attn avg");
   // out-projection + residual (fusion_model.py:119,130), then LayerNorm
-  set_res(g.nt(w.O, H, P[CAMO_P_A1_OUT_W], H, P[CAMO_P_A1_OUT_B], w.U, H, T, H, H), R, H);
+  if (!fused) set_res(g.nt(w.O, H, P[CAMO_P_A1_OUT_W], H, P[CAMO_P_A1_OUT_B], w.U, H, T, H, H), R, H);
   set_res(g.nt(w.O2, H, P[CAMO_P_A2_OUT_W], H, P[CAMO_P_A2_OUT_B], w.U2, H, TK, H, H), G, H);
   CK(g.run(), "attention out-projections");
   {
-    LnSeg s0{w.U, w.Y, w.st1, P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], T};
+    LnSeg s0{w.U, w.Y, w.st1, P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], fused ? 0 : T};
     LnSeg s1{w.U2, w.Y2, w.st2, P[CAMO_P_LN2_W], P[CAMO_P_LN2_B], TK};
     CK(launch_ln_fwd(s0, s1, H, st), "layernorm fwd");
   }
   // FFN first layers (ReLU + dropout fused), fusion_model.py:53-65
-  set_drop(g.nt(w.Y, H, P[CAMO_P_F1_W0], H, P[CAMO_P_F1_B0], w.H1, 2 * H, T, 2 * H, H, GF_RELU), SITE_FFN_RG);
+  if (!fused) set_drop(g.nt(w.Y, H, P[CAMO_P_F1_W0], H, P[CAMO_P_F1_B0], w.H1, 2 * H, T, 2 * H, H, GF_RELU), SITE_FFN_RG);
   set_drop(g.nt(w.Y2, H, P[CAMO_P_F2_W0], H, P[CAMO_P_F2_B0], w.H2, 2 * H, TK, 2 * H, H, GF_RELU), SITE_FFN_KG);
   CK(g.run(), "ffn layer 0");
   // per-sample means of Y and H1d, then the second FFN layer on the means (mean-pool linearity)
-  {
+  if (fused) {   // the node-level sums were accumulated by the fused kernel
+    SegMean sm[2] = {{w.Y2, H, H, nullptr, Nk, w.Y2mean, H}, {w.H2, 2 * H, 2 * H, nullptr, Nk, w.H2mean, 2 * H}};
+    CK(launch_seg_mean(sm, 2, B, Nk, st), "pool (kg)");
+  } else {
     SegMean sm[4] = {{w.Y, H, H, rg_offsets, 0, w.Ymean, H}, {w.H1, 2 * H, 2 * H, rg_offsets, 0, w.H1mean, 2 * H},
                      {w.Y2, H, H, nullptr, Nk, w.Y2mean, H}, {w.H2, 2 * H, 2 * H, nullptr, Nk, w.H2mean, 2 * H}};
     CK(launch_seg_mean(sm, 4, B, max_nr > Nk ? max_nr : Nk, st), "pool");
