@@ -172,6 +172,11 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
+  // Accumulator orientation.  Plain-store problems (x.W^T, dy.W) feed the WEIGHT-side operand as MFMA "A",
+  // so the tile is C^T: lane = output row m, registers = 4-column quads -> 16-B stores (dword stores made the
+  // epilogue store-issue bound).  Weight gradients keep C orientation: their fp32 atomics run at full rate
+  // only when a wave-instruction covers 128 contiguous bytes per row (lanes along n).
+  constexpr bool TRANS = !(akm && bkm);
 
   f32x16 acc[2];
 #pragma unroll
@@ -290,8 +295,13 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[0][e], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[1][e], acc[1], 0, 0, 0);
+          if constexpr (TRANS) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0][e], a[e], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[1][e], a[e], acc[1], 0, 0, 0);
+          } else {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[0][e], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[1][e], acc[1], 0, 0, 0);
+          }
         }
       }
     };
@@ -353,8 +363,13 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[0][s], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[1][s], acc[1], 0, 0, 0);
+        if constexpr (TRANS) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0][s], a[s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1][s], a[s], acc[1], 0, 0, 0);
+        } else {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[0][s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[1][s], acc[1], 0, 0, 0);
+        }
       }
     };
     PIPELINE_LOOP
@@ -362,45 +377,89 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
 
   if (do_bsum && tid < BM && m0 + tid < M) atomicAdd(P.bias_grad + m0 + tid, bsum);
 
-  // ---- epilogue.  32x32 accumulator: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-  // Executed once per block but 32 elements deep per lane, so it is kept lean: the common forms
-  // (store / relu / dropout / residual, and the atomic accumulate of a weight gradient) run in
-  // loops whose only per-element control flow is the row bound; the first version's fully generic
-  // per-element flag tests cost ~10 us per launch in straight-line code.
+  // ---- epilogue, executed once per block but 32 elements deep per lane, so it is kept lean
   const int flags = P.flags;
-  const int rowb = m0 + wr * 32 + 4 * h;
-  const bool rare = flags & (GF_RELU_BWD | GF_RES_BCAST | GF_SIGMOID);
+  if constexpr (!TRANS) {
+    // C orientation: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int rowb = m0 + wr * 32 + 4 * h;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wc * 64 + j * 32 + l31;
-    if (col >= N) continue;
-    const float bv = P.bias ? P.bias[col] : 0.f;
-    float* cp = P.C + col;
-    if (flags & GF_ATOMIC) {
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 64 + j * 32 + l31;
+      if (col >= N) continue;
+      const float bv = P.bias ? P.bias[col] : 0.f;
+      float* cp = P.C + col;
+      if (flags & GF_ATOMIC) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rowb + (r & 3) + 8 * (r >> 2);
-        if (row < M) atomicAdd(cp + (size_t)row * P.ldc, acc[j][r] + bv);
-      }
-    } else if (rare) {
-#pragma unroll 4
-      for (int r = 0; r < 16; ++r) {
-        const int row = rowb + (r & 3) + 8 * (r >> 2);
-        if (row < M) epilogue_store(P, gb.drop, acc[j][r] + bv, row, col);
-      }
-    } else {
-      const float floor_ = (flags & GF_RELU) ? 0.f : -INFINITY;
-      const bool dodrop = (flags & GF_DROPOUT) && gb.drop.p > 0.f;
-      const float* rp = P.res ? P.res + col : nullptr;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rowb + (r & 3) + 8 * (r >> 2);
-        if (row < M) {
-          float v = fmaxf(acc[j][r] + bv, floor_);
-          if (dodrop) v *= drop_mult(gb.drop, P.drop_site, (uint32_t)row * (uint32_t)N + (uint32_t)col);
-          if (rp) v += rp[(size_t)row * P.ldr];
-          cp[(size_t)row * P.ldc] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int row = rowb + (r & 3) + 8 * (r >> 2);
+          if (row < M) atomicAdd(cp + (size_t)row * P.ldc, acc[j][r] + bv);
         }
+      } else {
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+          const int row = rowb + (r & 3) + 8 * (r >> 2);
+          if (row < M) epilogue_store(P, gb.drop, acc[j][r] + bv, row, col);
+        }
+      }
+    }
+  } else {
+    // C^T orientation: lane&31 = output row, registers 4g..4g+3 = columns c0..c0+3, c0 = 32j + 8g + 4(lane>>5)
+    const int row = m0 + wr * 32 + l31;
+    if (row < M) {
+      const bool v4 = ((N & 3) == 0) && ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) &&
+                      (!P.bias || (reinterpret_cast<uintptr_t>(P.bias) & 15) == 0) &&
+                      (!P.res || (((P.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.res) & 15) == 0)));
+      const bool simple = !(flags & (GF_ATOMIC | GF_SIGMOID));
+      if (v4 && simple) {
+        const float floor_ = (flags & GF_RELU) ? 0.f : -INFINITY;
+        const bool dodrop = (flags & GF_DROPOUT) && gb.drop.p > 0.f;
+        float* crow = P.C + (size_t)row * P.ldc;
+        // residual / aux row of this output row
+        const float* rrow = nullptr; float rscale = 1.f;
+        if (P.res) {
+          if (flags & GF_RES_BCAST) {
+            int sb;
+            if (P.row_sample) { sb = P.row_sample[row]; rscale = P.inv_nr[sb]; }
+            else { sb = row / P.uniform_n; rscale = 1.0f / (float)P.uniform_n; }
+            rrow = P.res + (size_t)sb * P.ldr;
+          } else {
+            rrow = P.res + (size_t)row * P.ldr;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c0 = n0 + wc * 64 + j * 32 + 8 * g + 4 * h;
+            if (c0 < N) {
+              float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+              if (P.bias) { const float4 bv = *reinterpret_cast<const float4*>(P.bias + c0); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+              v.x = fmaxf(v.x, floor_); v.y = fmaxf(v.y, floor_); v.z = fmaxf(v.z, floor_); v.w = fmaxf(v.w, floor_);
+              if (dodrop) {
+                const uint32_t idx = (uint32_t)row * (uint32_t)N + (uint32_t)c0;
+                v.x *= drop_mult(gb.drop, P.drop_site, idx); v.y *= drop_mult(gb.drop, P.drop_site, idx + 1);
+                v.z *= drop_mult(gb.drop, P.drop_site, idx + 2); v.w *= drop_mult(gb.drop, P.drop_site, idx + 3);
+              }
+              if (rrow) {
+                const float4 rv = *reinterpret_cast<const float4*>(rrow + c0);
+                if (flags & GF_RELU_BWD) {
+                  v.x *= rv.x > 0.f ? P.aux_scale : 0.f; v.y *= rv.y > 0.f ? P.aux_scale : 0.f;
+                  v.z *= rv.z > 0.f ? P.aux_scale : 0.f; v.w *= rv.w > 0.f ? P.aux_scale : 0.f;
+                } else {
+                  v.x = fmaf(rv.x, rscale, v.x); v.y = fmaf(rv.y, rscale, v.y); v.z = fmaf(rv.z, rscale, v.z); v.w = fmaf(rv.w, rscale, v.w);
+                }
+              }
+              *reinterpret_cast<float4*>(crow + c0) = v;
+            }
+          }
+      } else {
+#pragma unroll 2
+        for (int j = 0; j < 2; ++j)
+#pragma unroll 4
+          for (int r = 0; r < 16; ++r) {
+            const int col = n0 + wc * 64 + j * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (col < N) epilogue_store(P, gb.drop, acc[j][r] + (P.bias ? P.bias[col] : 0.f), row, col);
+          }
       }
     }
   }
