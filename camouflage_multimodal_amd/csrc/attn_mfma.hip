@@ -77,7 +77,7 @@ __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64)
 // of a block share Q rows.  The head-averaged map (inference only) is a separate pass over P.
 __global__ __launch_bounds__(256) void rg2kg_fwd_mfma_kernel(
     const float* __restrict__ Q, const float* __restrict__ KV, const int* __restrict__ offs,
-    float* __restrict__ P, float* __restrict__ O, int H, int nh, int Nk, float scale, DropCfg drop) {
+    float* __restrict__ P, float* __restrict__ O, Bf16Dst o16, int H, int nh, int Nk, float scale, DropCfg drop) {
   const int b = blockIdx.y;
   const int r0 = offs[b], nr = offs[b + 1] - r0;
   const int lane = threadIdx.x & 63, x = lane & 15, q = lane >> 4;
@@ -118,7 +118,10 @@ __global__ __launch_bounds__(256) void rg2kg_fwd_mfma_kernel(
     const f4 o = mma_acc16(s, vb[n], f4{0.f, 0.f, 0.f, 0.f});   // rows = nodes 4q+r, col = 16n + x
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (t0 + 4 * q + r < nr) O[(size_t)(r0 + t0 + 4 * q + r) * H + h * DH + 16 * n + x] = o[r];
+      if (t0 + 4 * q + r < nr) {
+        const size_t rw = (size_t)(r0 + t0 + 4 * q + r); const int cl = h * DH + 16 * n + x;
+        if (o16.p) o16.p[rw * o16.ld + cl] = f2bf(o[r]); else O[rw * H + cl] = o[r];
+      }
   }
 }
 
@@ -145,7 +148,7 @@ constexpr int TPW = 2;
 __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
     const float* __restrict__ Q, const float* __restrict__ KV, const float* __restrict__ P,
     const float* __restrict__ dO, const int* __restrict__ offs,
-    float* __restrict__ dQ, float* __restrict__ dKV,
+    float* __restrict__ dQ, float* __restrict__ dKV, Bf16Dst dq16,
     int H, int nh, int Nk, float scale, DropCfg drop) {
   __shared__ float comb[3][16][64];
   const int b = blockIdx.z, h = blockIdx.y;
@@ -191,7 +194,10 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
       const f4 dq = mma_acc16(dsT, kb[n], f4{0.f, 0.f, 0.f, 0.f});     // rows = nodes 4q+r, col = 16n + x
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (t0 + 4 * q + r < nr) dQ[(size_t)(r0 + t0 + 4 * q + r) * H + h * DH + 16 * n + x] = dq[r];
+        if (t0 + 4 * q + r < nr) {
+          const size_t rw = (size_t)(r0 + t0 + 4 * q + r); const int cl = h * DH + 16 * n + x;
+          if (dq16.p) dq16.p[rw * dq16.ld + cl] = f2bf(dq[r]); else dQ[rw * H + cl] = dq[r];
+        }
     }
     // ---- orientation N: rows = nodes 4q+r, col = key x
     f4 dpN = mma_nt32(gf, vf, f4{0.f, 0.f, 0.f, 0.f});
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
 // wave w owns key tiles w, w+4, ...; scores S2^T (rows = keys 4q+r, col = query x) stay in registers.
 __global__ __launch_bounds__(64 * NW) void kg2rg_fwd_mfma_kernel(
     const float* __restrict__ Q2, const float* __restrict__ KV2, const int* __restrict__ offs,
-    float* __restrict__ P2, float* __restrict__ O2, int H, int nh, int Nk, float scale, DropCfg drop) {
+    float* __restrict__ P2, float* __restrict__ O2, Bf16Dst o16, int H, int nh, int Nk, float scale, DropCfg drop) {
   __shared__ float red[NW][16];
   __shared__ float ored[NW - 1][2][4][64];
   const int h = blockIdx.x, b = blockIdx.y;
@@ -324,7 +330,10 @@ __global__ __launch_bounds__(64 * NW) void kg2rg_fwd_mfma_kernel(
         float v = o[n][r];
 #pragma unroll
         for (int w = 0; w < NW - 1; ++w) v += ored[w][n][r][lane];
-        if (4 * q + r < Nk) O2[(size_t)(b * Nk + 4 * q + r) * H + h * DH + 16 * n + x] = v;
+        if (4 * q + r < Nk) {
+          const size_t rw = (size_t)(b * Nk + 4 * q + r); const int cl = h * DH + 16 * n + x;
+          if (o16.p) o16.p[rw * o16.ld + cl] = f2bf(v); else O2[rw * H + cl] = v;
+        }
       }
   }
 }
@@ -333,10 +342,20 @@ __global__ __launch_bounds__(64 * NW) void kg2rg_fwd_mfma_kernel(
 __global__ __launch_bounds__(64 * NW) void kg2rg_bwd_mfma_kernel(
     const float* __restrict__ Q2, const float* __restrict__ KV2, const float* __restrict__ P2,
     const float* __restrict__ dO2, const int* __restrict__ offs,
-    float* __restrict__ dQ2, float* __restrict__ dKV2, int H, int nh, int Nk, float scale, DropCfg drop) {
+    float* __restrict__ dQ2, float* __restrict__ dKV2, Bf16Dst dq2_16, Bf16Dst dkv2_16,
+    const float* __restrict__ dKV_done, Bf16Dst dkv_16, int H, int nh, int Nk, float scale, DropCfg drop) {
   __shared__ float red[NW][16];
   __shared__ float ored[NW - 1][2][4][64];
   const int h = blockIdx.x, b = blockIdx.y;
+  // bf16 schedule: dK|dV of the OTHER attention block (complete: its kernel ran before this one) is the next
+  // GEMM's operand; this block converts the slice of its (sample, head)
+  if (dkv_16.p) {
+    for (int i = threadIdx.x; i < Nk * 2 * DH; i += 64 * NW) {
+      const int j = i / (2 * DH), c = i - j * 2 * DH;
+      const int col = c < DH ? h * DH + c : H + h * DH + (c - DH);
+      dkv_16.p[(size_t)(b * Nk + j) * dkv_16.ld + col] = f2bf(dKV_done[(size_t)(b * Nk + j) * 2 * H + col]);
+    }
+  }
   const int r0 = offs[b], nr = offs[b + 1] - r0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
   const int ntiles = (nr + 15) >> 4;
@@ -402,7 +421,10 @@ __global__ __launch_bounds__(64 * NW) void kg2rg_bwd_mfma_kernel(
         float v = dq[n][r];
 #pragma unroll
         for (int w = 0; w < NW - 1; ++w) v += ored[w][n][r][lane];
-        if (4 * q + r < Nk) dQ2[(size_t)(b * Nk + 4 * q + r) * H + h * DH + 16 * n + x] = v;
+        if (4 * q + r < Nk) {
+          const size_t rw = (size_t)(b * Nk + 4 * q + r); const int cl = h * DH + 16 * n + x;
+          if (dq2_16.p) dq2_16.p[rw * dq2_16.ld + cl] = f2bf(v); else dQ2[rw * H + cl] = v;
+        }
       }
   }
   // ---- phase 2, orientation N (rows = queries 4q+r, col = key x): dK2, dV2 of every key tile
@@ -441,9 +463,15 @@ __global__ __launch_bounds__(64 * NW) void kg2rg_bwd_mfma_kernel(
       for (int r = 0; r < 4; ++r) {
         const int t = t0 + 4 * q + r;
         if (t < nr) {
-          float* dst = dKV2 + (size_t)(r0 + t) * 2 * H + h * DH + 16 * n + x;
-          dst[0] = dk[r];
-          dst[H] = dv[r];
+          if (dkv2_16.p) {
+            unsigned short* dst = dkv2_16.p + (size_t)(r0 + t) * dkv2_16.ld + h * DH + 16 * n + x;
+            dst[0] = f2bf(dk[r]);
+            dst[H] = f2bf(dv[r]);
+          } else {
+            float* dst = dKV2 + (size_t)(r0 + t) * 2 * H + h * DH + 16 * n + x;
+            dst[0] = dk[r];
+            dst[H] = dv[r];
+          }
         }
       }
     }
@@ -460,10 +488,10 @@ int attn_mfma_ok(int H, int nh, int Nk, int max_nr, bool kg2rg) {
 }
 
 int launch_rg2kg_fwd_mfma(const float* Q, const float* KV, const int* offs, float* P, float* O, float* attn_avg,
-                          int B, int T, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
+                          int B, int T, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream, Bf16Dst o16) {
   const int tasks = ((max_nr + 15) / 16) * nh;
   hipLaunchKernelGGL(rg2kg_fwd_mfma_kernel, dim3((tasks + 3) / 4, B), dim3(256), 0, stream, Q, KV, offs, P, O,
-                     H, nh, Nk, 1.0f / sqrtf((float)DH), drop);
+                     o16, H, nh, Nk, 1.0f / sqrtf((float)DH), drop);
   if (attn_avg) {
     const int n = T * Nk;
     hipLaunchKernelGGL(attn_avg_site_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, P, attn_avg, T, nh, Nk,
@@ -473,23 +501,25 @@ int launch_rg2kg_fwd_mfma(const float* Q, const float* KV, const int* offs, floa
 }
 
 int launch_rg2kg_bwd_mfma(const float* Q, const float* KV, const float* P, const float* dO, const int* offs, float* dQ,
-                          float* dKV, int B, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
+                          float* dKV, int B, int max_nr, int H, int nh, int Nk, DropCfg drop, hipStream_t stream, Bf16Dst dq16) {
   const int tiles = (max_nr + 15) / 16;
   hipLaunchKernelGGL(rg2kg_bwd_mfma_kernel, dim3((tiles + 4 * TPW - 1) / (4 * TPW), nh, B), dim3(256), 0, stream, Q, KV, P, dO,
-                     offs, dQ, dKV, H, nh, Nk, 1.0f / sqrtf((float)DH), drop);
+                     offs, dQ, dKV, dq16, H, nh, Nk, 1.0f / sqrtf((float)DH), drop);
   return (int)hipGetLastError();
 }
 
 int launch_kg2rg_fwd_mfma(const float* Q2, const float* KV2, const int* offs, float* P2, float* O2, int B, int H, int nh,
-                          int Nk, DropCfg drop, hipStream_t stream) {
-  hipLaunchKernelGGL(kg2rg_fwd_mfma_kernel, dim3(nh, B), dim3(64 * NW), 0, stream, Q2, KV2, offs, P2, O2, H, nh, Nk,
+                          int Nk, DropCfg drop, hipStream_t stream, Bf16Dst o16) {
+  hipLaunchKernelGGL(kg2rg_fwd_mfma_kernel, dim3(nh, B), dim3(64 * NW), 0, stream, Q2, KV2, offs, P2, O2, o16, H, nh, Nk,
                      1.0f / sqrtf((float)DH), drop);
   return (int)hipGetLastError();
 }
 
 int launch_kg2rg_bwd_mfma(const float* Q2, const float* KV2, const float* P2, const float* dO2, const int* offs, float* dQ2,
-                          float* dKV2, int B, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
-  hipLaunchKernelGGL(kg2rg_bwd_mfma_kernel, dim3(nh, B), dim3(64 * NW), 0, stream, Q2, KV2, P2, dO2, offs, dQ2, dKV2, H, nh, Nk,
+                          float* dKV2, int B, int H, int nh, int Nk, DropCfg drop, hipStream_t stream, Bf16Dst dq2_16,
+                          Bf16Dst dkv2_16, const float* dKV_done, Bf16Dst dkv_16) {
+  hipLaunchKernelGGL(kg2rg_bwd_mfma_kernel, dim3(nh, B), dim3(64 * NW), 0, stream, Q2, KV2, P2, dO2, offs, dQ2, dKV2,
+                     dq2_16, dkv2_16, dKV_done, dkv_16, H, nh, Nk,
                      1.0f / sqrtf((float)DH), drop);
   return (int)hipGetLastError();
 }

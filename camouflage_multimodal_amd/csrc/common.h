@@ -53,3 +53,10 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// fp32 -> bf16 bit pattern, round-to-nearest-even (what every MFMA operand of the bf16 schedule sees)
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  __bf16 b = (__bf16)f;     // round-to-nearest-even, NaN stays NaN
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }

@@ -23,6 +23,7 @@
 #include "attn.h"
 #include "fused.h"
 #include "gemm.h"
+#include "gemm16.h"
 #include "misc.h"
 
 namespace {
@@ -63,6 +64,16 @@ struct Ws {
   // backward scratch
   float *dlog, *dhid, *dfused, *dF1, *dcomb, *dHm1, *dHm2, *da2;
   float *dH1, *dH2, *dY, *dY2, *dU, *dU2, *dO, *dO2, *dQ, *dKV, *dQ2, *dKV2, *dS2, *dR, *dG;
+  // bf16 schedule ("sched16"): a bf16 copy of every node-level GEMM operand.  Activations have their row
+  // count padded to a multiple of 128 (Tp, TKp; the pad rows are cleared by the prep launch) so the weight-
+  // gradient GEMMs contract over whole 64-row tiles without masks.  Weights: [out][in] copies for x.W^T,
+  // transposed copies for dy.W, and the two in-projection slices that meet at one input concatenated
+  // (WcRgT = [Wq1^T | Wk2^T | Wv2^T], WcKgT = [Wq2^T | Wk1^T | Wv1^T], both [H][3H]).
+  struct H16 {
+    unsigned short *X, *KG, *R, *G, *O, *O2, *Y, *Y2, *dH1, *dH2, *dU, *dU2, *dQKV, *dQKVkg, *dR, *dG;
+    unsigned short *Wrg, *Wkg, *Win1, *Win2, *Wo1, *Wo2, *W1, *W2, *W1T, *W2T, *Wo1T, *Wo2T, *WcRgT, *WcKgT;
+  } h;
+  size_t Tp, TKp;
   size_t bytes;
 };
 
@@ -104,6 +115,20 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
     w.dR = c.take<float>(T * H); w.dG = c.take<float>(TK * H);
     w.sWrg = c.take<unsigned short>(H * (size_t)d.rg_dim); w.sWq = c.take<unsigned short>(H * H);
     w.sWkv2 = c.take<unsigned short>(2 * H * H); w.sWo = c.take<unsigned short>(H * H); w.sW1 = c.take<unsigned short>(2 * H * H);
+    {
+      typedef unsigned short us;
+      const size_t Tp = ((size_t)T + 127) / 128 * 128, TKp = (TK + 127) / 128 * 128, D = d.rg_dim, Dk = d.kg_dim;
+      w.Tp = Tp; w.TKp = TKp;
+      Ws::H16& h = w.h;
+      h.X = c.take<us>(Tp * D); h.KG = c.take<us>(TKp * Dk); h.R = c.take<us>(Tp * H); h.G = c.take<us>(TKp * H);
+      h.O = c.take<us>(Tp * H); h.O2 = c.take<us>(TKp * H); h.Y = c.take<us>(Tp * H); h.Y2 = c.take<us>(TKp * H);
+      h.dH1 = c.take<us>(Tp * 2 * H); h.dH2 = c.take<us>(TKp * 2 * H); h.dU = c.take<us>(Tp * H); h.dU2 = c.take<us>(TKp * H);
+      h.dQKV = c.take<us>(Tp * 3 * H); h.dQKVkg = c.take<us>(TKp * 3 * H); h.dR = c.take<us>(Tp * H); h.dG = c.take<us>(TKp * H);
+      h.Wrg = c.take<us>(H * D); h.Wkg = c.take<us>(H * Dk); h.Win1 = c.take<us>(3 * H * H); h.Win2 = c.take<us>(3 * H * H);
+      h.Wo1 = c.take<us>(H * H); h.Wo2 = c.take<us>(H * H); h.W1 = c.take<us>(2 * H * H); h.W2 = c.take<us>(2 * H * H);
+      h.W1T = c.take<us>(2 * H * H); h.W2T = c.take<us>(2 * H * H); h.Wo1T = c.take<us>(H * H); h.Wo2T = c.take<us>(H * H);
+      h.WcRgT = c.take<us>(3 * H * H); h.WcKgT = c.take<us>(3 * H * H);
+    }
   } else {
     const size_t F = H / 2, Fh = F / 2, Dc = (size_t)d.rg_dim + d.kg_dim;
     w.means_n = (size_t)B * Dc;
@@ -193,6 +218,53 @@ void set_bcast(GemmProb& p, const float* v, int ldv, const int* row_sample, cons
   p.flags |= GF_RES_BCAST; p.res = v; p.ldr = ldv; p.row_sample = row_sample; p.inv_nr = inv_nr; p.uniform_n = uniform_n;
 }
 
+// ---- the bf16 schedule's GEMM batch (gemm16.h) ------------------------------------------------
+typedef unsigned short us;
+struct GB16 {
+  Gemm16Batch b; hipStream_t st;
+  GB16(const DropCfg& d, hipStream_t st_) : st(st_) { std::memset(&b, 0, sizeof(b)); b.drop = d; }
+  Gemm16Prob& add() { Gemm16Prob& p = b.p[b.n++]; std::memset(&p, 0, sizeof(p)); p.aux_scale = 1.f; return p; }
+  // y = x.W^T (+bias): x16 [M,K], W16 [N,K]; fp32 result y and/or bf16 result y16 (either may be null)
+  Gemm16Prob& nt(const us* x, int ldx, const us* W, int ldw, const float* bias, float* y, int ldy, us* y16, int ldy16,
+                 int M, int N, int K, int flags = 0) {
+    Gemm16Prob& p = add();
+    p.A = x; p.lda = ldx; p.B = W; p.ldb = ldw; p.bias = bias; p.C = y; p.ldc = ldy; p.C16 = y16; p.ldc16 = ldy16;
+    p.M = M; p.N = N; p.K = K; p.flags = flags;
+    return p;
+  }
+  // dW [Nout, Nin] += dy^T.x : dy16 [rows, Nout], x16 [rows, Nin]; db [Nout] += colsum(dy)
+  Gemm16Prob& tn(const us* dy, int lddy, const us* x, int ldx, float* dW, int lddw, float* db, int Nout, int Nin, int rows) {
+    Gemm16Prob& p = add();
+    p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.C = dW; p.ldc = lddw; p.bias_grad = db;
+    p.M = Nout; p.N = Nin; p.K = rows; p.flags = GF_A_KMAJOR | GF_B_KMAJOR | GF_ATOMIC;
+    return p;
+  }
+  int run() {
+    if (b.n == 0) return 0;
+    int e = launch_gemm16_batch(b, st);
+    b.n = 0;
+    return e;
+  }
+};
+void set_res(Gemm16Prob& p, const float* res, int ldr) { p.res = res; p.ldr = ldr; }
+void set_drop(Gemm16Prob& p, uint32_t site) { p.flags |= GF_DROPOUT; p.drop_site = site; }
+void set_bcast(Gemm16Prob& p, const float* v, int ldv, const int* row_sample, const float* inv_nr, int uniform_n) {
+  p.flags |= GF_RES_BCAST; p.res = v; p.ldr = ldv; p.row_sample = row_sample; p.inv_nr = inv_nr; p.uniform_n = uniform_n;
+}
+
+// The bf16 schedule runs when the operands can live in HBM as bf16 tiles the gemm16 kernel takes whole:
+// cross-attention fusion with both input projections, every width a multiple of 64, head_dim 32 attention
+// on the MFMA kernels.  Anything else (and CAMO_SCHED16=0) takes the general fp32-operand schedule.
+bool sched16_ok(const camo_dims_t& d, const float* const* P, int precision, int T, int Nk, int max_nr) {
+  const char* env = std::getenv("CAMO_SCHED16");          // read per call: tests A/B the two schedules in one process
+  if ((env && env[0] == '0') || precision != CAMO_PREC_BF16 || d.fusion_type != CAMO_FUSION_CROSS_ATTENTION) return false;
+  if (!P[CAMO_P_RG_PROJ_W] || !P[CAMO_P_KG_PROJ_W]) return false;
+  if ((d.hidden_dim % 64) || (d.rg_dim % 64) || (d.kg_dim % 64)) return false;
+  if (!attn_mfma_ok(d.hidden_dim, d.num_heads, Nk, max_nr, false) || !attn_mfma_ok(d.hidden_dim, d.num_heads, Nk, max_nr, true))
+    return false;
+  return ((double)T + 128.0) * 3.0 * d.hidden_dim * 2.0 < 4.0e9;
+}
+
 // ---- the four heads (fusion_model.py:208-235), shared by both fusion types -------------------
 // The per-sample ("tail") GEMMs have M = B rows and a negligible FLOP share, so they always run
 // on the exact f32 MFMA; `precision` selects the MFMA type of the node-level (T-row) GEMMs only.
@@ -237,6 +309,123 @@ int heads_backward(const camo_dims_t& d, const float* const* hp, float* const* h
   return 0;
 }
 
+
+// ---- node-level forward of the bf16 schedule: CrossAttentionFusion.forward, fusion_model.py:75-135 ----
+int forward_nodes16(const camo_dims_t& d, const float* const* P, const float* rg, const int32_t* rg_offsets, const float* kg,
+                    int B, int T, int Nk, int max_nr, const Ws& w, float* attn_rg2kg, float* attn_kg2rg, const DropCfg& drop,
+                    hipStream_t st) {
+  const int H = d.hidden_dim, D = d.rg_dim, Dk = d.kg_dim, TK = B * Nk, nh = d.num_heads;
+  const size_t HH = (size_t)H * H;
+  const Ws::H16& h = w.h;
+  {   // prep: clear the atomics block and the pad rows, cast the inputs and the node-level weights to bf16
+    PrepBatch pb; pb.n = 0;
+    auto job = [&](int type, const float* src, void* dst, size_t n, int rows, int cols, int ld, int off) {
+      PrepJob& J = pb.j[pb.n++];
+      J.type = type; J.src = src; J.dst = dst; J.n = n; J.rows = rows; J.cols = cols; J.ld_dst = ld; J.col_off = off; J.blk_begin = 0;
+    };
+    auto cast = [&](const float* src, us* dst, size_t n) { job(PREP_CAST, src, dst, n, 0, 0, 0, 0); };
+    auto castT = [&](const float* src, us* dst, int rows, int cols, int ld, int off) { job(PREP_CAST_T, src, dst, 0, rows, cols, ld, off); };
+    auto pad = [&](us* buf, size_t rows, size_t rows_p, size_t width) {
+      job(PREP_ZERO, nullptr, buf + rows * width, (rows_p - rows) * width * sizeof(us), 0, 0, 0, 0);
+    };
+    job(PREP_ZERO, nullptr, w.zero_base, w.zero_bytes, 0, 0, 0, 0);
+    cast(rg, h.X, (size_t)T * D); cast(kg, h.KG, (size_t)TK * Dk);
+    cast(P[CAMO_P_RG_PROJ_W], h.Wrg, (size_t)H * D); cast(P[CAMO_P_KG_PROJ_W], h.Wkg, (size_t)H * Dk);
+    cast(P[CAMO_P_A1_IN_W], h.Win1, 3 * HH); cast(P[CAMO_P_A2_IN_W], h.Win2, 3 * HH);
+    cast(P[CAMO_P_A1_OUT_W], h.Wo1, HH); cast(P[CAMO_P_A2_OUT_W], h.Wo2, HH);
+    cast(P[CAMO_P_F1_W0], h.W1, 2 * HH); cast(P[CAMO_P_F2_W0], h.W2, 2 * HH);
+    castT(P[CAMO_P_F1_W0], h.W1T, 2 * H, H, 2 * H, 0); castT(P[CAMO_P_F2_W0], h.W2T, 2 * H, H, 2 * H, 0);
+    castT(P[CAMO_P_A1_OUT_W], h.Wo1T, H, H, H, 0); castT(P[CAMO_P_A2_OUT_W], h.Wo2T, H, H, H, 0);
+    castT(P[CAMO_P_A1_IN_W], h.WcRgT, H, H, 3 * H, 0); castT(P[CAMO_P_A2_IN_W] + HH, h.WcRgT, 2 * H, H, 3 * H, H);
+    castT(P[CAMO_P_A2_IN_W], h.WcKgT, H, H, 3 * H, 0); castT(P[CAMO_P_A1_IN_W] + HH, h.WcKgT, 2 * H, H, 3 * H, H);
+    const size_t t = T, tk = TK;
+    pad(h.X, t, w.Tp, D); pad(h.R, t, w.Tp, H); pad(h.O, t, w.Tp, H); pad(h.Y, t, w.Tp, H); pad(h.dH1, t, w.Tp, 2 * H);
+    pad(h.dU, t, w.Tp, H); pad(h.dQKV, t, w.Tp, 3 * H); pad(h.dR, t, w.Tp, H);
+    pad(h.KG, tk, w.TKp, Dk); pad(h.G, tk, w.TKp, H); pad(h.O2, tk, w.TKp, H); pad(h.Y2, tk, w.TKp, H); pad(h.dH2, tk, w.TKp, 2 * H);
+    pad(h.dU2, tk, w.TKp, H); pad(h.dQKVkg, tk, w.TKp, 3 * H); pad(h.dG, tk, w.TKp, H);
+    CK(launch_prep(pb, st), "prep (clear + bf16 casts)");
+  }
+  GB16 g(drop, st);
+  // input projections: fp32 for the residual stream, bf16 for the GEMMs that read them
+  g.nt(h.KG, Dk, h.Wkg, Dk, P[CAMO_P_KG_PROJ_B], w.G, H, h.G, H, TK, H, Dk);
+  g.nt(h.X, D, h.Wrg, D, P[CAMO_P_RG_PROJ_B], w.R, H, h.R, H, T, H, D);
+  CK(g.run(), "input projections");
+  // in-projections of both attention blocks (packed in_proj_weight: rows 0..H-1 = Wq, H..3H-1 = Wk|Wv)
+  g.nt(h.R, H, h.Win1, H, P[CAMO_P_A1_IN_B], w.Q, H, nullptr, 0, T, H, H);
+  g.nt(h.R, H, h.Win2 + HH, H, P[CAMO_P_A2_IN_B] + H, w.KV2, 2 * H, nullptr, 0, T, 2 * H, H);
+  g.nt(h.G, H, h.Win1 + HH, H, P[CAMO_P_A1_IN_B] + H, w.KV, 2 * H, nullptr, 0, TK, 2 * H, H);
+  g.nt(h.G, H, h.Win2, H, P[CAMO_P_A2_IN_B], w.Q2, H, nullptr, 0, TK, H, H);
+  CK(g.run(), "attention in-projections");
+  CK(launch_rg2kg_fwd_mfma(w.Q, w.KV, rg_offsets, w.P, nullptr, attn_rg2kg, B, T, max_nr, H, nh, Nk, drop, st, Bf16Dst{h.O, H}), "attn rg2kg fwd");
+  CK(launch_kg2rg_fwd_mfma(w.Q2, w.KV2, rg_offsets, w.P2, nullptr, B, H, nh, Nk, drop, st, Bf16Dst{h.O2, H}), "attn kg2rg fwd");
+  if (attn_kg2rg) CK(launch_attn_avg(w.P2, attn_kg2rg, T, nh, Nk, drop, st), "attn avg");
+  // out-projection + residual (fusion_model.py:119,130), then LayerNorm
+  set_res(g.nt(h.O, H, h.Wo1, H, P[CAMO_P_A1_OUT_B], w.U, H, nullptr, 0, T, H, H), w.R, H);
+  set_res(g.nt(h.O2, H, h.Wo2, H, P[CAMO_P_A2_OUT_B], w.U2, H, nullptr, 0, TK, H, H), w.G, H);
+  CK(g.run(), "attention out-projections");
+  {
+    LnSeg s0{w.U, w.Y, w.st1, P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], T, h.Y};
+    LnSeg s1{w.U2, w.Y2, w.st2, P[CAMO_P_LN2_W], P[CAMO_P_LN2_B], TK, h.Y2};
+    CK(launch_ln_fwd(s0, s1, H, st), "layernorm fwd");
+  }
+  // FFN first layers (ReLU + dropout fused), fusion_model.py:53-65
+  set_drop(g.nt(h.Y, H, h.W1, H, P[CAMO_P_F1_B0], w.H1, 2 * H, nullptr, 0, T, 2 * H, H, GF_RELU), SITE_FFN_RG);
+  set_drop(g.nt(h.Y2, H, h.W2, H, P[CAMO_P_F2_B0], w.H2, 2 * H, nullptr, 0, TK, 2 * H, H, GF_RELU), SITE_FFN_KG);
+  CK(g.run(), "ffn layer 0");
+  return 0;
+}
+
+// ---- node-level backward of the bf16 schedule (w.dcomb, w.dHm1, w.dHm2 hold the pooled gradients) ----
+int backward_nodes16(const camo_dims_t& d, const float* const* P, float* const* Gr, const int32_t* rg_offsets,
+                     const int32_t* row_sample, const float* inv_nr, int B, int T, int Nk, int max_nr, const Ws& w,
+                     const DropCfg& drop, hipStream_t st) {
+  const int H = d.hidden_dim, D = d.rg_dim, Dk = d.kg_dim, TK = B * Nk, nh = d.num_heads;
+  const size_t HH = (size_t)H * H;
+  const Ws::H16& h = w.h;
+  {
+    BcastSeg s0{w.H1, w.dHm1, 2 * H, row_sample, inv_nr, 0, nullptr, T, h.dH1};
+    BcastSeg s1{w.H2, w.dHm2, 2 * H, nullptr, nullptr, Nk, nullptr, TK, h.dH2};
+    CK(launch_relu_bcast_bwd(s0, s1, 2 * H, drop.scale, st), "relu bcast bwd");
+  }
+  GB16 g(drop, st);
+  // first FFN layer: dY = bcast(dpool)/n + dH1.W1 ; dW1 += dH1^T.Y
+  set_bcast(g.nt(h.dH1, 2 * H, h.W1T, 2 * H, nullptr, w.dY, H, nullptr, 0, T, H, 2 * H), w.dcomb, 2 * H, row_sample, inv_nr, 0);
+  set_bcast(g.nt(h.dH2, 2 * H, h.W2T, 2 * H, nullptr, w.dY2, H, nullptr, 0, TK, H, 2 * H), w.dcomb + H, 2 * H, nullptr, nullptr, Nk);
+  g.tn(h.dH1, 2 * H, h.Y, H, Gr[CAMO_P_F1_W0], H, Gr[CAMO_P_F1_B0], 2 * H, H, T);
+  g.tn(h.dH2, 2 * H, h.Y2, H, Gr[CAMO_P_F2_W0], H, Gr[CAMO_P_F2_B0], 2 * H, H, TK);
+  CK(g.run(), "ffn layer 0 bwd");
+  {
+    LnBwdSeg s0{w.U, w.dY, w.st1, P[CAMO_P_LN1_W], w.dU, Gr[CAMO_P_LN1_W], Gr[CAMO_P_LN1_B], T, h.dU};
+    LnBwdSeg s1{w.U2, w.dY2, w.st2, P[CAMO_P_LN2_W], w.dU2, Gr[CAMO_P_LN2_W], Gr[CAMO_P_LN2_B], TK, h.dU2};
+    CK(launch_ln_bwd(s0, s1, H, st), "layernorm bwd");
+  }
+  // out-projections
+  g.nt(h.dU, H, h.Wo1T, H, nullptr, w.dO, H, nullptr, 0, T, H, H);
+  g.nt(h.dU2, H, h.Wo2T, H, nullptr, w.dO2, H, nullptr, 0, TK, H, H);
+  g.tn(h.dU, H, h.O, H, Gr[CAMO_P_A1_OUT_W], H, Gr[CAMO_P_A1_OUT_B], H, H, T);
+  g.tn(h.dU2, H, h.O2, H, Gr[CAMO_P_A2_OUT_W], H, Gr[CAMO_P_A2_OUT_B], H, H, TK);
+  CK(g.run(), "out-projection bwd");
+  // attention cores.  Their node-side outputs are GEMM operands only, so they are written as bf16 straight into the
+  // concatenated [dQ | dK2 | dV2] (rg rows) and [dQ2 | dK | dV] (kg rows) operands of the in-projection backward.
+  CK(launch_rg2kg_bwd_mfma(w.Q, w.KV, w.P, w.dO, rg_offsets, nullptr, w.dKV, B, max_nr, H, nh, Nk, drop, st,
+                           Bf16Dst{h.dQKV, 3 * H}), "attn rg2kg bwd");
+  CK(launch_kg2rg_bwd_mfma(w.Q2, w.KV2, w.P2, w.dO2, rg_offsets, nullptr, nullptr, B, H, nh, Nk, drop, st,
+                           Bf16Dst{h.dQKVkg, 3 * H}, Bf16Dst{h.dQKV + H, 3 * H}, w.dKV, Bf16Dst{h.dQKVkg + H, 3 * H}), "attn kg2rg bwd");
+  // in-projections: one K = 3H product per side for the input gradient (dR = dU + [dQ|dK2|dV2].[Wq1;Wk2;Wv2]),
+  // and the four weight gradients
+  set_res(g.nt(h.dQKV, 3 * H, h.WcRgT, 3 * H, nullptr, nullptr, 0, h.dR, H, T, H, 3 * H), w.dU, H);
+  set_res(g.nt(h.dQKVkg, 3 * H, h.WcKgT, 3 * H, nullptr, nullptr, 0, h.dG, H, TK, H, 3 * H), w.dU2, H);
+  g.tn(h.dQKV, 3 * H, h.R, H, Gr[CAMO_P_A1_IN_W], H, Gr[CAMO_P_A1_IN_B], H, H, T);
+  g.tn(h.dQKV + H, 3 * H, h.R, H, Gr[CAMO_P_A2_IN_W] + HH, H, Gr[CAMO_P_A2_IN_B] + H, 2 * H, H, T);
+  g.tn(h.dQKVkg, 3 * H, h.G, H, Gr[CAMO_P_A2_IN_W], H, Gr[CAMO_P_A2_IN_B], H, H, TK);
+  g.tn(h.dQKVkg + H, 3 * H, h.G, H, Gr[CAMO_P_A1_IN_W] + HH, H, Gr[CAMO_P_A1_IN_B] + H, 2 * H, H, TK);
+  CK(g.run(), "in-projection bwd");
+  g.tn(h.dR, H, h.X, D, Gr[CAMO_P_RG_PROJ_W], D, Gr[CAMO_P_RG_PROJ_B], H, D, T);
+  g.tn(h.dG, H, h.KG, Dk, Gr[CAMO_P_KG_PROJ_W], Dk, Gr[CAMO_P_KG_PROJ_B], H, Dk, TK);
+  CK(g.run(), "input projection bwd");
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -274,8 +463,10 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
   const float* const* P = params;
   GB g(drop, precision, st);
   GB gt(drop, CAMO_PREC_F32, st);   // per-sample (B-row) GEMMs
-  // one memset for everything this step accumulates into with atomics (means now, dfused/dKV in backward)
-  CK((int)hipMemsetAsync(w.zero_base, 0, w.zero_bytes, st), "memset zero block");
+  // one clear of everything this step accumulates into with atomics (means now, dfused/dKV in backward);
+  // the bf16 schedule's prep launch does it along with its casts
+  const bool use16 = sched16_ok(d, P, precision, T, Nk, max_nr);
+  if (!use16) CK((int)hipMemsetAsync(w.zero_base, 0, w.zero_bytes, st), "memset zero block");
 
   if (d.fusion_type == CAMO_FUSION_LATE) {
     // LateFusion.forward, fusion_model.py:164-171
@@ -299,9 +490,12 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
   // schedule on MI355X (each stage inside the workgroup is as latency-bound as the separate launches were), so
   // the general schedule below (any dims, exact-f32 mode) stays the default and the reference it is tested against.
   const char* fenv = std::getenv("CAMO_FUSED");
-  const bool fused = fenv && fenv[0] == '1' && precision == CAMO_PREC_BF16 && P[CAMO_P_RG_PROJ_W] &&
+  const bool fused = !use16 && fenv && fenv[0] == '1' && precision == CAMO_PREC_BF16 && P[CAMO_P_RG_PROJ_W] &&
                      rg_fused_supported(D, H, nh, Nk);
   const size_t HH2 = (size_t)H * H;
+  if (use16) {
+    if (int e = forward_nodes16(d, P, rg, rg_offsets, kg, B, T, Nk, max_nr, w, attn_rg2kg, attn_kg2rg, drop, st)) return e;
+  } else {
   if (P[CAMO_P_KG_PROJ_W]) { g.nt(kg, Dk, P[CAMO_P_KG_PROJ_W], Dk, P[CAMO_P_KG_PROJ_B], w.G, H, TK, H, Dk); G = w.G; }
   if (!fused && P[CAMO_P_RG_PROJ_W]) { g.nt(rg, D, P[CAMO_P_RG_PROJ_W], D, P[CAMO_P_RG_PROJ_B], w.R, H, T, H, D); R = w.R; }
   CK(g.run(), "input projections");
@@ -349,6 +543,7 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
   if (!fused) set_drop(g.nt(w.Y, H, P[CAMO_P_F1_W0], H, P[CAMO_P_F1_B0], w.H1, 2 * H, T, 2 * H, H, GF_RELU), SITE_FFN_RG);
   set_drop(g.nt(w.Y2, H, P[CAMO_P_F2_W0], H, P[CAMO_P_F2_B0], w.H2, 2 * H, TK, 2 * H, H, GF_RELU), SITE_FFN_KG);
   CK(g.run(), "ffn layer 0");
+  }
   // per-sample means of Y and H1d, then the second FFN layer on the means (mean-pool linearity)
   if (fused) {   // the node-level sums were accumulated by the fused kernel
     SegMean sm[2] = {{w.Y2, H, H, nullptr, Nk, w.Y2mean, H}, {w.H2, 2 * H, 2 * H, nullptr, Nk, w.H2mean, 2 * H}};
@@ -421,6 +616,8 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
   gt.tn(w.dcomb, 2 * H, w.H1mean, 2 * H, Gr[CAMO_P_F1_W3], 2 * H, Gr[CAMO_P_F1_B3], H, 2 * H, B);
   gt.tn(w.dcomb + H, 2 * H, w.H2mean, 2 * H, Gr[CAMO_P_F2_W3], 2 * H, Gr[CAMO_P_F2_B3], H, 2 * H, B);
   CK(gt.run(), "ffn layer 3 bwd (pooled)");
+  if (sched16_ok(d, P, precision, T, Nk, max_nr))
+    return backward_nodes16(d, P, Gr, rg_offsets, row_sample, inv_nr, B, T, Nk, max_nr, w, drop, st);
   {
     BcastSeg s0{w.H1, w.dHm1, 2 * H, row_sample, inv_nr, 0, w.dH1, T};
     BcastSeg s1{w.H2, w.dHm2, 2 * H, nullptr, nullptr, Nk, w.dH2, TK};
@@ -495,6 +692,22 @@ int camo_debug_gemm(const float* A, int32_t lda, const float* B, int32_t ldb, fl
   GemmProb& p = g.add(A, lda, B, ldb, C, ldc, M, N, K, flags);
   p.bias = bias; p.res = res; p.ldr = ldr; p.bias_grad = bias_grad;
   CK(g.run(), "debug gemm");
+  return 0;
+}
+
+int camo_debug_gemm16(const void* A16, int32_t lda, const void* B16, int32_t ldb, float* C, int32_t ldc, void* C16,
+                      int32_t ldc16, const float* bias, const float* res, int32_t ldr, float* bias_grad, int32_t M,
+                      int32_t N, int32_t K, int32_t flags, void* stream) {
+  if (!A16 || !B16 || (!C && !C16) || M < 1 || N < 1 || K < 1) return fail(CAMO_E_ARG, "bad gemm16 arguments");
+  Gemm16Batch gb;
+  std::memset(&gb, 0, sizeof(gb));
+  gb.drop = make_drop(0, 0.f, 0);
+  Gemm16Prob& p = gb.p[0];
+  gb.n = 1;
+  p.A = static_cast<const unsigned short*>(A16); p.lda = lda; p.B = static_cast<const unsigned short*>(B16); p.ldb = ldb;
+  p.C = C; p.ldc = ldc; p.C16 = static_cast<unsigned short*>(C16); p.ldc16 = ldc16;
+  p.bias = bias; p.res = res; p.ldr = ldr; p.bias_grad = bias_grad; p.M = M; p.N = N; p.K = K; p.flags = flags; p.aux_scale = 1.f;
+  CK(launch_gemm16_batch(gb, static_cast<hipStream_t>(stream)), "debug gemm16");
   return 0;
 }
 

@@ -38,6 +38,7 @@ struct GemmBatch {
   GemmProb p[GEMM_MAXP];
   int n;
   DropCfg drop;
+  int dev;   // developer experiments (CAMO_DEV_EPI), 0 in production
 };
 
 // precision: CAMO_PREC_F32 / CAMO_PREC_BF16.  Returns hipError_t as int.
@@ -47,3 +48,6 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream);
 // around every grouped-GEMM launch between prof_begin and prof_end.  Single-threaded use only.
 int gemm_prof_begin(int max_launches);
 int gemm_prof_end(double* total_ms, int* launches, double* total_flops);
+// used by the launchers of both grouped-GEMM kernels: returns a slot (or -1 when timing is off)
+int gemm_prof_open(hipStream_t stream, double flops);
+void gemm_prof_close(int slot, hipStream_t stream);

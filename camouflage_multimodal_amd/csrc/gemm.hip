@@ -98,11 +98,6 @@ __device__ __forceinline__ float4 raw_ks(const Operand& o, int c, int k) {
                      base[(size_t)min(k + 2, km) * o.ld], base[(size_t)min(k + 3, km) * o.ld]);
 }
 
-__device__ __forceinline__ unsigned short f2bf(float f) {
-  __bf16 b = (__bf16)f;     // round-to-nearest-even, NaN stays NaN
-  return __builtin_bit_cast(unsigned short, b);
-}
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
 // value -> C with the problem's fused epilogue (v already holds acc + bias)
 __device__ __forceinline__ void epilogue_store(const GemmProb& P, const DropCfg& drop, float v, int row, int col) {
@@ -135,23 +130,23 @@ struct TileCtx {
 // K loop shared by both precisions: tile t sits in LDS buffer t & 1; while it is multiplied, tile
 // t+1 (loaded PIPE-1 iterations ago into stage (t+1) % PIPE) is converted into the other buffer and
 // that stage is refilled with tile t+1+PIPE.  One barrier per tile.
+// The body is STRAIGHT-LINE on purpose: every gload is unconditional (addresses are clamped into the
+// block's K range, tiles past `nt` are masked to zero and multiply as zeros, the trip count is nt
+// rounded up to PIPE).  With "if (more tiles) gload(...)" the refilled stage registers became PHIs at
+// the join, hipcc materialised them as v_mov copies right after the loads, and the s_waitcnt vmcnt(0)
+// in front of those copies drained the whole pipeline every K step (0.85 us per 32-deep tile).
 #define PIPELINE_LOOP                                                                         \
-  _Pragma("unroll") for (int j = 0; j < PIPE; ++j)                                            \
-    if (j < nt) gload(st[j], kbeg + j * BK);                                                  \
+  _Pragma("unroll") for (int j = 0; j < PIPE; ++j) gload(st[j], kbeg + j * BK);               \
   sstore(st[0], kbeg, 0);                                                                     \
-  if (PIPE < nt) gload(st[0], kbeg + PIPE * BK);                                              \
+  gload(st[0], kbeg + PIPE * BK);                                                             \
   __syncthreads();                                                                            \
   for (int t = 0; t < nt; t += PIPE) {                                                        \
     _Pragma("unroll") for (int j = 0; j < PIPE; ++j) {                                        \
       const int tt = t + j;                                                                   \
-      if (tt < nt) {                                                                          \
-        if (tt + 1 < nt) {                                                                    \
-          sstore(st[(j + 1) % PIPE], kbeg + (tt + 1) * BK, (j + 1) & 1);                      \
-          if (tt + 1 + PIPE < nt) gload(st[(j + 1) % PIPE], kbeg + (tt + 1 + PIPE) * BK);     \
-        }                                                                                     \
-        compute(j & 1);                                                                       \
-        __syncthreads();                                                                      \
-      }                                                                                       \
+      sstore(st[(j + 1) % PIPE], kbeg + (tt + 1) * BK, (j + 1) & 1);                          \
+      gload(st[(j + 1) % PIPE], kbeg + (tt + 1 + PIPE) * BK);                                 \
+      compute(j & 1);                                                                         \
+      __syncthreads();                                                                        \
     }                                                                                         \
   }
 
@@ -166,7 +161,8 @@ template <int PREC, int PIPE, bool akm, bool bkm, bool VEC>
 __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmProb& P, const TileCtx tc, char* smem_raw) {
   const int m0 = tc.m0, n0 = tc.n0, tn = tc.tn, kbeg = tc.kbeg, kend = tc.kend;
   const int M = P.M, N = P.N;
-  const Operand oa{P.A, P.lda, akm, VEC, M, P.K}, ob{P.B, P.ldb, bkm, VEC, N, P.K};
+  // (K field = end of this block's K range: loads past it re-read its last rows instead of the next split's)
+  const Operand oa{P.A, P.lda, akm, VEC, M, kend}, ob{P.B, P.ldb, bkm, VEC, N, kend};
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -191,6 +187,11 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
   // thread -> staging slot maps.  f32: slot s = tid + 256 i; m-major (row s>>3, k4 s&7), k-major
   // (k s>>4 | s>>5, m4 s&15 | s&31).  bf16 k-major sources are transposed in registers, so there a
   // thread loads a 2(k) x 4(m) block of A and a 4(k) x 4(n) block of B.
+  // bf16 k-major maps (see the LDS image note below): A thread = 2(k) x 4(m) block, B thread = 4(k) x 4(n) block.
+  // Eight neighbouring lanes take eight neighbouring 4-row blocks (128 contiguous bytes of a source row), the next
+  // lane bits walk the dwords of one 16-B chunk, the wave index picks the chunk.
+  const int ka_tm = (tid & 7) | (((tid >> 5) & 1) << 3), ka_kp = ((tid >> 3) & 3) | ((tid >> 6) << 2);
+  const int kb_tn = (tid & 7) | (((tid >> 4) & 3) << 3), kb_q = ((tid >> 3) & 1) | ((tid >> 6) << 1);
   auto gload = [&](Stage& r, int k0) {
     if constexpr (PREC == 0 || !akm) {
 #pragma unroll
@@ -199,7 +200,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
         r.a[i] = !akm ? raw_mm<VEC>(oa, m0 + (s >> 3), k0 + (s & 7) * 4) : raw_km<VEC>(oa, m0 + (s & 15) * 4, k0 + (s >> 4));
       }
     } else {
-      const int kq = 4 * (tid >> 5) + 2 * ((tid >> 4) & 1), m = m0 + (tid & 15) * 4;
+      const int kq = 2 * ka_kp, m = m0 + 4 * ka_tm;
       r.a[0] = raw_km<VEC>(oa, m, k0 + kq);
       r.a[1] = raw_km<VEC>(oa, m, k0 + kq + 1);
     }
@@ -210,7 +211,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
         r.b[i] = !bkm ? raw_mm<VEC>(ob, n0 + (s >> 3), k0 + (s & 7) * 4) : raw_km<VEC>(ob, n0 + (s & 31) * 4, k0 + (s >> 5));
       }
     } else {
-      const int kq = 4 * (tid >> 5), n = n0 + (tid & 31) * 4;
+      const int kq = 4 * kb_q, n = n0 + 4 * kb_tn;
 #pragma unroll
       for (int e = 0; e < 4; ++e) r.b[e] = raw_km<VEC>(ob, n, k0 + kq + e);
     }
@@ -228,7 +229,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
         r.a[i] = !akm ? mask_mm(oa, r.a[i], m0 + (s >> 3), k0 + (s & 7) * 4, kend) : mask_km(oa, r.a[i], m0 + (s & 15) * 4, k0 + (s >> 4), kend);
       }
     } else {
-      const int kq = 4 * (tid >> 5) + 2 * ((tid >> 4) & 1), m = m0 + (tid & 15) * 4;
+      const int kq = 2 * ka_kp, m = m0 + 4 * ka_tm;
       r.a[0] = mask_km(oa, r.a[0], m, k0 + kq, kend); r.a[1] = mask_km(oa, r.a[1], m, k0 + kq + 1, kend);
     }
     if constexpr (PREC == 0 || !bkm) {
@@ -238,7 +239,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
         r.b[i] = !bkm ? mask_mm(ob, r.b[i], n0 + (s >> 3), k0 + (s & 7) * 4, kend) : mask_km(ob, r.b[i], n0 + (s & 31) * 4, k0 + (s >> 5), kend);
       }
     } else {
-      const int kq = 4 * (tid >> 5), n = n0 + (tid & 31) * 4;
+      const int kq = 4 * kb_q, n = n0 + 4 * kb_tn;
 #pragma unroll
       for (int e = 0; e < 4; ++e) r.b[e] = mask_km(ob, r.b[e], n, k0 + kq + e, kend);
     }
@@ -311,6 +312,11 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
     unsigned short* Bbuf = Abuf + 2 * A_BF16;                              // [2][B_BF16]
     // bf16 image [row][k], 80-B rows.  m-major sources: a float4 is 4 consecutive k of one row -> one
     // 8-B store.  k-major sources: B 4(k) x 4(n) block -> four 8-B stores; A 2(k) x 4(m) -> four 4-B stores.
+    // A thread's four stores go to rows 4t..4t+3 and 80-B rows put row r at bank 20r: blocks 4t, 4(t+2), ...
+    // land on the same banks (the first layout was 8- and 16-way conflicted and the K loop of the weight
+    // gradients ran at LDS-store speed).  So k-major images swap the four 16-B chunks of a row by
+    // chunk ^= (row >> 3) & 3: with the thread maps above every 32-lane (b32) / 16-lane (b64) store group
+    // covers 32 distinct banks, and the 8-lane groups of the b128 fragment reads still do.
     auto sstore = [&](Stage& r, int k0, int buf) {
       mask_stage(r, k0);
       unsigned short* As = Abuf + buf * A_BF16; unsigned short* Bs = Bbuf + buf * B_BF16;
@@ -321,11 +327,12 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
           *reinterpret_cast<uint2*>(As + (s >> 3) * LDH + (s & 7) * 4) = make_uint2(pack2(r.a[i].x, r.a[i].y), pack2(r.a[i].z, r.a[i].w));
         }
       } else {
-        const int kq = 4 * (tid >> 5) + 2 * ((tid >> 4) & 1), m = (tid & 15) * 4;
-        *reinterpret_cast<uint32_t*>(As + (m + 0) * LDH + kq) = pack2(r.a[0].x, r.a[1].x);
-        *reinterpret_cast<uint32_t*>(As + (m + 1) * LDH + kq) = pack2(r.a[0].y, r.a[1].y);
-        *reinterpret_cast<uint32_t*>(As + (m + 2) * LDH + kq) = pack2(r.a[0].z, r.a[1].z);
-        *reinterpret_cast<uint32_t*>(As + (m + 3) * LDH + kq) = pack2(r.a[0].w, r.a[1].w);
+        const int m = 4 * ka_tm;
+        const int off = (((ka_kp >> 2) ^ ((ka_tm >> 1) & 3)) << 3) + 2 * (ka_kp & 3);   // swizzled chunk, dword in chunk
+        *reinterpret_cast<uint32_t*>(As + (m + 0) * LDH + off) = pack2(r.a[0].x, r.a[1].x);
+        *reinterpret_cast<uint32_t*>(As + (m + 1) * LDH + off) = pack2(r.a[0].y, r.a[1].y);
+        *reinterpret_cast<uint32_t*>(As + (m + 2) * LDH + off) = pack2(r.a[0].z, r.a[1].z);
+        *reinterpret_cast<uint32_t*>(As + (m + 3) * LDH + off) = pack2(r.a[0].w, r.a[1].w);
       }
       if (!bkm) {
 #pragma unroll
@@ -334,7 +341,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
           *reinterpret_cast<uint2*>(Bs + (s >> 3) * LDH + (s & 7) * 4) = make_uint2(pack2(r.b[i].x, r.b[i].y), pack2(r.b[i].z, r.b[i].w));
         }
       } else {
-        const int kq = 4 * (tid >> 5), n = (tid & 31) * 4;
+        const int n = 4 * kb_tn;
+        const int kq = (((kb_q >> 1) ^ ((kb_tn >> 1) & 3)) << 3) + 4 * (kb_q & 1);      // swizzled chunk, half of it
         *reinterpret_cast<uint2*>(Bs + (n + 0) * LDH + kq) = make_uint2(pack2(r.b[0].x, r.b[1].x), pack2(r.b[2].x, r.b[3].x));
         *reinterpret_cast<uint2*>(Bs + (n + 1) * LDH + kq) = make_uint2(pack2(r.b[0].y, r.b[1].y), pack2(r.b[2].y, r.b[3].y));
         *reinterpret_cast<uint2*>(Bs + (n + 2) * LDH + kq) = make_uint2(pack2(r.b[0].z, r.b[1].z), pack2(r.b[2].z, r.b[3].z));
@@ -345,15 +353,19 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
       const unsigned short* As = Abuf + buf * A_BF16; const unsigned short* Bs = Bbuf + buf * B_BF16;
       bf16x8 a[2], b[2][2];
       {
-        const unsigned short* p = As + (wr * 32 + l31) * LDH + 8 * h;
-        a[0] = *reinterpret_cast<const bf16x8*>(p);
-        a[1] = *reinterpret_cast<const bf16x8*>(p + 16);
+        const int row = wr * 32 + l31;
+        const int c = akm ? (h ^ ((row >> 3) & 3)) : h;
+        const unsigned short* p = As + row * LDH;
+        a[0] = *reinterpret_cast<const bf16x8*>(p + 8 * c);
+        a[1] = *reinterpret_cast<const bf16x8*>(p + 8 * (c ^ 2));
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const unsigned short* p = Bs + (wc * 64 + j * 32 + l31) * LDH + 8 * h;
-        b[j][0] = *reinterpret_cast<const bf16x8*>(p);
-        b[j][1] = *reinterpret_cast<const bf16x8*>(p + 16);
+        const int row = wc * 64 + j * 32 + l31;
+        const int c = bkm ? (h ^ ((row >> 3) & 3)) : h;
+        const unsigned short* p = Bs + row * LDH;
+        b[j][0] = *reinterpret_cast<const bf16x8*>(p + 8 * c);
+        b[j][1] = *reinterpret_cast<const bf16x8*>(p + 8 * (c ^ 2));
       }
       if (do_bsum && tid < BM) {
         // bias gradient from the bf16 image (what the MFMA sees), summed in fp32
@@ -392,7 +404,11 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rowb + (r & 3) + 8 * (r >> 2);
-          if (row < M) atomicAdd(cp + (size_t)row * P.ldc, acc[j][r] + bv);
+          if (row < M) {
+            if (gb.dev == 0) atomicAdd(cp + (size_t)row * P.ldc, acc[j][r] + bv);
+            else if (gb.dev == 1) cp[(size_t)row * P.ldc] = acc[j][r] + bv;
+            else if (acc[j][r] == 12345.678f) cp[(size_t)row * P.ldc] = acc[j][r] + bv;
+          }
         }
       } else {
 #pragma unroll 4
@@ -550,6 +566,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmBatch gb) {
     auto lda_ = [&](int kb) { const int k = kb * 16 + 4 * q; return akm ? raw_ks(oa, m0 + x, k) : (oa.vec ? raw_mm<true>(oa, m0 + x, k) : raw_mm<false>(oa, m0 + x, k)); };
     auto ldb_ = [&](int kb) { const int k = kb * 16 + 4 * q; return bkm ? raw_ks(ob, n0 + x, k) : (ob.vec ? raw_mm<true>(ob, m0 * 0 + n0 + x, k) : raw_mm<false>(ob, n0 + x, k)); };
     // two k blocks in flight; raw loads are address-clamped, masking happens at the point of use
+    // (a 4-deep version with 8 blocks in flight measured SLOWER: the extra clamped loads cost more than the
+    // latency they hide on these few-KB operands)
     float4 a0 = lda_(kb0), b0 = ldb_(kb0), a1 = lda_(kb0 + kbstep), b1 = ldb_(kb0 + kbstep);
     for (int kb = kb0; kb < nkb; kb += kbstep) {
       float4 a = a0, b = b0;
@@ -636,6 +654,18 @@ int gemm_prof_end(double* total_ms, int* launches, double* total_flops) {
   return 0;
 }
 
+int gemm_prof_open(hipStream_t stream, double flops) {
+  if (!g_prof.on || 2 * (g_prof.used + 1) > g_prof.ev.size()) return -1;
+  g_prof.flops.push_back(flops);
+  (void)hipEventRecord(g_prof.ev[2 * g_prof.used], stream);
+  return (int)g_prof.used;
+}
+void gemm_prof_close(int slot, hipStream_t stream) {
+  if (slot < 0) return;
+  (void)hipEventRecord(g_prof.ev[2 * slot + 1], stream);
+  ++g_prof.used;
+}
+
 static int launch_skinny(GemmBatch& gb, hipStream_t stream) {
   int total = 0;
   for (int i = 0; i < gb.n; ++i) {
@@ -662,6 +692,10 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
     }
     if (skinny) return launch_skinny(gb, stream);
   }
+  // (developer knob for sweeps: K tiles per split-K block of a weight-gradient problem)
+  static const int kcap = [] { const char* e = std::getenv("CAMO_DEV_TN_KCAP"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 12; }();
+  static const int dev_epi = [] { const char* e = std::getenv("CAMO_DEV_EPI"); return e ? std::atoi(e) : 0; }();
+  gb.dev = dev_epi;
   // tiles without split-K
   for (int i = 0; i < gb.n; ++i) {
     GemmProb& p = gb.p[i];
@@ -676,7 +710,7 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
       // weight-gradient GEMM: small output, long contraction.  A block's K loop is serial
       // (~1 us per 32-deep tile), so cap it at ~12 tiles and let the fp32 atomics merge the splits.
       const int ktiles = (p.K + BK - 1) / BK;
-      ksplit = (ktiles + 11) / 12;
+      ksplit = (ktiles + kcap - 1) / kcap;
     }
     const int ktiles = (p.K + BK - 1) / BK;
     const int per = (ktiles + ksplit - 1) / ksplit;
@@ -688,24 +722,23 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
   }
   if (total == 0) return 0;
   const size_t lds = precision == 0 ? (size_t)2 * (A_F32 + B_F32) * 4 : (size_t)2 * (A_BF16 + B_BF16) * 2;
-  const bool prof = g_prof.on && 2 * (g_prof.used + 1) <= g_prof.ev.size();
-  if (prof) {
+  int prof = -1;
+  if (g_prof.on) {
     double fl = 0.0;
     for (int i = 0; i < gb.n; ++i) fl += 2.0 * gb.p[i].M * (double)gb.p[i].N * gb.p[i].K;
-    g_prof.flops.push_back(fl);
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.used], stream);
+    prof = gemm_prof_open(stream, fl);
   }
   const bool deep = total <= 320;
   if (precision == 0) {
     if (deep) hipLaunchKernelGGL((gemm_grouped_kernel<0, 4>), dim3(total), dim3(256), lds, stream, gb, total);
     else      hipLaunchKernelGGL((gemm_grouped_kernel<0, 2>), dim3(total), dim3(256), lds, stream, gb, total);
   } else {
-    if (deep) hipLaunchKernelGGL((gemm_grouped_kernel<1, 4>), dim3(total), dim3(256), lds, stream, gb, total);
+    static const int dev_pipe = [] { const char* e = std::getenv("CAMO_DEV_PIPE"); return e ? std::atoi(e) : 0; }();
+    if (deep && dev_pipe == 8) hipLaunchKernelGGL((gemm_grouped_kernel<1, 8>), dim3(total), dim3(256), lds, stream, gb, total);
+    else if (deep && dev_pipe == 6) hipLaunchKernelGGL((gemm_grouped_kernel<1, 6>), dim3(total), dim3(256), lds, stream, gb, total);
+    else if (deep) hipLaunchKernelGGL((gemm_grouped_kernel<1, 4>), dim3(total), dim3(256), lds, stream, gb, total);
     else      hipLaunchKernelGGL((gemm_grouped_kernel<1, 2>), dim3(total), dim3(256), lds, stream, gb, total);
   }
-  if (prof) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], stream);
-    ++g_prof.used;
-  }
+  gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }

@@ -1,0 +1,45 @@
+// Grouped GEMM on bf16-RESIDENT operands (gfx950): the node-level GEMMs of the bf16 schedule.
+//
+// gemm.hip reads fp32 operands and rounds them to bf16 while staging; on MI355X its K loop is bound by
+// that VALU work (mask + convert + pack: 100-150 vector instructions per 32-deep step per wave at 4
+// cycles each against 4 MFMAs).  Here every operand already sits in HBM as bf16 -- producers emit a bf16
+// copy of what a GEMM will read (fusion_abi.hip, "schedule16") -- so a K step is loads, LDS traffic and
+// MFMAs only, and the operand bytes read from HBM halve.
+//
+// Supported per problem (checked by the launcher):
+//   NT : C[M,N] = epi(A[M,K] . B[N,K]^T)        A, B row-major bf16, K % 64 == 0        (x.W^T, dy.(W^T)^T)
+//   TN : C[M,N] += A[K,M]^T . B[K,N]  (fp32 atomics, split-K)   A, B row-major bf16 with K rows; rows up to
+//        round_up(K, 128) must be readable, and zero in one operand / finite in the other (the workspace
+//        pads and clears them); M % 8 == 0, N % 8 == 0                                    (dW += dy^T.x)
+// N % 4 == 0, 16-byte aligned pointers and leading dimensions throughout.
+#pragma once
+#include "common.h"
+#include "gemm.h"   // GF_* flags
+
+#define GEMM16_MAXP 8
+
+struct Gemm16Prob {
+  const unsigned short* A; const unsigned short* B;   // bf16 bit patterns
+  float* C;                 // fp32 output (or null)
+  unsigned short* C16;      // bf16 copy of the output (or null); NT only
+  const float* bias;        // [N] or null
+  const float* res;         // fp32 residual / aux (ld = ldr) or null
+  float* bias_grad;         // TN: [M] += sum_k A(k, m)
+  int M, N, K;
+  int lda, ldb, ldc, ldc16, ldr;
+  int flags;                // GF_RELU | GF_DROPOUT | GF_RELU_BWD | GF_RES_BCAST; GF_A_KMAJOR|GF_B_KMAJOR together = TN
+  uint32_t drop_site;
+  float aux_scale;
+  const int* row_sample; const float* inv_nr; int uniform_n;
+  // filled by the launcher
+  int tiles_n, ksplit, kchunk, tile_begin;
+};
+
+struct Gemm16Batch {
+  Gemm16Prob p[GEMM16_MAXP];
+  int n;
+  DropCfg drop;
+};
+
+// Returns hipError_t as int; hipErrorInvalidValue for an unsupported problem.
+int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream);

@@ -1,0 +1,349 @@
+// Grouped GEMM on bf16-resident operands for gfx950 (see gemm16.h for the contract).
+//
+// Block tile 64(M) x 128(N), K step 64, 4 waves as 2(M) x 2(N), each wave two 32x32 fp32 accumulators on
+// v_mfma_f32_32x32x16_bf16.  Global -> registers -> LDS staging with PIPE register stages (16-byte loads
+// from a wave-uniform tile pointer plus a loop-invariant 32-bit lane offset: no address arithmetic, no
+// masks and no conversions inside the K loop), double-buffered LDS, one barrier per K step.
+//
+// LDS images (bank rules: MI355X_MICROARCH.md, LDS):
+//   NT  : both operands k-contiguous.  [row][64 k] bf16 with a 144-byte pitch (128 + 16): the sixteen rows of
+//         a ds_read_b128 lane group start 144*r bytes apart = sixteen distinct 16-byte bank quads.
+//   TN  : both operands are stored [k][m] / [k][n] (the contraction runs over ROWS of dy and x).  The tile is
+//         written as it is read from HBM, [k row][m] with pitch 192 B (A, 64 m) / 320 B (B, 128 n), and the
+//         MFMA fragments (8 consecutive k per lane) come out of ds_read_b64_tr_b16, the hardware transposing
+//         read: a 16-lane group fetches 4 k rows x 16 columns and each lane receives its column's 4 k values.
+//         Pitch = 64 mod 256 puts the 4 rows of a 32-lane group on the four 64-byte bank quarters.
+// Epilogue: NT accumulates C^T (weight-side operand as MFMA "A"), so a lane owns 4 consecutive columns of
+// one output row -> 16-byte fp32 stores and 8-byte bf16 stores; TN keeps C orientation for its fp32 atomics
+// (a wave-instruction covers 128 contiguous bytes of two rows).
+#include "gemm16.h"
+
+#include <cstdlib>
+
+namespace {
+
+constexpr int BM = 64, BN = 128, BK = 64;
+constexpr int PM = 144;                 // row pitch (bytes) of a k-contiguous image
+constexpr int PKA = 192, PKB = 320;     // k-row pitch (bytes) of the k-major images
+constexpr int A_NT_BYTES = BM * PM;     // 9216
+constexpr int A_TN_BYTES = BK * PKA;    // 12288
+constexpr int BUF_BYTES = 32768;        // >= 9216 + 128*144 = 27648 (NT), = 12288 + 64*320 (TN)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct Stage { u32x4 a[2], b[4]; };
+
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+// The staged-K loop shared by both layouts.  Straight-line on purpose (see gemm.hip, PIPELINE_LOOP): every
+// gload is unconditional (tile index clamped into the block's range), tiles past `nt` are reloads of the
+// last tile that get written to LDS and never multiplied.
+#define G16_PIPELINE_LOOP                                                                      \
+  _Pragma("unroll") for (int j = 0; j < PIPE; ++j) gload(st[j], j);                            \
+  sstore(st[0], 0);                                                                            \
+  gload(st[0], PIPE);                                                                          \
+  __syncthreads();                                                                             \
+  for (int t = 0; t < nt; t += PIPE) {                                                         \
+    _Pragma("unroll") for (int j = 0; j < PIPE; ++j) {                                         \
+      sstore(st[(j + 1) % PIPE], (j + 1) & 1);                                                 \
+      gload(st[(j + 1) % PIPE], t + j + 1 + PIPE);                                             \
+      if (t + j < nt) compute(j & 1);                                                          \
+      __syncthreads();                                                                         \
+    }                                                                                          \
+  }
+
+// ------------------------------------------------------------------------------------------ NT
+template <int PIPE>
+__device__ __forceinline__ void body_nt(const Gemm16Batch& gb, const Gemm16Prob& P, int m0, int n0, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int M = P.M, N = P.N;
+  const int nt = P.K / BK;
+
+  // thread -> 16-byte chunk slots: slot s = tid + 256 i is (row s >> 3, chunk s & 7); 8 neighbouring lanes
+  // move one row's 128 contiguous bytes
+  uint32_t goa[2], gob[4];
+  int la[2], lb[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int s = tid + 256 * i, row = s >> 3, c = s & 7;
+    goa[i] = ((uint32_t)min(m0 + row, M - 1) * (uint32_t)P.lda + 8u * c) * 2u;
+    la[i] = row * PM + 16 * c;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int s = tid + 256 * i, row = s >> 3, c = s & 7;
+    gob[i] = ((uint32_t)min(n0 + row, N - 1) * (uint32_t)P.ldb + 8u * c) * 2u;
+    lb[i] = A_NT_BYTES + row * PM + 16 * c;
+  }
+  const char* Ab = reinterpret_cast<const char*>(P.A);
+  const char* Bb = reinterpret_cast<const char*>(P.B);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  Stage st[PIPE];
+
+  auto gload = [&](Stage& r, int kt) {
+    const int k = min(kt, nt - 1);                                   // wave-uniform
+    const char* a = Ab + (size_t)k * (BK * 2);
+    const char* b = Bb + (size_t)k * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r.a[i] = *reinterpret_cast<const u32x4*>(a + goa[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.b[i] = *reinterpret_cast<const u32x4*>(b + gob[i]);
+  };
+  auto sstore = [&](const Stage& r, int buf) {
+    char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(base + la[i]) = r.a[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(base + lb[i]) = r.b[i];
+  };
+  // lane (l31, h) of MFMA step s holds k = 16 s + 8 h .. + 7 of its row: byte 32 s + 16 h
+  const int fa = (wr * 32 + l31) * PM + 16 * h;
+  const int fb = A_NT_BYTES + (wc * 64 + l31) * PM + 16 * h;
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(base + fa + 32 * s);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(base + fb + 32 * s);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(base + fb + 32 * PM + 32 * s);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, acc[0], 0, 0, 0);   // C^T
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[1], 0, 0, 0);
+    }
+  };
+  G16_PIPELINE_LOOP
+
+  // ---- epilogue.  C^T orientation: lane&31 = output row, registers 4g..4g+3 = columns c0..c0+3,
+  // c0 = 32 j + 8 g + 4 (lane>>5)
+  const int row = m0 + wr * 32 + l31;
+  if (row >= M) return;
+  const int flags = P.flags;
+  const float floor_ = (flags & GF_RELU) ? 0.f : -INFINITY;
+  const bool dodrop = (flags & GF_DROPOUT) && gb.drop.p > 0.f;
+  const float* rrow = nullptr; float rscale = 1.f;
+  if (P.res) {
+    if (flags & GF_RES_BCAST) {
+      int sb;
+      if (P.row_sample) { sb = P.row_sample[row]; rscale = P.inv_nr[sb]; }
+      else { sb = row / P.uniform_n; rscale = 1.0f / (float)P.uniform_n; }
+      rrow = P.res + (size_t)sb * P.ldr;
+    } else {
+      rrow = P.res + (size_t)row * P.ldr;
+    }
+  }
+  float* crow = P.C ? P.C + (size_t)row * P.ldc : nullptr;
+  unsigned short* hrow = P.C16 ? P.C16 + (size_t)row * P.ldc16 : nullptr;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c0 = n0 + wc * 64 + j * 32 + 8 * g + 4 * h;
+      if (c0 < N) {
+        float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+        if (P.bias) { const float4 bv = *reinterpret_cast<const float4*>(P.bias + c0); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+        v.x = fmaxf(v.x, floor_); v.y = fmaxf(v.y, floor_); v.z = fmaxf(v.z, floor_); v.w = fmaxf(v.w, floor_);
+        if (dodrop) {
+          const uint32_t idx = (uint32_t)row * (uint32_t)N + (uint32_t)c0;
+          v.x *= drop_mult(gb.drop, P.drop_site, idx); v.y *= drop_mult(gb.drop, P.drop_site, idx + 1);
+          v.z *= drop_mult(gb.drop, P.drop_site, idx + 2); v.w *= drop_mult(gb.drop, P.drop_site, idx + 3);
+        }
+        if (rrow) {
+          const float4 rv = *reinterpret_cast<const float4*>(rrow + c0);
+          if (flags & GF_RELU_BWD) {
+            v.x *= rv.x > 0.f ? P.aux_scale : 0.f; v.y *= rv.y > 0.f ? P.aux_scale : 0.f;
+            v.z *= rv.z > 0.f ? P.aux_scale : 0.f; v.w *= rv.w > 0.f ? P.aux_scale : 0.f;
+          } else {
+            v.x = fmaf(rv.x, rscale, v.x); v.y = fmaf(rv.y, rscale, v.y); v.z = fmaf(rv.z, rscale, v.z); v.w = fmaf(rv.w, rscale, v.w);
+          }
+        }
+        if (crow) *reinterpret_cast<float4*>(crow + c0) = v;
+        if (hrow) *reinterpret_cast<uint2*>(hrow + c0) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ TN
+template <int PIPE>
+__device__ __forceinline__ void body_tn(const Gemm16Prob& P, int m0, int n0, int kt0, int nt, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int M = P.M, N = P.N;
+
+  // slots: A tile = 64 k rows x 8 chunks (8 m each), B tile = 64 k rows x 16 chunks (8 n each)
+  uint32_t goa[2], gob[4];
+  int la[2], lb[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int s = tid + 256 * i, kr = s >> 3, c = s & 7;
+    goa[i] = ((uint32_t)kr * (uint32_t)P.lda + (uint32_t)min(m0 + 8 * c, M - 8)) * 2u;
+    la[i] = kr * PKA + 16 * c;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int s = tid + 256 * i, kr = s >> 4, c = s & 15;
+    gob[i] = ((uint32_t)kr * (uint32_t)P.ldb + (uint32_t)min(n0 + 8 * c, N - 8)) * 2u;
+    lb[i] = A_TN_BYTES + kr * PKB + 16 * c;
+  }
+  const char* Ab = reinterpret_cast<const char*>(P.A);
+  const char* Bb = reinterpret_cast<const char*>(P.B);
+  const size_t astep = (size_t)BK * P.lda * 2, bstep = (size_t)BK * P.ldb * 2;
+
+  f32x16 acc[2], accb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; accb[r] = 0.f; }
+  const bool do_bsum = P.bias_grad != nullptr && n0 == 0 && wc == 0;     // wave-uniform
+  const short one = (short)0x3F80;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
+  Stage st[PIPE];
+
+  auto gload = [&](Stage& r, int kt) {
+    const int k = kt0 + min(kt, nt - 1);                             // wave-uniform
+    const char* a = Ab + (size_t)k * astep;
+    const char* b = Bb + (size_t)k * bstep;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r.a[i] = *reinterpret_cast<const u32x4*>(a + goa[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.b[i] = *reinterpret_cast<const u32x4*>(b + gob[i]);
+  };
+  auto sstore = [&](const Stage& r, int buf) {
+    char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(base + la[i]) = r.a[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(base + lb[i]) = r.b[i];
+  };
+  // transposing reads: lane = 16 g + 4 q + p of its 32-lane half supplies (k row .. + q, columns 16 g + 4 p ..)
+  // and receives column 16 g + (lane & 15) = lane & 31 of those 4 k rows
+  const int g = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+  const int fa = (8 * h + q) * PKA + 64 * wr + 32 * g + 8 * p;
+  const int fb = A_TN_BYTES + (8 * h + q) * PKB + 128 * wc + 32 * g + 8 * p;
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const char* pa = base + fa + 16 * s * PKA;
+      const char* pb = base + fb + 16 * s * PKB;
+      const s16x4 a0 = lds_tr16(pa), a1 = lds_tr16(pa + 4 * PKA);
+      const s16x4 b00 = lds_tr16(pb), b01 = lds_tr16(pb + 4 * PKB);
+      const s16x4 b10 = lds_tr16(pb + 64), b11 = lds_tr16(pb + 64 + 4 * PKB);
+      const bf16x8 a = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const bf16x8 b0 = {b00.x, b00.y, b00.z, b00.w, b01.x, b01.y, b01.z, b01.w};
+      const bf16x8 b1 = {b10.x, b10.y, b10.z, b10.w, b11.x, b11.y, b11.z, b11.w};
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[1], 0, 0, 0);
+      if (do_bsum) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, accb, 0, 0, 0);   // row sums of dy^T
+    }
+  };
+  G16_PIPELINE_LOOP
+
+  // C orientation: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  const int rowb = m0 + wr * 32 + 4 * h;
+  if (do_bsum && l31 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rowb + (r & 3) + 8 * (r >> 2);
+      if (row < M) atomicAdd(P.bias_grad + row, accb[r]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc * 64 + j * 32 + l31;
+    if (col >= N) continue;
+    float* cp = P.C + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rowb + (r & 3) + 8 * (r >> 2);
+      if (row < M) atomicAdd(cp + (size_t)row * P.ldc, acc[j][r]);
+    }
+  }
+}
+
+template <int PIPE>
+__global__ __launch_bounds__(256, 2) void gemm16_kernel(const Gemm16Batch gb, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // XCD-aware block remap (bijective): blocks that share an XCD (bid % 8) take a contiguous run of tiles
+  int bid = blockIdx.x;
+  {
+    const int nwg = total_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM16_MAXP; ++i)
+    if (i < gb.n && bid >= gb.p[i].tile_begin) pi = i;
+  const Gemm16Prob& P = gb.p[pi];
+  int t = bid - P.tile_begin;
+  const int ks = t % P.ksplit; t /= P.ksplit;
+  const int tn = t % P.tiles_n, tm = t / P.tiles_n;
+  if (P.flags & GF_A_KMAJOR) {
+    const int ktiles = (P.K + 127) / 128 * 2;                 // K rounded up to 128 rows, in 64-row tiles
+    const int per = P.kchunk / BK, kt0 = ks * per;
+    body_tn<PIPE>(P, tm * BM, tn * BN, kt0, min(per, ktiles - kt0), smem_raw);
+  } else {
+    body_nt<PIPE>(gb, P, tm * BM, tn * BN, smem_raw);
+  }
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
+  if (gb.n <= 0) return 0;
+  if (gb.n > GEMM16_MAXP) return (int)hipErrorInvalidValue;
+  static const int kcap = [] { const char* e = std::getenv("CAMO_DEV_TN16_KCAP"); const int v = e ? std::atoi(e) : 0; return v > 0 ? 2 * ((v + 1) / 2) : 6; }();
+  int total = 0;
+  for (int i = 0; i < gb.n; ++i) {
+    Gemm16Prob& p = gb.p[i];
+    const bool akm = p.flags & GF_A_KMAJOR, bkm = p.flags & GF_B_KMAJOR;
+    if (akm != bkm || p.M < 1 || p.N < 1 || p.K < 1) return (int)hipErrorInvalidValue;
+    if (!al16(p.A) || !al16(p.B) || (p.lda & 7) || (p.ldb & 7)) return (int)hipErrorInvalidValue;
+    if ((double)(akm ? p.K + 128 : p.M) * p.lda * 2.0 >= 4.0e9 || (double)(akm ? p.K + 128 : p.N) * p.ldb * 2.0 >= 4.0e9)
+      return (int)hipErrorInvalidValue;                                    // 32-bit lane offsets
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
+    if (akm) {
+      if ((p.M & 7) || (p.N & 7) || p.M < 8 || p.N < 8 || !p.C || p.C16 || p.bias || p.res ||
+          (p.flags & ~(GF_A_KMAJOR | GF_B_KMAJOR | GF_ATOMIC)))
+        return (int)hipErrorInvalidValue;
+      const int ktiles = (p.K + 127) / 128 * 2;
+      const int per = ktiles < kcap ? ktiles : kcap;                       // even
+      p.kchunk = per * BK;
+      p.ksplit = (ktiles + per - 1) / per;
+    } else {
+      if ((p.K % BK) || (p.N & 3) || (p.flags & (GF_ATOMIC | GF_SIGMOID)) || p.bias_grad) return (int)hipErrorInvalidValue;
+      if ((p.C && (!al16(p.C) || (p.ldc & 3))) || (p.C16 && ((reinterpret_cast<uintptr_t>(p.C16) & 7) || (p.ldc16 & 3))) ||
+          (p.bias && !al16(p.bias)) || (p.res && (!al16(p.res) || (p.ldr & 3))))
+        return (int)hipErrorInvalidValue;
+      p.kchunk = p.K; p.ksplit = 1;
+    }
+    p.tile_begin = total;
+    total += tiles * p.ksplit;
+  }
+  static const int dev_pipe = [] { const char* e = std::getenv("CAMO_DEV_PIPE16"); return e ? std::atoi(e) : 0; }();
+  const size_t lds = 2 * BUF_BYTES;
+  static const bool attr_ok = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    return true;
+  }();
+  (void)attr_ok;
+  const int pipe = dev_pipe ? dev_pipe : (total <= 512 ? 4 : 2);
+  double fl = 0.0;
+  for (int i = 0; i < gb.n; ++i) fl += 2.0 * gb.p[i].M * (double)gb.p[i].N * gb.p[i].K;
+  const int prof = gemm_prof_open(stream, fl);
+  if (pipe == 4) hipLaunchKernelGGL(gemm16_kernel<4>, dim3(total), dim3(256), lds, stream, gb, total);
+  else           hipLaunchKernelGGL(gemm16_kernel<2>, dim3(total), dim3(256), lds, stream, gb, total);
+  gemm_prof_close(prof, stream);
+  return (int)hipGetLastError();
+}

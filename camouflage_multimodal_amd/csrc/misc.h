@@ -2,13 +2,26 @@
 #pragma once
 #include "common.h"
 
-struct LnSeg { const float* U; float* Y; float* stats; const float* gamma; const float* beta; int rows; };
+struct LnSeg { const float* U; float* Y; float* stats; const float* gamma; const float* beta; int rows;
+               unsigned short* Y16; /* optional bf16 copy of Y (bf16 schedule) */ };
 struct LnBwdSeg { const float* U; const float* dY; const float* stats; const float* gamma; float* dU;
-                  float* dgamma; float* dbeta; int rows; };
+                  float* dgamma; float* dbeta; int rows;
+                  unsigned short* dU16; /* optional bf16 copy of dU */ };
 // per-sample column means: rows of sample b are offs[b]..offs[b+1]-1, or b*uniform_n.. when offs == null
 struct SegMean { const float* X; int ld, C; const int* offs; int uniform_n; float* out; int ldo; };
 struct BcastSeg { const float* act; const float* v; int ldv; const int* row_sample; const float* inv_n;
-                  int uniform_n; float* dst; int rows; };
+                  int uniform_n; float* dst; int rows;
+                  unsigned short* dst16; /* when set the result is written as bf16 here INSTEAD of dst */ };
+
+// One launch of small data-movement jobs in front of the bf16 schedule (misc.hip, prep_kernel):
+//   PREP_ZERO  : n bytes at dst := 0                                   (n, dst 16-byte multiples)
+//   PREP_CAST  : dst[i] = bf16(src[i]), i < n                          (n % 4 == 0)
+//   PREP_CAST_T: dst[c * ld_dst + col_off + r] = bf16(src[r * cols + c]), r < rows, c < cols   (transposed copy)
+enum : int { PREP_ZERO = 0, PREP_CAST = 1, PREP_CAST_T = 2 };
+struct PrepJob { const float* src; void* dst; size_t n; int type, rows, cols, ld_dst, col_off, blk_begin; };
+#define PREP_MAXJ 48
+struct PrepBatch { PrepJob j[PREP_MAXJ]; int n; };
+int launch_prep(PrepBatch& pb, hipStream_t stream);
 
 int ln_supported(int H);
 int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int B, int max_nr, hipStream_t stream);

@@ -47,15 +47,66 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnSeg s0, LnSeg s1, int H, 
 #pragma unroll
   for (int i = 0; i < HPL; ++i) {
     const int c = lane + 64 * i;
-    if (c < H) y[c] = (x[i] - mean) * rstd * S.gamma[c] + S.beta[c];
+    if (c < H) {
+      const float v = (x[i] - mean) * rstd * S.gamma[c] + S.beta[c];
+      y[c] = v;
+      if (S.Y16) S.Y16[(size_t)row * H + c] = f2bf(v);
+    }
   }
   if (lane == 0) { S.stats[2 * row] = mean; S.stats[2 * row + 1] = rstd; }
 }
 
 // ---------------------------------------------------------------- LayerNorm backward
 // dU = (g - mean(g) - xh*mean(g*xh)) * rstd, g = dY*gamma; dgamma += sum dY*xh; dbeta += sum dY
-template <int HPL>
+// A wave owns rows blk*4+wave, +4*nblk, ...; the next row's operands are in flight while the current
+// row reduces (the rows come from HBM / Infinity Cache, ~2 us away).  VEC: H % 4 == 0, lane owns
+// columns 4*lane..4*lane+3 (+256 per further quad) and moves them with 16-byte accesses.
+template <int HPL, bool VEC>
+struct LnCols {
+  static __device__ __forceinline__ int col(int lane, int i) { return VEC ? 4 * lane + (i & 3) + 256 * (i >> 2) : lane + 64 * i; }
+  static __device__ __forceinline__ void load(const float* __restrict__ p, int lane, int H, float (&x)[HPL]) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int q = 0; q < HPL / 4; ++q) {
+        const int c = 4 * lane + 256 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < H) v = *reinterpret_cast<const float4*>(p + c);
+        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < HPL; ++i) { const int c = lane + 64 * i; x[i] = c < H ? p[c] : 0.f; }
+    }
+  }
+  static __device__ __forceinline__ void store16(unsigned short* __restrict__ p, int lane, int H, const float (&x)[HPL]) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int q = 0; q < HPL / 4; ++q) {
+        const int c = 4 * lane + 256 * q;
+        if (c < H) *reinterpret_cast<uint2*>(p + c) = make_uint2(pack2(x[4 * q], x[4 * q + 1]), pack2(x[4 * q + 2], x[4 * q + 3]));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < HPL; ++i) { const int c = lane + 64 * i; if (c < H) p[c] = f2bf(x[i]); }
+    }
+  }
+  static __device__ __forceinline__ void store(float* __restrict__ p, int lane, int H, const float (&x)[HPL]) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int q = 0; q < HPL / 4; ++q) {
+        const int c = 4 * lane + 256 * q;
+        if (c < H) *reinterpret_cast<float4*>(p + c) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < HPL; ++i) { const int c = lane + 64 * i; if (c < H) p[c] = x[i]; }
+    }
+  }
+};
+
+template <int HPL, bool VEC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdSeg s0, LnBwdSeg s1, int H, int nb0) {
+  using LC = LnCols<HPL, VEC>;
   __shared__ float red[2][4][64 * HPL];
   const bool first = (int)blockIdx.x < nb0;
   const LnBwdSeg& S = first ? s0 : s1;
@@ -63,39 +114,50 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdSeg s0, LnBwdSeg s1, i
   const int nblk = first ? nb0 : (int)gridDim.x - nb0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dg[HPL], db[HPL], gam[HPL];
+  LC::load(S.gamma, lane, H, gam);
 #pragma unroll
-  for (int i = 0; i < HPL; ++i) {
-    const int c = lane + 64 * i;
-    dg[i] = 0.f; db[i] = 0.f; gam[i] = c < H ? S.gamma[c] : 0.f;
+  for (int i = 0; i < HPL; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+  const int stride = nblk * 4;
+  int row = blk * 4 + wave;
+  float un[HPL], dn[HPL], mean_n = 0.f, rstd_n = 0.f;
+  if (row < S.rows) {
+    LC::load(S.U + (size_t)row * H, lane, H, un);
+    LC::load(S.dY + (size_t)row * H, lane, H, dn);
+    mean_n = S.stats[2 * row]; rstd_n = S.stats[2 * row + 1];
   }
-  for (int row = blk * 4 + wave; row < S.rows; row += nblk * 4) {
-    const float mean = S.stats[2 * row], rstd = S.stats[2 * row + 1];
-    const float* u = S.U + (size_t)row * H;
-    const float* dy = S.dY + (size_t)row * H;
+  for (; row < S.rows; row += stride) {
+    float u[HPL], d[HPL];
+#pragma unroll
+    for (int i = 0; i < HPL; ++i) { u[i] = un[i]; d[i] = dn[i]; }
+    const float mean = mean_n, rstd = rstd_n;
+    const int nx = min(row + stride, S.rows - 1);          // clamped: a harmless re-read on the last trip
+    LC::load(S.U + (size_t)nx * H, lane, H, un);
+    LC::load(S.dY + (size_t)nx * H, lane, H, dn);
+    mean_n = S.stats[2 * nx]; rstd_n = S.stats[2 * nx + 1];
     float xh[HPL], g[HPL];
     float s1_ = 0.f, s2_ = 0.f;
 #pragma unroll
     for (int i = 0; i < HPL; ++i) {
-      const int c = lane + 64 * i;
-      const bool ok = c < H;
-      const float d = ok ? dy[c] : 0.f;
-      xh[i] = ok ? (u[c] - mean) * rstd : 0.f;
-      g[i] = d * gam[i];
+      const bool ok = LC::col(lane, i) < H;
+      xh[i] = ok ? (u[i] - mean) * rstd : 0.f;
+      g[i] = d[i] * gam[i];
       s1_ += g[i];
       s2_ = fmaf(g[i], xh[i], s2_);
-      dg[i] = fmaf(d, xh[i], dg[i]);
-      db[i] += d;
+      dg[i] = fmaf(d[i], xh[i], dg[i]);
+      db[i] += d[i];
     }
     const float m1 = wave_sum(s1_) / (float)H, m2 = wave_sum(s2_) / (float)H;
-    float* du = S.dU + (size_t)row * H;
+    float o[HPL];
 #pragma unroll
-    for (int i = 0; i < HPL; ++i) {
-      const int c = lane + 64 * i;
-      if (c < H) du[c] = (g[i] - m1 - xh[i] * m2) * rstd;
-    }
+    for (int i = 0; i < HPL; ++i) o[i] = (g[i] - m1 - xh[i] * m2) * rstd;
+    LC::store(S.dU + (size_t)row * H, lane, H, o);
+    if (S.dU16) LC::store16(S.dU16 + (size_t)row * H, lane, H, o);
   }
 #pragma unroll
-  for (int i = 0; i < HPL; ++i) { red[0][wave][lane + 64 * i] = dg[i]; red[1][wave][lane + 64 * i] = db[i]; }
+  for (int i = 0; i < HPL; ++i) {
+    const int c = LC::col(lane, i);                        // < 64*HPL by construction
+    red[0][wave][c] = dg[i]; red[1][wave][c] = db[i];
+  }
   __syncthreads();
   for (int c = threadIdx.x; c < H; c += 256) {
     const float a = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
@@ -107,8 +169,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdSeg s0, LnBwdSeg s1, i
 
 // ---------------------------------------------------------------- per-sample column means
 // out[b][c] += (1/n_b) * sum_{rows of b in this block's chunk} X[row][c]   (out zeroed by the caller)
-// grid (chunks, B, nseg)
+// grid (chunks, B, nseg).  VEC (C, ld % 4 == 0): a thread owns a column quad and every `groups`-th row of
+// the chunk, all of its 16-byte loads independent; the row groups combine through LDS -> C atomics a block.
+template <bool VEC>
 __global__ __launch_bounds__(256) void seg_mean_kernel(SegMean a, SegMean b2, SegMean c3, SegMean d4, int rows_per_block) {
+  __shared__ float4 red[256];
   const SegMean& S = blockIdx.z == 0 ? a : (blockIdx.z == 1 ? b2 : (blockIdx.z == 2 ? c3 : d4));
   if (!S.X) return;
   const int b = blockIdx.y;
@@ -118,17 +183,52 @@ __global__ __launch_bounds__(256) void seg_mean_kernel(SegMean a, SegMean b2, Se
   if (c0 >= nr) return;
   const int c1 = min(nr, c0 + rows_per_block);
   const float inv = 1.0f / (float)nr;
-  for (int c = threadIdx.x; c < S.C; c += 256) {
-    float acc = 0.f;
-    for (int r = c0; r < c1; ++r) acc += S.X[(size_t)(r0 + r) * S.ld + c];
-    atomicAdd(S.out + (size_t)b * S.ldo + c, acc * inv);
+  if constexpr (VEC) {
+    const int C4 = S.C >> 2;
+    const int lanes = C4 < 256 ? C4 : 256, groups = 256 / lanes;
+    const int cq = threadIdx.x % lanes, grp = threadIdx.x / lanes;
+    for (int q0 = 0; q0 < C4; q0 += lanes) {               // (one trip unless C > 1024)
+      const int q = q0 + cq;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (grp < groups && q < C4) {
+        const float* base = S.X + (size_t)r0 * S.ld + 4 * q;
+#pragma unroll 8
+        for (int r = c0 + grp; r < c1; r += groups) {
+          const float4 v = *reinterpret_cast<const float4*>(base + (size_t)r * S.ld);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
+      if (groups > 1) {
+        __syncthreads();
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (grp == 0) {
+          for (int gi = 1; gi < groups; ++gi) {
+            const float4 v = red[gi * lanes + cq];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          }
+        }
+      }
+      if (grp == 0 && q < C4) {
+        float* o = S.out + (size_t)b * S.ldo + 4 * q;
+        atomicAdd(o, acc.x * inv); atomicAdd(o + 1, acc.y * inv); atomicAdd(o + 2, acc.z * inv); atomicAdd(o + 3, acc.w * inv);
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < S.C; c += 256) {
+      float acc = 0.f;
+      for (int r = c0; r < c1; ++r) acc += S.X[(size_t)(r0 + r) * S.ld + c];
+      atomicAdd(S.out + (size_t)b * S.ldo + c, acc * inv);
+    }
   }
 }
 
 // ---------------------------------------------------------------- ReLU-mask broadcast backward
 // dst[t][c] = v[sample(t)][c] * inv_n[sample(t)] * (act[t][c] > 0 ? scale : 0)
+// W = 4: C % 4 == 0, one 16-byte quad per thread.
+template <int W>
 __global__ __launch_bounds__(256) void relu_bcast_bwd_kernel(BcastSeg s0, BcastSeg s1, int C, long n0, float scale) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * W;
   const bool first = i < n0;
   const BcastSeg& S = first ? s0 : s1;
   const long k = first ? i : i - n0;
@@ -136,8 +236,20 @@ __global__ __launch_bounds__(256) void relu_bcast_bwd_kernel(BcastSeg s0, BcastS
   const int t = (int)(k / C), c = (int)(k - (long)t * C);
   int sb; float inv;
   if (S.row_sample) { sb = S.row_sample[t]; inv = S.inv_n[sb]; } else { sb = t / S.uniform_n; inv = 1.0f / (float)S.uniform_n; }
-  const float a = S.act[k];
-  S.dst[k] = a > 0.f ? S.v[(size_t)sb * S.ldv + c] * inv * scale : 0.f;
+  inv *= scale;
+  if constexpr (W == 4) {
+    const float4 a = *reinterpret_cast<const float4*>(S.act + k);
+    const float4 v = *reinterpret_cast<const float4*>(S.v + (size_t)sb * S.ldv + c);
+    float4 o;
+    o.x = a.x > 0.f ? v.x * inv : 0.f; o.y = a.y > 0.f ? v.y * inv : 0.f;
+    o.z = a.z > 0.f ? v.z * inv : 0.f; o.w = a.w > 0.f ? v.w * inv : 0.f;
+    if (S.dst16) *reinterpret_cast<uint2*>(S.dst16 + k) = make_uint2(pack2(o.x, o.y), pack2(o.z, o.w));
+    else *reinterpret_cast<float4*>(S.dst + k) = o;
+  } else {
+    const float a = S.act[k];
+    const float o = a > 0.f ? S.v[(size_t)sb * S.ldv + c] * inv : 0.f;
+    if (S.dst16) S.dst16[k] = f2bf(o); else S.dst[k] = o;
+  }
 }
 
 // ---------------------------------------------------------------- d(outs) -> d(pre-activation)
@@ -268,9 +380,69 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
   for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) upd(p[i], g[i], m[i], v[i]);
 }
 
+// ---------------------------------------------------------------- prep jobs of the bf16 schedule
+__global__ __launch_bounds__(256) void prep_kernel(const PrepBatch pb) {
+  __shared__ float tile[64][65];
+  int ji = 0;
+  for (int i = 1; i < pb.n; ++i)
+    if ((int)blockIdx.x >= pb.j[i].blk_begin) ji = i;
+  const PrepJob& J = pb.j[ji];
+  const int blk = blockIdx.x - J.blk_begin, tid = threadIdx.x;
+  if (J.type == PREP_ZERO) {                                  // 16 KB per block
+    uint4* d = reinterpret_cast<uint4*>(J.dst);
+    const size_t n16 = J.n >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t k = (size_t)blk * 1024 + i * 256 + tid;
+      if (k < n16) d[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  } else if (J.type == PREP_CAST) {                           // 4096 elements per block
+    const float4* s = reinterpret_cast<const float4*>(J.src);
+    uint2* d = reinterpret_cast<uint2*>(J.dst);
+    const size_t n4 = J.n >> 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t k = (size_t)blk * 1024 + i * 256 + tid;
+      if (k < n4) { const float4 v = s[k]; d[k] = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w)); }
+    }
+  } else {                                                    // 64 x 64 tile through LDS
+    const int tc = (J.cols + 63) >> 6;
+    const int r0 = (blk / tc) * 64, c0 = (blk % tc) * 64;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {                            // all 16 loads in flight before the first LDS store
+      const int i = tid + 256 * k, r = i >> 6, c = i & 63;
+      v[k] = J.src[(size_t)min(r0 + r, J.rows - 1) * J.cols + min(c0 + c, J.cols - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int i = tid + 256 * k; tile[i >> 6][i & 63] = v[k]; }
+    __syncthreads();
+    unsigned short* d = reinterpret_cast<unsigned short*>(J.dst);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = tid + 256 * k, c = i >> 6, r = i & 63;
+      if (r0 + r < J.rows && c0 + c < J.cols) d[(size_t)(c0 + c) * J.ld_dst + J.col_off + r0 + r] = f2bf(tile[r][c]);
+    }
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
+int launch_prep(PrepBatch& pb, hipStream_t stream) {
+  int total = 0;
+  for (int i = 0; i < pb.n; ++i) {
+    PrepJob& J = pb.j[i];
+    J.blk_begin = total;
+    if (J.type == PREP_ZERO) total += (int)(((J.n >> 4) + 1023) / 1024);
+    else if (J.type == PREP_CAST) total += (int)(((J.n >> 2) + 1023) / 1024);
+    else total += ((J.rows + 63) / 64) * ((J.cols + 63) / 64);
+  }
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(prep_kernel, dim3(total), dim3(256), 0, stream, pb);
+  return (int)hipGetLastError();
+}
+
 int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int B, int max_nr, hipStream_t stream) {
   hipLaunchKernelGGL(rowmap_kernel, dim3((max_nr + 255) / 256, B), dim3(256), 0, stream, offs, row_sample, inv_nr);
   return (int)hipGetLastError();
@@ -290,8 +462,14 @@ int launch_ln_bwd(const LnBwdSeg& s0, const LnBwdSeg& s1, int H, hipStream_t str
   auto nblk = [](int rows) { int b = (rows + 15) / 16; return rows == 0 ? 0 : (b > 512 ? 512 : (b < 1 ? 1 : b)); };
   const int nb0 = nblk(s0.rows), nb1 = nblk(s1.rows);
   if (nb0 + nb1 == 0) return 0;
-  if (H <= 256) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb0 + nb1), dim3(256), 0, stream, s0, s1, H, nb0);
-  else          hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(nb0 + nb1), dim3(256), 0, stream, s0, s1, H, nb0);
+  const bool vec = (H & 3) == 0;
+  if (H <= 256) {
+    if (vec) hipLaunchKernelGGL((ln_bwd_kernel<4, true>), dim3(nb0 + nb1), dim3(256), 0, stream, s0, s1, H, nb0);
+    else     hipLaunchKernelGGL((ln_bwd_kernel<4, false>), dim3(nb0 + nb1), dim3(256), 0, stream, s0, s1, H, nb0);
+  } else {
+    if (vec) hipLaunchKernelGGL((ln_bwd_kernel<16, true>), dim3(nb0 + nb1), dim3(256), 0, stream, s0, s1, H, nb0);
+    else     hipLaunchKernelGGL((ln_bwd_kernel<16, false>), dim3(nb0 + nb1), dim3(256), 0, stream, s0, s1, H, nb0);
+  }
   return (int)hipGetLastError();
 }
 
@@ -299,15 +477,23 @@ int launch_seg_mean(const SegMean* segs, int nseg, int B, int max_rows, hipStrea
   SegMean z{}; SegMean s[4] = {z, z, z, z};
   for (int i = 0; i < nseg && i < 4; ++i) s[i] = segs[i];
   const int rpb = 32;
-  hipLaunchKernelGGL(seg_mean_kernel, dim3((max_rows + rpb - 1) / rpb, B, nseg), dim3(256), 0, stream,
-                     s[0], s[1], s[2], s[3], rpb);
+  bool vec = true;
+  for (int i = 0; i < nseg && i < 4; ++i)
+    vec = vec && (s[i].C & 3) == 0 && (s[i].ld & 3) == 0 && (reinterpret_cast<uintptr_t>(s[i].X) & 15) == 0;
+  const dim3 grid((max_rows + rpb - 1) / rpb, B, nseg);
+  if (vec) hipLaunchKernelGGL(seg_mean_kernel<true>, grid, dim3(256), 0, stream, s[0], s[1], s[2], s[3], rpb);
+  else     hipLaunchKernelGGL(seg_mean_kernel<false>, grid, dim3(256), 0, stream, s[0], s[1], s[2], s[3], rpb);
   return (int)hipGetLastError();
 }
 
 int launch_relu_bcast_bwd(const BcastSeg& s0, const BcastSeg& s1, int C, float scale, hipStream_t stream) {
   const long n0 = (long)s0.rows * C, n1 = (long)s1.rows * C;
   if (n0 + n1 == 0) return 0;
-  hipLaunchKernelGGL(relu_bcast_bwd_kernel, dim3((unsigned)((n0 + n1 + 255) / 256)), dim3(256), 0, stream, s0, s1, C, n0, scale);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec = (C & 3) == 0 && (s0.ldv & 3) == 0 && (s1.ldv & 3) == 0 && al16(s0.act) && al16(s0.v) && al16(s0.dst) &&
+                   al16(s1.act) && al16(s1.v) && al16(s1.dst) && al16(s0.dst16) && al16(s1.dst16);
+  if (vec) hipLaunchKernelGGL(relu_bcast_bwd_kernel<4>, dim3((unsigned)(((n0 + n1) / 4 + 255) / 256)), dim3(256), 0, stream, s0, s1, C, n0, scale);
+  else     hipLaunchKernelGGL(relu_bcast_bwd_kernel<1>, dim3((unsigned)((n0 + n1 + 255) / 256)), dim3(256), 0, stream, s0, s1, C, n0, scale);
   return (int)hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ _PREC = {"f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
 
 
 def _stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)   # (~8 us of torch bookkeeping: fetch once per step)
 
 
 def _ptr(t):
@@ -110,7 +110,9 @@ class FusionEngine:
         if self.flat_grads is None:
             self.flat_grads = torch.zeros_like(self.flat_params)
             self._gtab = self._grad_table(self.flat_grads)
+            self._grads_attached = False
         if attach:
+            self._grads_attached = True
             named = dict(self.module().named_parameters())
             for i, name, o, n, shape in self._layout:
                 p = named[name]

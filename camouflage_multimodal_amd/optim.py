@@ -56,7 +56,8 @@ class FusedClipAdamW:
         it.  Returns nothing; ``grad_norm()`` reads the norm lazily."""
         eng = self.engine
         _lib.require_device(eng.flat_params, "model parameters")
-        g = eng.ensure_flat_grads()
+        # param.grad views are attached once; walking named_parameters() every step cost ~130 us of host time
+        g = eng.ensure_flat_grads(attach=not getattr(eng, "_grads_attached", False))
         if allreduce is not None:
             allreduce(g)
         m, v, ss = self._state()

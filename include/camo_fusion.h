@@ -169,6 +169,11 @@ int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sum
 int camo_debug_gemm(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
                     const float* bias, const float* res, int32_t ldr, float* bias_grad,
                     int32_t M, int32_t N, int32_t K, int32_t flags, int32_t precision, void* stream);
+/* camo_debug_gemm16: one problem of the bf16-resident grouped GEMM (csrc/gemm16.h): A16/B16/C16 are bf16
+ * bit patterns; flags 64|128 together = dW += A^T.B (rows of A/B up to round_up(K,128) must be readable). */
+int camo_debug_gemm16(const void* A16, int32_t lda, const void* B16, int32_t ldb, float* C, int32_t ldc,
+                      void* C16, int32_t ldc16, const float* bias, const float* res, int32_t ldr, float* bias_grad,
+                      int32_t M, int32_t N, int32_t K, int32_t flags, void* stream);
 int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int32_t Nk, const char* name);
 
 /* Opt-in launch timing for bench.py's roofline leg: between camo_prof_begin and camo_prof_end every

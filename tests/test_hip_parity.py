@@ -330,6 +330,7 @@ def test_fused_forward_kernel_matches_unfused_schedule(training, kg_real, monkey
     names = [("R", (T, 256)), ("Q", (T, 256)), ("KV2", (T, 512)), ("P", (T, 8, 13)), ("O", (T, 256)), ("U", (T, 256)),
              ("Y", (T, 256)), ("H1", (T, 512)), ("comb", (len(nrs), 512)), ("fused", (len(nrs), 256))]
     res = {}
+    monkeypatch.setenv("CAMO_SCHED16", "0")               # both legs on the fp32-operand schedule
     for mode in ("fused", "unfused"):
         if mode == "fused":
             monkeypatch.setenv("CAMO_FUSED", "1")
@@ -350,3 +351,50 @@ def test_fused_forward_kernel_matches_unfused_schedule(training, kg_real, monkey
         tol = 2e-6 * scale if k in ("R",) else 4e-3 * scale
         assert err <= tol, f"{k}: max |fused - unfused| = {err:.3e} (scale {scale:.3e})"
         assert float(np.abs(a - b).mean()) <= 2e-5 * scale, f"{k}: mean diff {np.abs(a - b).mean():.3e}"
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_bf16_resident_schedule_matches_fp32_operand_schedule(training, kg_real, monkeypatch):
+    """The default bf16 schedule (bf16-resident operands, gemm16.hip, concatenated in-projection backward) against the
+    general schedule in bf16 mode (fp32 operands rounded while staging, gemm.hip).  Both round the same values to
+    bf16 at the same points and accumulate in fp32, so forward activations, outputs and every parameter gradient
+    agree up to summation order (and rare 1-ulp bf16 flips downstream of it)."""
+    cfg = OP.full_cfg()
+    m = make_model(cfg, 0, "bf16")
+    m.train(training)
+    eng = m._engine
+    nrs = [303, 64, 1, 530, 65, 127, 128, 500]
+    rg = [OP.make_rg(n, 128, seed=90 + i) for i, n in enumerate(nrs)]
+    kg = np.stack([kg_real] * len(nrs))
+    batch = eng.make_batch(torch.from_numpy(np.concatenate(rg)).cuda(), nrs, torch.from_numpy(kg).cuda())
+    T, B = sum(nrs), len(nrs)
+    names = [("R", (T, 256)), ("Q", (T, 256)), ("KV2", (T, 512)), ("KV", (B * 13, 512)), ("P", (T, 8, 13)), ("P2", (T, 8, 13)),
+             ("U", (T, 256)), ("U2", (B * 13, 256)), ("Y", (T, 256)), ("H1", (T, 512)), ("H2", (B * 13, 512)),
+             ("comb", (B, 512)), ("fused", (B, 256))]
+    d_outs = torch.from_numpy(np.random.RandomState(5).standard_normal((B, 6)).astype(np.float32)).cuda()
+    res = {}
+    for mode in ("sched16", "general"):
+        monkeypatch.setenv("CAMO_SCHED16", "1" if mode == "sched16" else "0")
+        ws = eng.workspace(batch, private=True)
+        ws.zero_()
+        outs, attn = eng.forward_raw(batch, ws, training, 0xABCDEF0123, want_attention=True)
+        r = dict(outs=t2n(outs), a1=t2n(attn[0]), a2=t2n(attn[1]), **{n: _ws_get(eng, batch, ws, n, sh) for n, sh in names})
+        g = eng.ensure_flat_grads(attach=True)
+        g.zero_()
+        eng.backward_raw(batch, ws, outs, d_outs, training, 0xABCDEF0123, eng._gtab)
+        torch.cuda.synchronize()
+        for k, p in m.named_parameters():
+            r["grad:" + k] = t2n(p.grad).copy()
+        res[mode] = r
+    monkeypatch.delenv("CAMO_SCHED16", raising=False)
+    worst = []
+    for k in res["sched16"]:
+        a, b = res["sched16"][k].astype(np.float64), res["general"][k].astype(np.float64)
+        scale = max(float(np.abs(b).max()), 1e-6)
+        err = float(np.abs(a - b).max())
+        worst.append((err / scale, k))
+        tol = 2e-6 if k in ("R", "Q", "KV2", "KV") else 4e-3
+        assert err <= tol * scale, f"{k}: max diff {err:.3e} (scale {scale:.3e})"
+        assert float(np.abs(a - b).mean()) <= 5e-5 * scale, f"{k}: mean diff {np.abs(a - b).mean():.3e} (scale {scale:.3e})"
+    worst.sort(reverse=True)
+    print("sched16 vs general, worst relative max-diffs:", [(f"{e:.2e}", k) for e, k in worst[:5]])
