@@ -164,13 +164,33 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
     kb[n] = load_col4(kvb + h * DH + 16 * n, (size_t)2 * H, 0, q, Nk - 1, x);   // K_h[key 4q+e][16n + x]
     dKa[n] = f4{0.f, 0.f, 0.f, 0.f}; dVa[n] = f4{0.f, 0.f, 0.f, 0.f};
   }
+  // all loads of both tiles first, unconditionally, from rows clamped into the sample (see kg2rg forward)
+  Frag8 gfv[TPW];
+  f4 pTv[TPW], pNv[TPW], qbv[TPW][2], gbv[TPW][2];
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int t0 = min((tfirst + tt) * 16, nr - 1);
+    const int node = r0 + min(t0 + x, nr - 1);
+    gfv[tt] = load_row8(dO + (size_t)node * H + h * DH, q, true);
+    const size_t pbase = ((size_t)node * nh + h) * Nk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pTv[tt][r] = P[pbase + min(4 * q + r, Nk - 1)];
+      pNv[tt][r] = P[((size_t)(r0 + min(t0 + 4 * q + r, nr - 1)) * nh + h) * Nk + min(x, Nk - 1)];
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      qbv[tt][n] = load_col4(Q + (size_t)r0 * H + h * DH + 16 * n, (size_t)H, t0, q, nr - 1, x);
+      gbv[tt][n] = load_col4(dO + (size_t)r0 * H + h * DH + 16 * n, (size_t)H, t0, q, nr - 1, x);
+    }
+  }
 #pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
     const int t0 = (tfirst + tt) * 16;
-    if (t0 >= nr) continue;
+    if (t0 >= nr) continue;                                  // wave-uniform; nothing below loads
     const int node = r0 + min(t0 + x, nr - 1);
     const bool node_ok = t0 + x < nr;
-    const Frag8 gf = load_row8(dO + (size_t)node * H + h * DH, q, true);
+    const Frag8 gf = gfv[tt];
     // ---- orientation T: rows = keys 4q+r, col = node x
     f4 dpT = mma_nt32(vf, gf, f4{0.f, 0.f, 0.f, 0.f});
     const size_t pbase = ((size_t)node * nh + h) * Nk;
@@ -180,7 +200,7 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
     for (int r = 0; r < 4; ++r) {
       const int key = 4 * q + r;
       const bool ok = key < Nk && node_ok;
-      pT[r] = ok ? P[pbase + min(key, Nk - 1)] : 0.f;
+      pT[r] = ok ? pTv[tt][r] : 0.f;
       const float m = (ok && drop.p > 0.f) ? drop_mult(drop, SITE_ATTN_RG2KG, (uint32_t)(pbase + key)) : 1.0f;
       dpT[r] *= m;
       dot = fmaf(pT[r], dpT[r], dot);
@@ -207,7 +227,7 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
       const int nd = t0 + 4 * q + r;
       const bool ok = x < Nk && nd < nr;
       const size_t pb = ((size_t)(r0 + min(nd, nr - 1)) * nh + h) * Nk;
-      const float p = ok ? P[pb + min(x, Nk - 1)] : 0.f;
+      const float p = ok ? pNv[tt][r] : 0.f;
       const float m = (ok && drop.p > 0.f) ? drop_mult(drop, SITE_ATTN_RG2KG, (uint32_t)(pb + x)) : 1.0f;
       const float dotn = __shfl(dot, 4 * q + r, 64);       // row-dot of node 4q+r lives in lane x' = 4q+r
       dsN[r] = p * (dpN[r] * m - dotn) * scale;
@@ -215,10 +235,8 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
     }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-      const f4 qb = load_col4(Q + (size_t)r0 * H + h * DH + 16 * n, (size_t)H, t0, q, nr - 1, x);
-      const f4 gb = load_col4(dO + (size_t)r0 * H + h * DH + 16 * n, (size_t)H, t0, q, nr - 1, x);
-      dKa[n] = mma_acc16(dsN, qb, dKa[n]);                 // rows = keys 4q+r, col = 16n + x
-      dVa[n] = mma_acc16(pdN, gb, dVa[n]);
+      dKa[n] = mma_acc16(dsN, qbv[tt][n], dKa[n]);         // rows = keys 4q+r, col = 16n + x
+      dVa[n] = mma_acc16(pdN, gbv[tt][n], dVa[n]);
     }
   }
   // combine the block's four partial tiles in LDS, then one atomicAdd per element per block
@@ -257,18 +275,30 @@ __global__ __launch_bounds__(64 * NW) void kg2rg_fwd_mfma_kernel(
   const int ntiles = (nr + 15) >> 4;
   const float* kv = KV2 + (size_t)r0 * 2 * H;
   const Frag8 q2f = scale8(load_row8(Q2 + (size_t)(b * Nk + min(x, Nk - 1)) * H + h * DH, q, x < Nk), scale);
+  // Every load of the kernel is issued up front, unconditionally, from row indices clamped into the sample
+  // (tiles past the end re-read its last row and are masked below): with the loads inside "if (tile valid)" the
+  // compiler kept each tile's load -> wait -> MFMA chain separate, one memory round trip per tile.
+  Frag8 kf[MAXT];
+  f4 vb[MAXT][2];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t0 = (wave + NW * i) * 16;
+    kf[i] = load_row8(kv + (size_t)min(t0 + x, nr - 1) * 2 * H + h * DH, q, true);
+  }
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t0 = (wave + NW * i) * 16;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) vb[i][n] = load_col4(kv + H + h * DH + 16 * n, (size_t)2 * H, min(t0, nr - 1), q, nr - 1, x);
+  }
   f4 s[MAXT];
   float m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int t0 = (wave + NW * i) * 16;
-    s[i] = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    if (wave + NW * i < ntiles) {
-      const Frag8 kf = load_row8(kv + (size_t)min(t0 + x, nr - 1) * 2 * H + h * DH, q, true);
-      s[i] = mma_nt32(kf, q2f, f4{0.f, 0.f, 0.f, 0.f});
+    s[i] = mma_nt32(kf[i], q2f, f4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { if (t0 + 4 * q + r >= nr) s[i][r] = -INFINITY; m = fmaxf(m, s[i][r]); }
-    }
+    for (int r = 0; r < 4; ++r) { if (t0 + 4 * q + r >= nr) s[i][r] = -INFINITY; m = fmaxf(m, s[i][r]); }
   }
   m = group_max(m);
   if (q == 0) red[wave][x] = m;
@@ -294,25 +324,22 @@ __global__ __launch_bounds__(64 * NW) void kg2rg_fwd_mfma_kernel(
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int t0 = (wave + NW * i) * 16;
-    if (wave + NW * i < ntiles) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = t0 + 4 * q + r;
-        float p = s[i][r] * inv;
-        if (t < nr && x < Nk) {
-          const size_t idx = ((size_t)(r0 + t) * nh + h) * Nk + x;
-          P2[idx] = p;
-          if (drop.p > 0.f) p *= drop_mult(drop, SITE_ATTN_KG2RG, (uint32_t)idx);
-        } else {
-          p = 0.f;
-        }
-        s[i][r] = p;
+    for (int r = 0; r < 4; ++r) {
+      const int t = t0 + 4 * q + r;
+      float p = s[i][r] * inv;
+      if (t < nr && x < Nk) {
+        const size_t idx = ((size_t)(r0 + t) * nh + h) * Nk + x;
+        P2[idx] = p;
+        if (drop.p > 0.f) p *= drop_mult(drop, SITE_ATTN_KG2RG, (uint32_t)idx);
+      } else {
+        p = 0.f;
       }
+      s[i][r] = p;
+    }
+    if (wave + NW * i < ntiles) {                           // (wave-uniform; skips only MFMAs on zeros)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const f4 vb = load_col4(kv + H + h * DH + 16 * n, (size_t)2 * H, t0, q, nr - 1, x);
-        o[n] = mma_acc16(s[i], vb, o[n]);                  // rows = queries 4q+r, col = 16n + x
-      }
+      for (int n = 0; n < 2; ++n) o[n] = mma_acc16(s[i], vb[i][n], o[n]);   // rows = queries 4q+r, col = 16n + x
     }
   }
   if (wave > 0) {
@@ -364,26 +391,44 @@ __global__ __launch_bounds__(64 * NW) void kg2rg_bwd_mfma_kernel(
   const float* g2p = dO2 + (size_t)b * Nk * H + h * DH;
   const Frag8 g2f = load_row8(g2p + (size_t)min(x, Nk - 1) * H, q, x < Nk);
   // ---- phase 1, orientation T (rows = keys 4q+r, col = query x): dP, row-dots, dS, dQ2
+  // (all loads of a phase are issued up front, unconditionally, from clamped rows -- see kg2rg forward)
   f4 ds[MAXT], pT[MAXT];
   float dot = 0.f;
+  {
+    Frag8 vf[MAXT];
+    f4 pld[MAXT];
 #pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
-    const int t0 = (wave + NW * i) * 16;
-    ds[i] = f4{0.f, 0.f, 0.f, 0.f}; pT[i] = f4{0.f, 0.f, 0.f, 0.f};
-    if (wave + NW * i < ntiles) {
-      const Frag8 vf = load_row8(kv + (size_t)min(t0 + x, nr - 1) * 2 * H + H + h * DH, q, true);
-      ds[i] = mma_nt32(vf, g2f, f4{0.f, 0.f, 0.f, 0.f});
+    for (int i = 0; i < MAXT; ++i) {
+      const int t0 = (wave + NW * i) * 16;
+      vf[i] = load_row8(kv + (size_t)min(t0 + x, nr - 1) * 2 * H + H + h * DH, q, true);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = t0 + 4 * q + r;
+        pld[i][r] = P2[((size_t)(r0 + min(t, nr - 1)) * nh + h) * Nk + min(x, Nk - 1)];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t0 = (wave + NW * i) * 16;
+      ds[i] = mma_nt32(vf[i], g2f, f4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int t = t0 + 4 * q + r;
         const bool ok = t < nr && x < Nk;
         const size_t idx = ((size_t)(r0 + min(t, nr - 1)) * nh + h) * Nk + min(x, Nk - 1);
-        pT[i][r] = ok ? P2[idx] : 0.f;
+        pT[i][r] = ok ? pld[i][r] : 0.f;
         const float mk = (ok && drop.p > 0.f) ? drop_mult(drop, SITE_ATTN_KG2RG, (uint32_t)idx) : 1.0f;
-        ds[i][r] *= mk;
+        ds[i][r] = ok ? ds[i][r] * mk : 0.f;
         dot = fmaf(pT[i][r], ds[i][r], dot);
       }
     }
+  }
+  f4 kb[MAXT][2];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t0 = (wave + NW * i) * 16;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) kb[i][n] = load_col4(kv + h * DH + 16 * n, (size_t)2 * H, min(t0, nr - 1), q, nr - 1, x);
   }
   dot = group_sum(dot);
   if (q == 0) red[wave][x] = dot;
@@ -395,15 +440,11 @@ __global__ __launch_bounds__(64 * NW) void kg2rg_bwd_mfma_kernel(
   f4 dq[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
-    const int t0 = (wave + NW * i) * 16;
-    if (wave + NW * i < ntiles) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ds[i][r] = pT[i][r] * (ds[i][r] - dot) * scale;
+    for (int r = 0; r < 4; ++r) ds[i][r] = pT[i][r] * (ds[i][r] - dot) * scale;       // 0 on masked entries (pT = 0)
+    if (wave + NW * i < ntiles) {                            // (wave-uniform; skips only MFMAs on zeros)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const f4 kb = load_col4(kv + h * DH + 16 * n, (size_t)2 * H, t0, q, nr - 1, x);
-        dq[n] = mma_acc16(ds[i], kb, dq[n]);               // rows = queries 4q+r, col = 16n + x
-      }
+      for (int n = 0; n < 2; ++n) dq[n] = mma_acc16(ds[i], kb[i][n], dq[n]);           // rows = queries 4q+r, col = 16n + x
     }
   }
   if (wave > 0) {
@@ -437,20 +478,30 @@ __global__ __launch_bounds__(64 * NW) void kg2rg_bwd_mfma_kernel(
   float dotq[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) dotq[r] = __shfl(dot, 4 * q + r, 64);  // row-dot of query 4q+r
+  Frag8 vf2[MAXT];
+  f4 pl2[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int key = min((wave + NW * i) * 16 + x, nr - 1);
+    vf2[i] = load_row8(kv + (size_t)key * 2 * H + H + h * DH, q, true);
+    const size_t pb = ((size_t)(r0 + key) * nh + h) * Nk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pl2[i][r] = P2[pb + min(4 * q + r, Nk - 1)];
+  }
+#pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int t0 = (wave + NW * i) * 16;
-    if (wave + NW * i >= ntiles) break;
+    if (wave + NW * i >= ntiles) continue;                   // wave-uniform; nothing below loads
     const int key = min(t0 + x, nr - 1);
     const bool key_ok = t0 + x < nr;
-    const Frag8 vf = load_row8(kv + (size_t)key * 2 * H + H + h * DH, q, true);
-    const f4 dpN = mma_nt32(g2f, vf, f4{0.f, 0.f, 0.f, 0.f});
+    const f4 dpN = mma_nt32(g2f, vf2[i], f4{0.f, 0.f, 0.f, 0.f});
     const size_t pb = ((size_t)(r0 + key) * nh + h) * Nk;
     f4 dsN, pdN;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int qi = 4 * q + r;
       const bool ok = key_ok && qi < Nk;
-      const float p = ok ? P2[pb + min(qi, Nk - 1)] : 0.f;
+      const float p = ok ? pl2[i][r] : 0.f;
       const float mk = (ok && drop.p > 0.f) ? drop_mult(drop, SITE_ATTN_KG2RG, (uint32_t)(pb + qi)) : 1.0f;
       dsN[r] = p * (dpN[r] * mk - dotq[r]) * scale;
       pdN[r] = p * mk;

@@ -537,8 +537,11 @@ __global__ __launch_bounds__(256, (PIPE <= 2 ? 2 : 1)) void gemm_grouped_kernel(
 // both operands, so a lane's four steps come from one 16-B load where the source is k-contiguous.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmBatch gb) {
-  __shared__ float red[3][4][64];
+// NW waves per block: 4, or 16 for launches made only of C = x.W^T problems with a long K (the forward tail:
+// 16 waves split K = 512 into two 16-deep blocks each, i.e. one memory round trip instead of four).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmBatch gb) {
+  __shared__ float red[NW - 1][4][64];
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < GEMM_MAXP; ++i)
@@ -555,8 +558,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmBatch gb) {
   const int local = blockIdx.x - P.tile_begin;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   int tile, kb0, kbstep;
-  if (akm) { tile = local * 4 + wave; kb0 = 0; kbstep = 1; }     // a wave per tile, whole K
-  else     { tile = local; kb0 = wave; kbstep = 4; }             // a block per tile, waves interleave K
+  if (akm) { tile = local * NW + wave; kb0 = 0; kbstep = 1; }    // a wave per tile, whole K
+  else     { tile = local; kb0 = wave; kbstep = NW; }            // a block per tile, waves interleave K
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * 16, n0 = tn * 16;
   const bool live = m0 < M;               // (only the a-wave-per-tile mode can run past the last tile)
@@ -591,7 +594,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmBatch gb) {
     __syncthreads();
     if (wave > 0) return;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += (red[0][r][lane] + red[1][r][lane]) + red[2][r][lane];
+    for (int r = 0; r < 4; ++r) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];
+      acc[r] += v;
+    }
   } else if (!live) {
     return;
   }
@@ -668,16 +676,20 @@ void gemm_prof_close(int slot, hipStream_t stream) {
 
 static int launch_skinny(GemmBatch& gb, hipStream_t stream) {
   int total = 0;
+  // (16-wave blocks for the long-K forward problems measured 17 us against 8-13 us with 4 waves: kept off)
+  bool wide = false;
+  const int nw = wide ? 16 : 4;
   for (int i = 0; i < gb.n; ++i) {
     GemmProb& p = gb.p[i];
     p.tiles_n = (p.N + 15) / 16;
     const int tiles = ((p.M + 15) / 16) * p.tiles_n;
     p.ksplit = 1; p.kchunk = p.K;
     p.tile_begin = total;
-    total += (p.flags & GF_A_KMAJOR) ? (tiles + 3) / 4 : tiles;
+    total += (p.flags & GF_A_KMAJOR) ? (tiles + nw - 1) / nw : tiles;
   }
   if (total == 0) return 0;
-  hipLaunchKernelGGL(gemm_skinny_kernel, dim3(total), dim3(256), 0, stream, gb);
+  if (wide) hipLaunchKernelGGL(gemm_skinny_kernel<16>, dim3(total), dim3(1024), 0, stream, gb);
+  else      hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(total), dim3(256), 0, stream, gb);
   return (int)hipGetLastError();
 }
 

@@ -301,34 +301,41 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
   if (gb.n <= 0) return 0;
   if (gb.n > GEMM16_MAXP) return (int)hipErrorInvalidValue;
-  static const int kcap = [] { const char* e = std::getenv("CAMO_DEV_TN16_KCAP"); const int v = e ? std::atoi(e) : 0; return v > 0 ? 2 * ((v + 1) / 2) : 6; }();
+  // Split-K depth of the weight-gradient problems, in 64-row tiles per block.  Long chunks (16 tiles) keep the
+  // fp32 atomics of the epilogue rare -- they, not the K loop, dominate short chunks -- but a launch that would
+  // leave most CUs idle (the lone dW_rg / dW_kg launch) takes shorter chunks to spread over the chip.
+  static const int kcap_env = [] { const char* e = std::getenv("CAMO_DEV_TN16_KCAP"); const int v = e ? std::atoi(e) : 0; return v > 0 ? 2 * ((v + 1) / 2) : 0; }();
   int total = 0;
-  for (int i = 0; i < gb.n; ++i) {
-    Gemm16Prob& p = gb.p[i];
-    const bool akm = p.flags & GF_A_KMAJOR, bkm = p.flags & GF_B_KMAJOR;
-    if (akm != bkm || p.M < 1 || p.N < 1 || p.K < 1) return (int)hipErrorInvalidValue;
-    if (!al16(p.A) || !al16(p.B) || (p.lda & 7) || (p.ldb & 7)) return (int)hipErrorInvalidValue;
-    if ((double)(akm ? p.K + 128 : p.M) * p.lda * 2.0 >= 4.0e9 || (double)(akm ? p.K + 128 : p.N) * p.ldb * 2.0 >= 4.0e9)
-      return (int)hipErrorInvalidValue;                                    // 32-bit lane offsets
-    p.tiles_n = (p.N + BN - 1) / BN;
-    const int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
-    if (akm) {
-      if ((p.M & 7) || (p.N & 7) || p.M < 8 || p.N < 8 || !p.C || p.C16 || p.bias || p.res ||
-          (p.flags & ~(GF_A_KMAJOR | GF_B_KMAJOR | GF_ATOMIC)))
-        return (int)hipErrorInvalidValue;
-      const int ktiles = (p.K + 127) / 128 * 2;
-      const int per = ktiles < kcap ? ktiles : kcap;                       // even
-      p.kchunk = per * BK;
-      p.ksplit = (ktiles + per - 1) / per;
-    } else {
-      if ((p.K % BK) || (p.N & 3) || (p.flags & (GF_ATOMIC | GF_SIGMOID)) || p.bias_grad) return (int)hipErrorInvalidValue;
-      if ((p.C && (!al16(p.C) || (p.ldc & 3))) || (p.C16 && ((reinterpret_cast<uintptr_t>(p.C16) & 7) || (p.ldc16 & 3))) ||
-          (p.bias && !al16(p.bias)) || (p.res && (!al16(p.res) || (p.ldr & 3))))
-        return (int)hipErrorInvalidValue;
-      p.kchunk = p.K; p.ksplit = 1;
+  for (int kcap = kcap_env ? kcap_env : 16;; kcap >>= 1) {
+    total = 0;
+    for (int i = 0; i < gb.n; ++i) {
+      Gemm16Prob& p = gb.p[i];
+      const bool akm = p.flags & GF_A_KMAJOR, bkm = p.flags & GF_B_KMAJOR;
+      if (akm != bkm || p.M < 1 || p.N < 1 || p.K < 1) return (int)hipErrorInvalidValue;
+      if (!al16(p.A) || !al16(p.B) || (p.lda & 7) || (p.ldb & 7)) return (int)hipErrorInvalidValue;
+      if ((double)(akm ? p.K + 128 : p.M) * p.lda * 2.0 >= 4.0e9 || (double)(akm ? p.K + 128 : p.N) * p.ldb * 2.0 >= 4.0e9)
+        return (int)hipErrorInvalidValue;                                    // 32-bit lane offsets
+      p.tiles_n = (p.N + BN - 1) / BN;
+      const int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
+      if (akm) {
+        if ((p.M & 7) || (p.N & 7) || p.M < 8 || p.N < 8 || !p.C || p.C16 || p.bias || p.res ||
+            (p.flags & ~(GF_A_KMAJOR | GF_B_KMAJOR | GF_ATOMIC)))
+          return (int)hipErrorInvalidValue;
+        const int ktiles = (p.K + 127) / 128 * 2;
+        const int per = ktiles < kcap ? ktiles : kcap;                       // even
+        p.kchunk = per * BK;
+        p.ksplit = (ktiles + per - 1) / per;
+      } else {
+        if ((p.K % BK) || (p.N & 3) || (p.flags & (GF_ATOMIC | GF_SIGMOID)) || p.bias_grad) return (int)hipErrorInvalidValue;
+        if ((p.C && (!al16(p.C) || (p.ldc & 3))) || (p.C16 && ((reinterpret_cast<uintptr_t>(p.C16) & 7) || (p.ldc16 & 3))) ||
+            (p.bias && !al16(p.bias)) || (p.res && (!al16(p.res) || (p.ldr & 3))))
+          return (int)hipErrorInvalidValue;
+        p.kchunk = p.K; p.ksplit = 1;
+      }
+      p.tile_begin = total;
+      total += tiles * p.ksplit;
     }
-    p.tile_begin = total;
-    total += tiles * p.ksplit;
+    if (kcap_env || total >= 384 || kcap <= 4) break;
   }
   static const int dev_pipe = [] { const char* e = std::getenv("CAMO_DEV_PIPE16"); return e ? std::atoi(e) : 0; }();
   const size_t lds = 2 * BUF_BYTES;
@@ -338,7 +345,7 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
     return true;
   }();
   (void)attr_ok;
-  const int pipe = dev_pipe ? dev_pipe : (total <= 512 ? 4 : 2);
+  const int pipe = dev_pipe ? dev_pipe : 2;     // (4 register stages measured slower on every launch of the step)
   double fl = 0.0;
   for (int i = 0; i < gb.n; ++i) fl += 2.0 * gb.p[i].M * (double)gb.p[i].N * gb.p[i].K;
   const int prof = gemm_prof_open(stream, fl);

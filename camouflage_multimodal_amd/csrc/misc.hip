@@ -4,6 +4,8 @@
 // needed; everything streams coalesced fp32.
 #include "misc.h"
 
+#include <cstdlib>
+
 namespace {
 
 // ---------------------------------------------------------------- row -> sample map
@@ -104,10 +106,14 @@ struct LnCols {
   }
 };
 
+// LNB_W waves per block: the dgamma/dbeta atomics (one per column per block, all blocks on the same 2H
+// addresses) cost more than the row pass itself -- 19 us with them, 8.6 us without at 4 waves x 503 blocks --
+// so the block is made as fat as the LDS combine allows without stretching a wave's serial row loop.
+constexpr int LNB_W = 8;
 template <int HPL, bool VEC>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdSeg s0, LnBwdSeg s1, int H, int nb0) {
+__global__ __launch_bounds__(64 * LNB_W) void ln_bwd_kernel(LnBwdSeg s0, LnBwdSeg s1, int H, int nb0) {
   using LC = LnCols<HPL, VEC>;
-  __shared__ float red[2][4][64 * HPL];
+  __shared__ float red[2][LNB_W][64 * HPL];
   const bool first = (int)blockIdx.x < nb0;
   const LnBwdSeg& S = first ? s0 : s1;
   const int blk = first ? blockIdx.x : blockIdx.x - nb0;
@@ -117,8 +123,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdSeg s0, LnBwdSeg s1, i
   LC::load(S.gamma, lane, H, gam);
 #pragma unroll
   for (int i = 0; i < HPL; ++i) { dg[i] = 0.f; db[i] = 0.f; }
-  const int stride = nblk * 4;
-  int row = blk * 4 + wave;
+  const int stride = nblk * LNB_W;
+  int row = blk * LNB_W + wave;
   float un[HPL], dn[HPL], mean_n = 0.f, rstd_n = 0.f;
   if (row < S.rows) {
     LC::load(S.U + (size_t)row * H, lane, H, un);
@@ -159,11 +165,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdSeg s0, LnBwdSeg s1, i
     red[0][wave][c] = dg[i]; red[1][wave][c] = db[i];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256) {
-    const float a = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-    const float b = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
-    atomicAdd(S.dgamma + c, a);
-    atomicAdd(S.dbeta + c, b);
+  for (int c = threadIdx.x; c < H; c += 64 * LNB_W) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < LNB_W; ++w) { a += red[0][w][c]; b += red[1][w][c]; }
+    if (S.dgamma) {
+      atomicAdd(S.dgamma + c, a);
+      atomicAdd(S.dbeta + c, b);
+    }
   }
 }
 
@@ -458,17 +467,21 @@ int launch_ln_fwd(const LnSeg& s0, const LnSeg& s1, int H, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-int launch_ln_bwd(const LnBwdSeg& s0, const LnBwdSeg& s1, int H, hipStream_t stream) {
-  auto nblk = [](int rows) { int b = (rows + 15) / 16; return rows == 0 ? 0 : (b > 512 ? 512 : (b < 1 ? 1 : b)); };
+int launch_ln_bwd(const LnBwdSeg& s0_, const LnBwdSeg& s1_, int H, hipStream_t stream) {
+  static const int rpb = [] { const char* e = std::getenv("CAMO_DEV_LNB_ROWS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 32; }();
+  static const bool noatom = [] { const char* e = std::getenv("CAMO_DEV_LNB_NOATOM"); return e && e[0] == '1'; }();
+  LnBwdSeg s0 = s0_, s1 = s1_;
+  if (noatom) { s0.dgamma = nullptr; s1.dgamma = nullptr; }
+  auto nblk = [](int rows) { int b = (rows + rpb - 1) / rpb; return rows == 0 ? 0 : (b > 2048 ? 2048 : (b < 1 ? 1 : b)); };
   const int nb0 = nblk(s0.rows), nb1 = nblk(s1.rows);
   if (nb0 + nb1 == 0) return 0;
   const bool vec = (H & 3) == 0;
   if (H <= 256) {
-    if (vec) hipLaunchKernelGGL((ln_bwd_kernel<4, true>), dim3(nb0 + nb1), dim3(256), 0, stream, s0, s1, H, nb0);
-    else     hipLaunchKernelGGL((ln_bwd_kernel<4, false>), dim3(nb0 + nb1), dim3(256), 0, stream, s0, s1, H, nb0);
+    if (vec) hipLaunchKernelGGL((ln_bwd_kernel<4, true>), dim3(nb0 + nb1), dim3(64 * LNB_W), 0, stream, s0, s1, H, nb0);
+    else     hipLaunchKernelGGL((ln_bwd_kernel<4, false>), dim3(nb0 + nb1), dim3(64 * LNB_W), 0, stream, s0, s1, H, nb0);
   } else {
-    if (vec) hipLaunchKernelGGL((ln_bwd_kernel<16, true>), dim3(nb0 + nb1), dim3(256), 0, stream, s0, s1, H, nb0);
-    else     hipLaunchKernelGGL((ln_bwd_kernel<16, false>), dim3(nb0 + nb1), dim3(256), 0, stream, s0, s1, H, nb0);
+    if (vec) hipLaunchKernelGGL((ln_bwd_kernel<16, true>), dim3(nb0 + nb1), dim3(64 * LNB_W), 0, stream, s0, s1, H, nb0);
+    else     hipLaunchKernelGGL((ln_bwd_kernel<16, false>), dim3(nb0 + nb1), dim3(64 * LNB_W), 0, stream, s0, s1, H, nb0);
   }
   return (int)hipGetLastError();
 }
