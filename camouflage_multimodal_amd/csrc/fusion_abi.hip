@@ -55,6 +55,7 @@ struct Carver {
 struct Ws {
   // zeroed once per forward: [ means | dfused | dKV ] (accumulated into by atomics)
   float* zero_base; size_t zero_bytes;
+  unsigned int* sync;   // 16 words inside the zero block: [0..2] forward tail barrier, [4..6] backward tail barrier
   // forward (saved for backward)
   float *R, *G, *Q, *KV2, *KV, *Q2, *P, *P2, *O, *O2, *U, *U2, *st1, *st2, *Y, *Y2, *H1, *H2;
   float *means, *Ymean, *H1mean, *Y2mean, *H2mean; size_t means_n;
@@ -94,10 +95,11 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
     w.H1 = c.take<float>(T * 2 * H); w.H2 = c.take<float>(TK * 2 * H);
     w.means_n = (size_t)B * 6 * H;
     {   // one contiguous block so a single memset clears every atomically-accumulated buffer
-      const size_t nz = w.means_n + (size_t)B * H + TK * 2 * H;
+      const size_t nz = w.means_n + (size_t)B * H + TK * 2 * H + 16;
       float* z = c.take<float>(nz);
       w.zero_base = z; w.zero_bytes = nz * sizeof(float);
       w.means = z; w.dfused = z ? z + w.means_n : nullptr; w.dKV = z ? w.dfused + (size_t)B * H : nullptr;
+      w.sync = z ? reinterpret_cast<unsigned int*>(w.dKV + TK * 2 * H) : nullptr;
     }
     if (w.means) { w.Ymean = w.means; w.H1mean = w.Ymean + B * H; w.Y2mean = w.H1mean + B * 2 * H; w.H2mean = w.Y2mean + B * H; }
     w.comb = c.take<float>(B * 2 * H); w.F1 = c.take<float>(B * H); w.fused = c.take<float>(B * H);
@@ -177,6 +179,7 @@ int check_dims(const camo_dims_t* d, int B, int T, int Nk) {
 struct GB {
   GemmBatch b;
   int prec; hipStream_t st;
+  TailPlan* plan = nullptr;   // when set, run() appends the batch to the plan as one phase instead of launching it
   GB(const DropCfg& d, int prec_, hipStream_t st_) : prec(prec_), st(st_) { std::memset(&b, 0, sizeof(b)); b.drop = d; }
   GemmProb& add(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K, int flags) {
     GemmProb& p = b.p[b.n++];
@@ -203,11 +206,32 @@ struct GB {
   }
   int run() {
     if (b.n == 0) return 0;
+    if (plan) {
+      if (plan->nphase >= TAIL_MAXPH || plan->n + b.n > TAIL_MAXP) return (int)hipErrorInvalidValue;
+      plan->phase_begin[plan->nphase] = plan->n;
+      for (int i = 0; i < b.n; ++i) plan->p[plan->n++] = b.p[i];
+      plan->phase_begin[++plan->nphase] = plan->n;
+      b.n = 0;
+      return 0;
+    }
     int e = launch_gemm_batch(b, prec, st);
     b.n = 0;
     return e;
   }
 };
+// The per-sample tail as ONE persistent launch with device-wide barriers between its layers: opt-in
+// (CAMO_TAIL_PERSIST=1).  Measured on MI355X it LOSES to the separate launches -- forward 58 us against 49 us,
+// backward 113 us against 30 us at B = 16: the release/acquire fences of a barrier write back and invalidate the
+// XCD's whole L2, which costs more than the ~5 us launch floor it replaces.
+bool tail_persistent_ok(int B) {
+  const char* env = std::getenv("CAMO_TAIL_PERSIST");
+  return B <= 64 && env && env[0] == '1';
+}
+void tail_begin(TailPlan& tp, GB& g, const DropCfg& drop, unsigned int* sync) {
+  std::memset(&tp, 0, sizeof(tp));
+  tp.drop = drop; tp.sync = sync;
+  g.plan = &tp;
+}
 
 void set_res(GemmProb& p, const float* res, int ldr) { p.res = res; p.ldr = ldr; }
 void set_drop(GemmProb& p, uint32_t site) { p.flags |= GF_DROPOUT; p.drop_site = site; }
@@ -269,11 +293,9 @@ bool sched16_ok(const camo_dims_t& d, const float* const* P, int precision, int 
 // The per-sample ("tail") GEMMs have M = B rows and a negligible FLOP share, so they always run
 // on the exact f32 MFMA; `precision` selects the MFMA type of the node-level (T-row) GEMMs only.
 int heads_forward(const camo_dims_t& d, const float* const* hp /*16 pointers*/, const Ws& w, int B, int F,
-                  float* outs, const DropCfg& drop, hipStream_t st) {
-  const int prec = CAMO_PREC_F32;
+                  float* outs, GB& g) {
   const int Fh = F / 2, C = d.num_classes, Wd = 2 * C + 2;
   const int nout[4] = {C, C, 1, 1}, coff[4] = {0, C, 2 * C, 2 * C + 1};
-  GB g(drop, prec, st);
   for (int x = 0; x < 4; ++x) {
     GemmProb& p = g.nt(w.fused, F, hp[4 * x], F, hp[4 * x + 1], w.hid + x * Fh, 4 * Fh, B, Fh, F, GF_RELU);
     set_drop(p, SITE_HEAD0 + x);
@@ -287,14 +309,12 @@ int heads_forward(const camo_dims_t& d, const float* const* hp /*16 pointers*/, 
 
 // d_outs -> dfused (w.dfused, zeroed here) and the 16 head-parameter gradients
 int heads_backward(const camo_dims_t& d, const float* const* hp, float* const* hg, const Ws& w, int B, int F,
-                   const float* outs, const float* d_outs, int pre_activation, const DropCfg& drop, hipStream_t st) {
-  const int prec = CAMO_PREC_F32;
+                   const float* outs, const float* d_outs, int pre_activation, const DropCfg& drop, hipStream_t st, GB& g) {
   const int Fh = F / 2, C = d.num_classes, Wd = 2 * C + 2;
   const int nout[4] = {C, C, 1, 1}, coff[4] = {0, C, 2 * C, 2 * C + 1};
   // (w.dfused was zeroed by the forward's memset of the workspace's zero block)
   const float* dlog = d_outs;
   if (!pre_activation) { CK(launch_head_out_grad(outs, d_outs, w.dlog, B, Wd, st), "head_out_grad"); dlog = w.dlog; }
-  GB g(drop, prec, st);
   for (int x = 0; x < 4; ++x) {
     GemmProb& p = g.nn(dlog + coff[x], Wd, hp[4 * x + 2], Fh, w.dhid + x * Fh, 4 * Fh, B, Fh, nout[x]);
     set_relu_bwd(p, w.hid + x * Fh, 4 * Fh, drop.scale);
@@ -479,7 +499,7 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
     CK(gt.run(), "late fc3");
     gt.nt(w.a2, F, P[CAMO_PL_W6], F, P[CAMO_PL_B6], w.fused, F, B, F, F);
     CK(gt.run(), "late fc6");
-    return heads_forward(d, P + CAMO_PL_HEADS, w, B, F, outs, drop, st);
+    return heads_forward(d, P + CAMO_PL_HEADS, w, B, F, outs, gt);
   }
 
   // ---- CrossAttentionFusion.forward, fusion_model.py:75-146
@@ -553,6 +573,8 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
                      {w.Y2, H, H, nullptr, Nk, w.Y2mean, H}, {w.H2, 2 * H, 2 * H, nullptr, Nk, w.H2mean, 2 * H}};
     CK(launch_seg_mean(sm, 4, B, max_nr > Nk ? max_nr : Nk, st), "pool");
   }
+  TailPlan tplan;
+  if (tail_persistent_ok(B)) tail_begin(tplan, gt, drop, w.sync);
   set_res(gt.nt(w.H1mean, 2 * H, P[CAMO_P_F1_W3], 2 * H, P[CAMO_P_F1_B3], w.comb, 2 * H, B, H, 2 * H), w.Ymean, H);
   set_res(gt.nt(w.H2mean, 2 * H, P[CAMO_P_F2_W3], 2 * H, P[CAMO_P_F2_B3], w.comb + H, 2 * H, B, H, 2 * H), w.Y2mean, H);
   CK(gt.run(), "ffn layer 3 on pooled rows");
@@ -561,7 +583,9 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
   CK(gt.run(), "fusion layer 0");
   gt.nt(w.F1, H, P[CAMO_P_FU_W3], H, P[CAMO_P_FU_B3], w.fused, H, B, H, H);
   CK(gt.run(), "fusion layer 3");
-  return heads_forward(d, P + CAMO_P_HEADS, w, B, H, outs, drop, st);
+  if (int e = heads_forward(d, P + CAMO_P_HEADS, w, B, H, outs, gt)) return e;
+  if (gt.plan) CK(launch_tail(tplan, st), "per-sample tail (persistent)");
+  return 0;
 }
 
 int camo_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
@@ -587,7 +611,7 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
 
   if (d.fusion_type == CAMO_FUSION_LATE) {
     const int F = H / 2, Dc = D + Dk;
-    if (int e = heads_backward(d, P + CAMO_PL_HEADS, Gr + CAMO_PL_HEADS, w, B, F, outs, d_outs, d_outs_pre_activation, drop, st)) return e;
+    if (int e = heads_backward(d, P + CAMO_PL_HEADS, Gr + CAMO_PL_HEADS, w, B, F, outs, d_outs, d_outs_pre_activation, drop, st, gt)) return e;
     set_relu_bwd(gt.nn(w.dfused, F, P[CAMO_PL_W6], F, w.da2, F, B, F, F), w.a2, F, drop.scale);
     gt.tn(w.dfused, F, w.a2, F, Gr[CAMO_PL_W6], F, Gr[CAMO_PL_B6], F, F, B);
     CK(gt.run(), "late fc6 bwd");
@@ -602,7 +626,9 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
   const bool has_rgp = P[CAMO_P_RG_PROJ_W] != nullptr, has_kgp = P[CAMO_P_KG_PROJ_W] != nullptr;
   const float* R = has_rgp ? w.R : rg;
   const float* G = has_kgp ? w.G : kg;
-  if (int e = heads_backward(d, P + CAMO_P_HEADS, Gr + CAMO_P_HEADS, w, B, H, outs, d_outs, d_outs_pre_activation, drop, st)) return e;
+  TailPlan tplan;
+  if (tail_persistent_ok(B)) tail_begin(tplan, gt, drop, w.sync + 4);
+  if (int e = heads_backward(d, P + CAMO_P_HEADS, Gr + CAMO_P_HEADS, w, B, H, outs, d_outs, d_outs_pre_activation, drop, st, gt)) return e;
   // fusion layer
   set_relu_bwd(gt.nn(w.dfused, H, P[CAMO_P_FU_W3], H, w.dF1, H, B, H, H), w.F1, H, drop.scale);
   gt.tn(w.dfused, H, w.F1, H, Gr[CAMO_P_FU_W3], H, Gr[CAMO_P_FU_B3], H, H, B);
@@ -616,6 +642,7 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
   gt.tn(w.dcomb, 2 * H, w.H1mean, 2 * H, Gr[CAMO_P_F1_W3], 2 * H, Gr[CAMO_P_F1_B3], H, 2 * H, B);
   gt.tn(w.dcomb + H, 2 * H, w.H2mean, 2 * H, Gr[CAMO_P_F2_W3], 2 * H, Gr[CAMO_P_F2_B3], H, 2 * H, B);
   CK(gt.run(), "ffn layer 3 bwd (pooled)");
+  if (gt.plan) CK(launch_tail(tplan, st), "per-sample tail bwd (persistent)");
   if (sched16_ok(d, P, precision, T, Nk, max_nr))
     return backward_nodes16(d, P, Gr, rg_offsets, row_sample, inv_nr, B, T, Nk, max_nr, w, drop, st);
   {

@@ -537,25 +537,18 @@ __global__ __launch_bounds__(256, (PIPE <= 2 ? 2 : 1)) void gemm_grouped_kernel(
 // both operands, so a lane's four steps come from one 16-B load where the source is k-contiguous.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// NW waves per block: 4, or 16 for launches made only of C = x.W^T problems with a long K (the forward tail:
-// 16 waves split K = 512 into two 16-deep blocks each, i.e. one memory round trip instead of four).
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmBatch gb) {
-  __shared__ float red[NW - 1][4][64];
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < GEMM_MAXP; ++i)
-    if (i < gb.n && (int)blockIdx.x >= gb.p[i].tile_begin) pi = i;
-  const GemmProb& P = gb.p[pi];
+// One 16x16 tile (or, for dW problems, NW tiles: one per wave) of skinny problem P; `local` = tile index within
+// the problem.  Every thread returns normally (the persistent tail kernel runs barriers after it).
+// Operand layouts and the 16-byte-load switch are COMPILE-TIME (block-uniform dispatch in skinny_tile below): with
+// runtime switches the loads sat in branches, their destination registers became PHIs, and the s_waitcnt in front
+// of the PHI copies drained the prefetch every k block (1.1 us per 16-deep block, one full memory round trip).
+template <int NW, bool akm, bool bkm, bool VEC>
+__device__ __forceinline__ void skinny_tile_body(const GemmProb& P, const DropCfg& drop, int local, float (*red)[4][64]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x = lane & 15, q = lane >> 4;
-  const bool akm = P.flags & GF_A_KMAJOR, bkm = P.flags & GF_B_KMAJOR;
   const int M = P.M, N = P.N, K = P.K;
-  Operand oa{P.A, P.lda, akm, false, M, K}, ob{P.B, P.ldb, bkm, false, N, K};
-  oa.vec = !akm && ((P.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.A) & 15) == 0) && ((K & 3) == 0);
-  ob.vec = !bkm && ((P.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.B) & 15) == 0) && ((K & 3) == 0);
+  const Operand oa{P.A, P.lda, akm, VEC, M, K}, ob{P.B, P.ldb, bkm, VEC, N, K};
   const int tiles_n = P.tiles_n;          // 16-wide column tiles
-  const int local = blockIdx.x - P.tile_begin;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   int tile, kb0, kbstep;
   if (akm) { tile = local * NW + wave; kb0 = 0; kbstep = 1; }    // a wave per tile, whole K
@@ -564,45 +557,55 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmBatch gb
   const int m0 = tm * 16, n0 = tn * 16;
   const bool live = m0 < M;               // (only the a-wave-per-tile mode can run past the last tile)
   float bsum = 0.f;
-  if (live) {
+  if (live && !(P.flags & (1 << 20))) {
     const int nkb = (K + 15) >> 4;
-    auto lda_ = [&](int kb) { const int k = kb * 16 + 4 * q; return akm ? raw_ks(oa, m0 + x, k) : (oa.vec ? raw_mm<true>(oa, m0 + x, k) : raw_mm<false>(oa, m0 + x, k)); };
-    auto ldb_ = [&](int kb) { const int k = kb * 16 + 4 * q; return bkm ? raw_ks(ob, n0 + x, k) : (ob.vec ? raw_mm<true>(ob, m0 * 0 + n0 + x, k) : raw_mm<false>(ob, n0 + x, k)); };
-    // two k blocks in flight; raw loads are address-clamped, masking happens at the point of use
-    // (a 4-deep version with 8 blocks in flight measured SLOWER: the extra clamped loads cost more than the
-    // latency they hide on these few-KB operands)
-    float4 a0 = lda_(kb0), b0 = ldb_(kb0), a1 = lda_(kb0 + kbstep), b1 = ldb_(kb0 + kbstep);
-    for (int kb = kb0; kb < nkb; kb += kbstep) {
-      float4 a = a0, b = b0;
-      a0 = a1; b0 = b1;
-      a1 = lda_(kb + 2 * kbstep); b1 = ldb_(kb + 2 * kbstep);
-      pin4(a); pin4(b);
-      a = mask_mm(oa, a, m0 + x, kb * 16 + 4 * q, K);     // (row/col, k) validity is layout-independent
-      b = mask_mm(ob, b, n0 + x, kb * 16 + 4 * q, K);
-      bsum += (a.x + a.y) + (a.z + a.w);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    auto lda_ = [&](int kb) { const int k = kb * 16 + 4 * q; if constexpr (akm) return raw_ks(oa, m0 + x, k); else return raw_mm<VEC>(oa, m0 + x, k); };
+    auto ldb_ = [&](int kb) { const int k = kb * 16 + 4 * q; if constexpr (bkm) return raw_ks(ob, n0 + x, k); else return raw_mm<VEC>(ob, n0 + x, k); };
+    // D k blocks in flight in D statically indexed register stages (rotating the stages through moves would make
+    // every move wait for its load); raw loads are address-clamped, blocks past K are masked to zero
+    constexpr int D = 4;
+    float4 sa[D], sb[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { sa[d] = lda_(kb0 + d * kbstep); sb[d] = ldb_(kb0 + d * kbstep); }
+    for (int kb = kb0; kb < nkb; kb += D * kbstep) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int kk = kb + d * kbstep;
+        pin4(sa[d]); pin4(sb[d]);
+        const float4 a = mask_mm(oa, sa[d], m0 + x, kk * 16 + 4 * q, K);     // (row/col, k) validity is layout-independent
+        const float4 b = mask_mm(ob, sb[d], n0 + x, kk * 16 + 4 * q, K);
+        // refill the stage only after its old contents are dead (the fence keeps the loads below it): a refill
+        // issued while they were still live went to other registers, and the copies back at the loop edge waited
+        // for every load in flight
+        asm volatile("" ::: "memory");
+        sa[d] = lda_(kk + D * kbstep); sb[d] = ldb_(kk + D * kbstep);
+        bsum += (a.x + a.y) + (a.z + a.w);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+      }
     }
   }
-  if (!akm) {
+  bool active = live;
+  if (!akm) {                              // (block-uniform)
     if (wave > 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave - 1][r][lane] = acc[r];
     }
     __syncthreads();
-    if (wave > 0) return;
+    active = wave == 0;
+    if (active) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = 0.f;
+      for (int r = 0; r < 4; ++r) {
+        float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];
-      acc[r] += v;
+        for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];
+        acc[r] += v;
+      }
     }
-  } else if (!live) {
-    return;
   }
+  if (!active) return;
   if (akm && P.bias_grad && tn == 0) {    // bias gradient: sum over k of A(m, k)
     bsum += __shfl_xor(bsum, 16, 64);
     bsum += __shfl_xor(bsum, 32, 64);
@@ -615,7 +618,83 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmBatch gb
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + 4 * q + r;
-      if (row < M) epilogue_store(P, gb.drop, acc[r] + bv, row, col);
+      if (row < M) epilogue_store(P, drop, acc[r] + bv, row, col);
+    }
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void skinny_tile(const GemmProb& P, const DropCfg& drop, int local, float (*red)[4][64]) {
+  const bool akm = P.flags & GF_A_KMAJOR, bkm = P.flags & GF_B_KMAJOR;
+  const bool vec = (akm || (((P.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.A) & 15) == 0))) &&
+                   (bkm || (((P.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.B) & 15) == 0))) && ((P.K & 3) == 0);
+  if (vec) {
+    if (!akm && !bkm)     skinny_tile_body<NW, false, false, true>(P, drop, local, red);
+    else if (!akm && bkm) skinny_tile_body<NW, false, true, true>(P, drop, local, red);
+    else if (akm && bkm)  skinny_tile_body<NW, true, true, true>(P, drop, local, red);
+    else                  skinny_tile_body<NW, true, false, true>(P, drop, local, red);
+  } else {
+    if (!akm && !bkm)     skinny_tile_body<NW, false, false, false>(P, drop, local, red);
+    else if (!akm && bkm) skinny_tile_body<NW, false, true, false>(P, drop, local, red);
+    else if (akm && bkm)  skinny_tile_body<NW, true, true, false>(P, drop, local, red);
+    else                  skinny_tile_body<NW, true, false, false>(P, drop, local, red);
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmBatch gb) {
+  __shared__ float red[NW - 1][4][64];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM_MAXP; ++i)
+    if (i < gb.n && (int)blockIdx.x >= gb.p[i].tile_begin) pi = i;
+  skinny_tile<NW>(gb.p[pi], gb.drop, blockIdx.x - gb.p[pi].tile_begin, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The whole per-sample tail in ONE launch.  Its five dependent layers (forward: pooled FFN layer, fusion MLP,
+// head layers; backward: the same in reverse with the weight gradients) are a few 16x16 tiles each, so as
+// separate launches they cost five launch floors (~5 us each on MI355X) for microseconds of work.  Here a
+// resident grid walks the phases and meets at a device-wide barrier between them: arrive = release fence +
+// atomic increment, wait = spin on the counter + acquire fence (the fences write back / invalidate the
+// non-coherent per-XCD L2 lines and the CU's L1, so plain loads and stores in between are safe).
+// Exit conditions: every block runs every phase and every barrier (no early exits); the spin gives up after
+// 2^22 polls and raises sync[2] instead of hanging; the counters reset themselves (last block out).
+__device__ __forceinline__ void tail_grid_barrier(unsigned int* sync, unsigned int target) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int spins = 0;
+    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 22)) { __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__global__ __launch_bounds__(256) void tail_persistent_kernel(const TailPlan tp) {
+  __shared__ float red[3][4][64];
+  const unsigned int nb = gridDim.x;
+  for (int ph = 0; ph < tp.nphase; ++ph) {
+    const int pb = tp.phase_begin[ph], pe = tp.phase_begin[ph + 1];
+    for (int t = blockIdx.x; t < tp.phase_tiles[ph]; t += nb) {
+      int pi = pb;
+      for (int i = pb + 1; i < pe; ++i)
+        if (t >= tp.p[i].tile_begin) pi = i;
+      skinny_tile<4>(tp.p[pi], tp.drop, t - tp.p[pi].tile_begin, red);
+      __syncthreads();                     // `red` is reused by the next tile
+    }
+    if (ph + 1 < tp.nphase) tail_grid_barrier(tp.sync, (unsigned int)(ph + 1) * nb);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int old = __hip_atomic_fetch_add(tp.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == nb - 1) {                   // last block out: every block is past its last barrier
+      __hip_atomic_store(tp.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(tp.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -676,9 +755,14 @@ void gemm_prof_close(int slot, hipStream_t stream) {
 
 static int launch_skinny(GemmBatch& gb, hipStream_t stream) {
   int total = 0;
-  // (16-wave blocks for the long-K forward problems measured 17 us against 8-13 us with 4 waves: kept off)
-  bool wide = false;
-  const int nw = wide ? 16 : 4;
+  // launches made only of C = x.W^T problems with a long K (the forward tail): 8 waves split K further
+  // (16-wave blocks measured 17 us against 8-13 us with 4 waves)
+  static const int dev_nw = [] { const char* e = std::getenv("CAMO_DEV_SKINNY_NW"); return e ? std::atoi(e) : 0; }();
+  static const bool dev_nok = [] { const char* e = std::getenv("CAMO_DEV_SKINNY_NOK"); return e && e[0] == '1'; }();
+  if (dev_nok) for (int i = 0; i < gb.n; ++i) gb.p[i].flags |= (1 << 20);      // timing experiment: skip the K loop
+  bool wide = dev_nw == 8;
+  for (int i = 0; i < gb.n; ++i) wide = wide && !(gb.p[i].flags & GF_A_KMAJOR) && gb.p[i].K >= 256;
+  const int nw = wide ? 8 : 4;
   for (int i = 0; i < gb.n; ++i) {
     GemmProb& p = gb.p[i];
     p.tiles_n = (p.N + 15) / 16;
@@ -688,8 +772,41 @@ static int launch_skinny(GemmBatch& gb, hipStream_t stream) {
     total += (p.flags & GF_A_KMAJOR) ? (tiles + nw - 1) / nw : tiles;
   }
   if (total == 0) return 0;
-  if (wide) hipLaunchKernelGGL(gemm_skinny_kernel<16>, dim3(total), dim3(1024), 0, stream, gb);
+  if (wide) hipLaunchKernelGGL(gemm_skinny_kernel<8>, dim3(total), dim3(512), 0, stream, gb);
   else      hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(total), dim3(256), 0, stream, gb);
+  return (int)hipGetLastError();
+}
+
+int tail_problem_ok(const GemmProb& p) { return ((p.flags & GF_A_KMAJOR) ? p.K : p.M) <= 64; }
+
+int launch_tail(TailPlan& tp, hipStream_t stream) {
+  if (tp.nphase <= 0 || tp.n <= 0) return 0;
+  if (!tp.sync || tp.nphase > TAIL_MAXPH || tp.n > TAIL_MAXP) return (int)hipErrorInvalidValue;
+  int max_tiles = 1;
+  for (int ph = 0; ph < tp.nphase; ++ph) {
+    int total = 0;
+    for (int i = tp.phase_begin[ph]; i < tp.phase_begin[ph + 1]; ++i) {
+      GemmProb& p = tp.p[i];
+      if (!tail_problem_ok(p)) return (int)hipErrorInvalidValue;
+      p.tiles_n = (p.N + 15) / 16;
+      const int tiles = ((p.M + 15) / 16) * p.tiles_n;
+      p.ksplit = 1; p.kchunk = p.K;
+      p.tile_begin = total;
+      total += (p.flags & GF_A_KMAJOR) ? (tiles + 3) / 4 : tiles;
+    }
+    tp.phase_tiles[ph] = total;
+    if (total > max_tiles) max_tiles = total;
+  }
+  // every block must be resident at once (the barrier spins): one block per CU at most, and no more blocks than
+  // the widest phase has tiles
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 64;
+    return n;
+  }();
+  int grid = max_tiles < 208 ? max_tiles : 208;
+  if (grid > cus) grid = cus;
+  hipLaunchKernelGGL(tail_persistent_kernel, dim3(grid), dim3(256), 0, stream, tp);
   return (int)hipGetLastError();
 }
 
