@@ -75,13 +75,13 @@ __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64)
 // ------------------------------------------------------------------ rg2kg forward
 // one wave = one (16-node tile, head) pair of sample blockIdx.y: tile-major, head fastest, so the 4 waves
 // of a block share Q rows.  The head-averaged map (inference only) is a separate pass over P.
-__global__ __launch_bounds__(256) void rg2kg_fwd_mfma_kernel(
+__device__ __forceinline__ void rg2kg_fwd_body(
     const float* __restrict__ Q, const float* __restrict__ KV, const int* __restrict__ offs,
-    float* __restrict__ P, float* __restrict__ O, Bf16Dst o16, int H, int nh, int Nk, float scale, DropCfg drop) {
-  const int b = blockIdx.y;
+    float* __restrict__ P, float* __restrict__ O, Bf16Dst o16, int H, int nh, int Nk, float scale, const DropCfg& drop,
+    int bx, int b) {
   const int r0 = offs[b], nr = offs[b + 1] - r0;
   const int lane = threadIdx.x & 63, x = lane & 15, q = lane >> 4;
-  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int task = bx * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
   const int h = task % nh, t0 = (task / nh) * 16;
   if (t0 >= nr) return;
   const int node = r0 + min(t0 + x, nr - 1);            // this lane's node as a COLUMN of S^T
@@ -125,6 +125,12 @@ __global__ __launch_bounds__(256) void rg2kg_fwd_mfma_kernel(
   }
 }
 
+__global__ __launch_bounds__(256) void rg2kg_fwd_mfma_kernel(
+    const float* __restrict__ Q, const float* __restrict__ KV, const int* __restrict__ offs,
+    float* __restrict__ P, float* __restrict__ O, Bf16Dst o16, int H, int nh, int Nk, float scale, DropCfg drop) {
+  rg2kg_fwd_body(Q, KV, offs, P, O, o16, H, nh, Nk, scale, drop, blockIdx.x, blockIdx.y);
+}
+
 // head-average of the (dropped) probabilities: out[t][j] = mean_h drop(P[t,h,j])
 __global__ void attn_avg_site_kernel(const float* __restrict__ Pm, float* __restrict__ out, int T, int nh, int Nk,
                                      uint32_t site, DropCfg drop) {
@@ -145,31 +151,19 @@ __global__ void attn_avg_site_kernel(const float* __restrict__ Pm, float* __rest
 // grid (chunks, nh, B); one wave = TPW consecutive 16-node tiles of (sample, head); dK/dV partials in
 // accumulator tiles, one atomicAdd per element per wave.
 constexpr int TPW = 2;
-__global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
-    const float* __restrict__ Q, const float* __restrict__ KV, const float* __restrict__ P,
-    const float* __restrict__ dO, const int* __restrict__ offs,
-    float* __restrict__ dQ, float* __restrict__ dKV, Bf16Dst dq16,
-    int H, int nh, int Nk, float scale, DropCfg drop) {
-  __shared__ float comb[3][16][64];
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int r0 = offs[b], nr = offs[b + 1] - r0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
-  if ((int)blockIdx.x * 4 * TPW * 16 >= nr) return;      // whole block past the sample (uniform)
-  const int tfirst = (blockIdx.x * 4 + wave) * TPW;
-  const float* kvb = KV + (size_t)b * Nk * 2 * H;
-  const Frag8 vf = load_row8(kvb + (size_t)min(x, Nk - 1) * 2 * H + H + h * DH, q, x < Nk);
-  f4 kb[2], dKa[2], dVa[2];
-#pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    kb[n] = load_col4(kvb + h * DH + 16 * n, (size_t)2 * H, 0, q, Nk - 1, x);   // K_h[key 4q+e][16n + x]
-    dKa[n] = f4{0.f, 0.f, 0.f, 0.f}; dVa[n] = f4{0.f, 0.f, 0.f, 0.f};
-  }
-  // all loads of both tiles first, unconditionally, from rows clamped into the sample (see kg2rg forward)
+// TPW 16-node tiles (first nodes t0s[], any order) of (sample, head): dQ rows are stored, the dK / dV partial sums
+// of the tiles are added to dKa / dVa (rows = keys 4q+r, col = 16n + x).
+__device__ __forceinline__ void rg2kg_bwd_tiles(
+    const float* __restrict__ Q, const float* __restrict__ P, const float* __restrict__ dO,
+    float* __restrict__ dQ, Bf16Dst dq16, int H, int nh, int Nk, float scale, const DropCfg& drop,
+    int r0, int nr, int h, const int (&t0s)[TPW], const Frag8& vf, const f4 (&kb)[2], f4 (&dKa)[2], f4 (&dVa)[2]) {
+  const int lane = threadIdx.x & 63, x = lane & 15, q = lane >> 4;
+  // all loads of the tiles first, unconditionally, from rows clamped into the sample (see kg2rg forward)
   Frag8 gfv[TPW];
   f4 pTv[TPW], pNv[TPW], qbv[TPW][2], gbv[TPW][2];
 #pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
-    const int t0 = min((tfirst + tt) * 16, nr - 1);
+    const int t0 = min(t0s[tt], nr - 1);
     const int node = r0 + min(t0 + x, nr - 1);
     gfv[tt] = load_row8(dO + (size_t)node * H + h * DH, q, true);
     const size_t pbase = ((size_t)node * nh + h) * Nk;
@@ -186,7 +180,7 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
   }
 #pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
-    const int t0 = (tfirst + tt) * 16;
+    const int t0 = t0s[tt];
     if (t0 >= nr) continue;                                  // wave-uniform; nothing below loads
     const int node = r0 + min(t0 + x, nr - 1);
     const bool node_ok = t0 + x < nr;
@@ -239,6 +233,31 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
       dVa[n] = mma_acc16(pdN, gbv[tt][n], dVa[n]);
     }
   }
+}
+
+// grid (chunks, nh, B); one wave = TPW consecutive 16-node tiles of (sample, head); the block's dK/dV partials are
+// combined in LDS, one atomicAdd per element per block.
+__global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
+    const float* __restrict__ Q, const float* __restrict__ KV, const float* __restrict__ P,
+    const float* __restrict__ dO, const int* __restrict__ offs,
+    float* __restrict__ dQ, float* __restrict__ dKV, Bf16Dst dq16,
+    int H, int nh, int Nk, float scale, DropCfg drop) {
+  __shared__ float comb[3][16][64];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int r0 = offs[b], nr = offs[b + 1] - r0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
+  if ((int)blockIdx.x * 4 * TPW * 16 >= nr) return;      // whole block past the sample (uniform)
+  const int tfirst = (blockIdx.x * 4 + wave) * TPW;
+  const float* kvb = KV + (size_t)b * Nk * 2 * H;
+  const Frag8 vf = load_row8(kvb + (size_t)min(x, Nk - 1) * 2 * H + H + h * DH, q, x < Nk);
+  f4 kb[2], dKa[2], dVa[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    kb[n] = load_col4(kvb + h * DH + 16 * n, (size_t)2 * H, 0, q, Nk - 1, x);   // K_h[key 4q+e][16n + x]
+    dKa[n] = f4{0.f, 0.f, 0.f, 0.f}; dVa[n] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int t0s[TPW] = {tfirst * 16, (tfirst + 1) * 16};
+  rg2kg_bwd_tiles(Q, P, dO, dQ, dq16, H, nh, Nk, scale, drop, r0, nr, h, t0s, vf, kb, dKa, dVa);
   // combine the block's four partial tiles in LDS, then one atomicAdd per element per block
   if (wave > 0) {
 #pragma unroll
@@ -264,12 +283,10 @@ __global__ __launch_bounds__(256) void rg2kg_bwd_mfma_kernel(
 
 // ------------------------------------------------------------------ kg2rg forward, grid (nh, B)
 // wave w owns key tiles w, w+4, ...; scores S2^T (rows = keys 4q+r, col = query x) stay in registers.
-__global__ __launch_bounds__(64 * NW) void kg2rg_fwd_mfma_kernel(
+__device__ __forceinline__ void kg2rg_fwd_body(
     const float* __restrict__ Q2, const float* __restrict__ KV2, const int* __restrict__ offs,
-    float* __restrict__ P2, float* __restrict__ O2, Bf16Dst o16, int H, int nh, int Nk, float scale, DropCfg drop) {
-  __shared__ float red[NW][16];
-  __shared__ float ored[NW - 1][2][4][64];
-  const int h = blockIdx.x, b = blockIdx.y;
+    float* __restrict__ P2, float* __restrict__ O2, Bf16Dst o16, int H, int nh, int Nk, float scale, const DropCfg& drop,
+    int h, int b, float (*red)[16], float (*ored)[2][4][64]) {
   const int r0 = offs[b], nr = offs[b + 1] - r0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
   const int ntiles = (nr + 15) >> 4;
@@ -365,15 +382,21 @@ __global__ __launch_bounds__(64 * NW) void kg2rg_fwd_mfma_kernel(
   }
 }
 
+__global__ __launch_bounds__(64 * NW) void kg2rg_fwd_mfma_kernel(
+    const float* __restrict__ Q2, const float* __restrict__ KV2, const int* __restrict__ offs,
+    float* __restrict__ P2, float* __restrict__ O2, Bf16Dst o16, int H, int nh, int Nk, float scale, DropCfg drop) {
+  __shared__ float red[NW][16];
+  __shared__ float ored[NW - 1][2][4][64];
+  kg2rg_fwd_body(Q2, KV2, offs, P2, O2, o16, H, nh, Nk, scale, drop, blockIdx.x, blockIdx.y, red, ored);
+}
+
 // ------------------------------------------------------------------ kg2rg backward, grid (nh, B)
-__global__ __launch_bounds__(64 * NW) void kg2rg_bwd_mfma_kernel(
+__device__ __forceinline__ void kg2rg_bwd_body(
     const float* __restrict__ Q2, const float* __restrict__ KV2, const float* __restrict__ P2,
     const float* __restrict__ dO2, const int* __restrict__ offs,
     float* __restrict__ dQ2, float* __restrict__ dKV2, Bf16Dst dq2_16, Bf16Dst dkv2_16,
-    const float* __restrict__ dKV_done, Bf16Dst dkv_16, int H, int nh, int Nk, float scale, DropCfg drop) {
-  __shared__ float red[NW][16];
-  __shared__ float ored[NW - 1][2][4][64];
-  const int h = blockIdx.x, b = blockIdx.y;
+    const float* __restrict__ dKV_done, Bf16Dst dkv_16, int H, int nh, int Nk, float scale, const DropCfg& drop,
+    int h, int b, float (*red)[16], float (*ored)[2][4][64]) {
   // bf16 schedule: dK|dV of the OTHER attention block (complete: its kernel ran before this one) is the next
   // GEMM's operand; this block converts the slice of its (sample, head)
   if (dkv_16.p) {
@@ -529,7 +552,125 @@ __global__ __launch_bounds__(64 * NW) void kg2rg_bwd_mfma_kernel(
   }
 }
 
+__global__ __launch_bounds__(64 * NW) void kg2rg_bwd_mfma_kernel(
+    const float* __restrict__ Q2, const float* __restrict__ KV2, const float* __restrict__ P2,
+    const float* __restrict__ dO2, const int* __restrict__ offs,
+    float* __restrict__ dQ2, float* __restrict__ dKV2, Bf16Dst dq2_16, Bf16Dst dkv2_16,
+    const float* __restrict__ dKV_done, Bf16Dst dkv_16, int H, int nh, int Nk, float scale, DropCfg drop) {
+  __shared__ float red[NW][16];
+  __shared__ float ored[NW - 1][2][4][64];
+  kg2rg_bwd_body(Q2, KV2, P2, dO2, offs, dQ2, dKV2, dq2_16, dkv2_16, dKV_done, dkv_16, H, nh, Nk, scale, drop,
+                 blockIdx.x, blockIdx.y, red, ored);
+}
+
+// ------------------------------------------------------------------ rg2kg backward, one block per (head, sample)
+// The "owner" form used by the paired launch below: the block's NW waves walk all 16-node tiles of the sample
+// (tile t -> wave t % NW), so dK / dV of the (head, sample) are complete inside the block: no atomics, no zeroed
+// accumulator, and the result is written straight as the bf16 GEMM operand.
+__device__ __forceinline__ void rg2kg_bwd_owner_body(
+    const float* __restrict__ Q, const float* __restrict__ KV, const float* __restrict__ P,
+    const float* __restrict__ dO, const int* __restrict__ offs, Bf16Dst dq16, Bf16Dst dkv16,
+    int H, int nh, int Nk, float scale, const DropCfg& drop, int h, int b, float (*comb)[16][64]) {
+  const int r0 = offs[b], nr = offs[b + 1] - r0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, q = lane >> 4;
+  const float* kvb = KV + (size_t)b * Nk * 2 * H;
+  const Frag8 vf = load_row8(kvb + (size_t)min(x, Nk - 1) * 2 * H + H + h * DH, q, x < Nk);
+  f4 kb[2], dKa[2], dVa[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    kb[n] = load_col4(kvb + h * DH + 16 * n, (size_t)2 * H, 0, q, Nk - 1, x);   // K_h[key 4q+e][16n + x]
+    dKa[n] = f4{0.f, 0.f, 0.f, 0.f}; dVa[n] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  static_assert(MAXT % TPW == 0, "tile groups");
+#pragma unroll 1
+  for (int g = 0; g < MAXT / TPW; ++g) {
+    const int t0s[TPW] = {(wave + NW * (TPW * g)) * 16, (wave + NW * (TPW * g + 1)) * 16};
+    if (t0s[0] >= nr) break;                                // wave-uniform
+    rg2kg_bwd_tiles(Q, P, dO, nullptr, dq16, H, nh, Nk, scale, drop, r0, nr, h, t0s, vf, kb, dKa, dVa);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { comb[wave - 1][n * 4 + r][lane] = dKa[n][r]; comb[wave - 1][8 + n * 4 + r][lane] = dVa[n][r]; }
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 4 * q + r;
+      if (key < Nk) {
+        const int i = n * 4 + r;
+        float dk = dKa[n][r], dv = dVa[n][r];
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w) { dk += comb[w][i][lane]; dv += comb[w][8 + i][lane]; }
+        unsigned short* dst = dkv16.p + (size_t)(b * Nk + key) * dkv16.ld + h * DH + 16 * n + x;
+        dst[0] = f2bf(dk);
+        dst[H] = f2bf(dv);
+      }
+    }
+}
+
+// ------------------------------------------------------------------ paired launches (bf16 schedule)
+// The two attention directions are independent of each other and each is a small-grid, latency-bound kernel, so
+// they share one launch: blocks [0, nh*B) run kg2rg for (head, sample), the rest run rg2kg.  Forward: rg2kg takes
+// NW (tile, head) tasks per block.  Backward: rg2kg in its owner form, nh*B blocks -- 2*nh*B blocks of NW waves in
+// all, one per CU at the benchmark batch.
+union PairLds {
+  struct { float red[NW][16]; float ored[NW - 1][2][4][64]; } k;
+  float comb[NW - 1][16][64];
+};
+
+__global__ __launch_bounds__(64 * NW) void attn_fwd_pair_kernel(
+    const float* __restrict__ Q, const float* __restrict__ KV, const float* __restrict__ Q2, const float* __restrict__ KV2,
+    const int* __restrict__ offs, float* __restrict__ P, float* __restrict__ P2, float* __restrict__ O, float* __restrict__ O2,
+    Bf16Dst o16, Bf16Dst o2_16, int H, int nh, int Nk, int B, int nbx, float scale, DropCfg drop) {
+  __shared__ PairLds lds;
+  const int bid = blockIdx.x;
+  if (bid < nh * B) {
+    kg2rg_fwd_body(Q2, KV2, offs, P2, O2, o2_16, H, nh, Nk, scale, drop, bid % nh, bid / nh, lds.k.red, lds.k.ored);
+  } else {
+    const int r = bid - nh * B;
+    rg2kg_fwd_body(Q, KV, offs, P, O, o16, H, nh, Nk, scale, drop, r % nbx, r / nbx);
+  }
+}
+
+__global__ __launch_bounds__(64 * NW) void attn_bwd_pair_kernel(
+    const float* __restrict__ Q, const float* __restrict__ KV, const float* __restrict__ P, const float* __restrict__ dO,
+    const float* __restrict__ Q2, const float* __restrict__ KV2, const float* __restrict__ P2, const float* __restrict__ dO2,
+    const int* __restrict__ offs, Bf16Dst dq16, Bf16Dst dkv16, Bf16Dst dq2_16, Bf16Dst dkv2_16,
+    int H, int nh, int Nk, int B, float scale, DropCfg drop) {
+  __shared__ PairLds lds;
+  const int bid = blockIdx.x;
+  if (bid < nh * B) {
+    kg2rg_bwd_body(Q2, KV2, P2, dO2, offs, nullptr, nullptr, dq2_16, dkv2_16, nullptr, Bf16Dst{nullptr, 0}, H, nh, Nk, scale, drop,
+                   bid % nh, bid / nh, lds.k.red, lds.k.ored);
+  } else {
+    const int r = bid - nh * B;
+    rg2kg_bwd_owner_body(Q, KV, P, dO, offs, dq16, dkv16, H, nh, Nk, scale, drop, r % nh, r / nh, lds.comb);
+  }
+}
+
 }  // namespace
+
+int launch_attn_fwd_pair(const float* Q, const float* KV, const float* Q2, const float* KV2, const int* offs, float* P,
+                         float* P2, Bf16Dst o16, Bf16Dst o2_16, int B, int max_nr, int H, int nh, int Nk, DropCfg drop,
+                         hipStream_t stream) {
+  const int tasks = ((max_nr + 15) / 16) * nh, nbx = (tasks + NW - 1) / NW;
+  hipLaunchKernelGGL(attn_fwd_pair_kernel, dim3(nh * B + nbx * B), dim3(64 * NW), 0, stream, Q, KV, Q2, KV2, offs, P, P2,
+                     (float*)nullptr, (float*)nullptr, o16, o2_16, H, nh, Nk, B, nbx, 1.0f / sqrtf((float)DH), drop);
+  return (int)hipGetLastError();
+}
+
+int launch_attn_bwd_pair(const float* Q, const float* KV, const float* P, const float* dO, const float* Q2, const float* KV2,
+                         const float* P2, const float* dO2, const int* offs, Bf16Dst dq16, Bf16Dst dkv16, Bf16Dst dq2_16,
+                         Bf16Dst dkv2_16, int B, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
+  hipLaunchKernelGGL(attn_bwd_pair_kernel, dim3(2 * nh * B), dim3(64 * NW), 0, stream, Q, KV, P, dO, Q2, KV2, P2, dO2, offs,
+                     dq16, dkv16, dq2_16, dkv2_16, H, nh, Nk, B, 1.0f / sqrtf((float)DH), drop);
+  return (int)hipGetLastError();
+}
 
 // ------------------------------------------------------------------ launchers
 int attn_mfma_ok(int H, int nh, int Nk, int max_nr, bool kg2rg) {

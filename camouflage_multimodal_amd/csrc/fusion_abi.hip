@@ -376,8 +376,10 @@ int forward_nodes16(const camo_dims_t& d, const float* const* P, const float* rg
   g.nt(h.G, H, h.Win1 + HH, H, P[CAMO_P_A1_IN_B] + H, w.KV, 2 * H, nullptr, 0, TK, 2 * H, H);
   g.nt(h.G, H, h.Win2, H, P[CAMO_P_A2_IN_B], w.Q2, H, nullptr, 0, TK, H, H);
   CK(g.run(), "attention in-projections");
-  CK(launch_rg2kg_fwd_mfma(w.Q, w.KV, rg_offsets, w.P, nullptr, attn_rg2kg, B, T, max_nr, H, nh, Nk, drop, st, Bf16Dst{h.O, H}), "attn rg2kg fwd");
-  CK(launch_kg2rg_fwd_mfma(w.Q2, w.KV2, rg_offsets, w.P2, nullptr, B, H, nh, Nk, drop, st, Bf16Dst{h.O2, H}), "attn kg2rg fwd");
+  // both attention directions in one launch; their outputs are GEMM operands only, so they are written as bf16
+  CK(launch_attn_fwd_pair(w.Q, w.KV, w.Q2, w.KV2, rg_offsets, w.P, w.P2, Bf16Dst{h.O, H}, Bf16Dst{h.O2, H}, B, max_nr, H, nh, Nk,
+                          drop, st), "attention fwd (both directions)");
+  if (attn_rg2kg) CK(launch_attn_avg_site(w.P, attn_rg2kg, T, nh, Nk, SITE_ATTN_RG2KG, drop, st), "attn avg rg2kg");
   if (attn_kg2rg) CK(launch_attn_avg(w.P2, attn_kg2rg, T, nh, Nk, drop, st), "attn avg");
   // out-projection + residual (fusion_model.py:119,130), then LayerNorm
   set_res(g.nt(h.O, H, h.Wo1, H, P[CAMO_P_A1_OUT_B], w.U, H, nullptr, 0, T, H, H), w.R, H);
@@ -427,10 +429,10 @@ int backward_nodes16(const camo_dims_t& d, const float* const* P, float* const* 
   CK(g.run(), "out-projection bwd");
   // attention cores.  Their node-side outputs are GEMM operands only, so they are written as bf16 straight into the
   // concatenated [dQ | dK2 | dV2] (rg rows) and [dQ2 | dK | dV] (kg rows) operands of the in-projection backward.
-  CK(launch_rg2kg_bwd_mfma(w.Q, w.KV, w.P, w.dO, rg_offsets, nullptr, w.dKV, B, max_nr, H, nh, Nk, drop, st,
-                           Bf16Dst{h.dQKV, 3 * H}), "attn rg2kg bwd");
-  CK(launch_kg2rg_bwd_mfma(w.Q2, w.KV2, w.P2, w.dO2, rg_offsets, nullptr, nullptr, B, H, nh, Nk, drop, st,
-                           Bf16Dst{h.dQKVkg, 3 * H}, Bf16Dst{h.dQKV + H, 3 * H}, w.dKV, Bf16Dst{h.dQKVkg + H, 3 * H}), "attn kg2rg bwd");
+  // Both directions run in one launch, each (head, sample) owned by one block, so nothing is accumulated with atomics.
+  CK(launch_attn_bwd_pair(w.Q, w.KV, w.P, w.dO, w.Q2, w.KV2, w.P2, w.dO2, rg_offsets, Bf16Dst{h.dQKV, 3 * H},
+                          Bf16Dst{h.dQKVkg + H, 3 * H}, Bf16Dst{h.dQKVkg, 3 * H}, Bf16Dst{h.dQKV + H, 3 * H}, B, H, nh, Nk, drop, st),
+     "attention bwd (both directions)");
   // in-projections: one K = 3H product per side for the input gradient (dR = dU + [dQ|dK2|dV2].[Wq1;Wk2;Wv2]),
   // and the four weight gradients
   set_res(g.nt(h.dQKV, 3 * H, h.WcRgT, 3 * H, nullptr, nullptr, 0, h.dR, H, T, H, 3 * H), w.dU, H);
