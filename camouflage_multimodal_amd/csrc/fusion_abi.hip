@@ -72,6 +72,7 @@ struct Ws {
   // (WcRgT = [Wq1^T | Wk2^T | Wv2^T], WcKgT = [Wq2^T | Wk1^T | Wv1^T], both [H][3H]).
   struct H16 {
     unsigned short *X, *KG, *R, *G, *O, *O2, *Y, *Y2, *dH1, *dH2, *dU, *dU2, *dQKV, *dQKVkg, *dR, *dG;
+    unsigned short *H1, *H2;   // post-ReLU/dropout FFN activations: only their sign pattern is read again (backward mask)
     unsigned short *Wrg, *Wkg, *Win1, *Win2, *Wo1, *Wo2, *W1, *W2, *W1T, *W2T, *Wo1T, *Wo2T, *WcRgT, *WcKgT;
   } h;
   size_t Tp, TKp;
@@ -130,6 +131,7 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
       h.Wo1 = c.take<us>(H * H); h.Wo2 = c.take<us>(H * H); h.W1 = c.take<us>(2 * H * H); h.W2 = c.take<us>(2 * H * H);
       h.W1T = c.take<us>(2 * H * H); h.W2T = c.take<us>(2 * H * H); h.Wo1T = c.take<us>(H * H); h.Wo2T = c.take<us>(H * H);
       h.WcRgT = c.take<us>(3 * H * H); h.WcKgT = c.take<us>(3 * H * H);
+      h.H1 = c.take<us>((size_t)T * 2 * H); h.H2 = c.take<us>(TK * 2 * H);
     }
   } else {
     const size_t F = H / 2, Fh = F / 2, Dc = (size_t)d.rg_dim + d.kg_dim;
@@ -331,7 +333,8 @@ int heads_backward(const camo_dims_t& d, const float* const* hp, float* const* h
 
 
 // ---- node-level forward of the bf16 schedule: CrossAttentionFusion.forward, fusion_model.py:75-135 ----
-int forward_nodes16(const camo_dims_t& d, const float* const* P, const float* rg, const int32_t* rg_offsets, const float* kg,
+int forward_nodes16(const camo_dims_t& d, const float* const* P, const float* rg, const int32_t* rg_offsets,
+                    const int32_t* row_sample, const float* inv_nr, const float* kg,
                     int B, int T, int Nk, int max_nr, const Ws& w, float* attn_rg2kg, float* attn_kg2rg, const DropCfg& drop,
                     hipStream_t st) {
   const int H = d.hidden_dim, D = d.rg_dim, Dk = d.kg_dim, TK = B * Nk, nh = d.num_heads;
@@ -386,13 +389,22 @@ int forward_nodes16(const camo_dims_t& d, const float* const* P, const float* rg
   set_res(g.nt(h.O2, H, h.Wo2, H, P[CAMO_P_A2_OUT_B], w.U2, H, nullptr, 0, TK, H, H), w.G, H);
   CK(g.run(), "attention out-projections");
   {
-    LnSeg s0{w.U, w.Y, w.st1, P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], T, h.Y};
-    LnSeg s1{w.U2, w.Y2, w.st2, P[CAMO_P_LN2_W], P[CAMO_P_LN2_B], TK, h.Y2};
+    // (the mean pools of Y and of the FFN activations are accumulated by the kernels that produce them)
+    LnSeg s0{w.U, w.Y, w.st1, P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], T, h.Y, w.Ymean, row_sample, inv_nr, 0};
+    LnSeg s1{w.U2, w.Y2, w.st2, P[CAMO_P_LN2_W], P[CAMO_P_LN2_B], TK, h.Y2, w.Y2mean, nullptr, nullptr, Nk};
     CK(launch_ln_fwd(s0, s1, H, st), "layernorm fwd");
   }
-  // FFN first layers (ReLU + dropout fused), fusion_model.py:53-65
-  set_drop(g.nt(h.Y, H, h.W1, H, P[CAMO_P_F1_B0], w.H1, 2 * H, nullptr, 0, T, 2 * H, H, GF_RELU), SITE_FFN_RG);
-  set_drop(g.nt(h.Y2, H, h.W2, H, P[CAMO_P_F2_B0], w.H2, 2 * H, nullptr, 0, TK, 2 * H, H, GF_RELU), SITE_FFN_KG);
+  // FFN first layers (ReLU + dropout fused), fusion_model.py:53-65.  The activation itself is kept only as bf16 (its
+  // sign pattern is the backward mask); its per-sample mean, which the pooled second layer consumes, comes out of
+  // the fp32 accumulators in the epilogue.
+  {
+    Gemm16Prob& p1 = g.nt(h.Y, H, h.W1, H, P[CAMO_P_F1_B0], nullptr, 0, h.H1, 2 * H, T, 2 * H, H, GF_RELU);
+    set_drop(p1, SITE_FFN_RG);
+    p1.colmean = w.H1mean; p1.ldm = 2 * H; p1.row_sample = row_sample; p1.inv_nr = inv_nr;
+    Gemm16Prob& p2 = g.nt(h.Y2, H, h.W2, H, P[CAMO_P_F2_B0], nullptr, 0, h.H2, 2 * H, TK, 2 * H, H, GF_RELU);
+    set_drop(p2, SITE_FFN_KG);
+    p2.colmean = w.H2mean; p2.ldm = 2 * H; p2.uniform_n = Nk;
+  }
   CK(g.run(), "ffn layer 0");
   return 0;
 }
@@ -405,8 +417,8 @@ int backward_nodes16(const camo_dims_t& d, const float* const* P, float* const* 
   const size_t HH = (size_t)H * H;
   const Ws::H16& h = w.h;
   {
-    BcastSeg s0{w.H1, w.dHm1, 2 * H, row_sample, inv_nr, 0, nullptr, T, h.dH1};
-    BcastSeg s1{w.H2, w.dHm2, 2 * H, nullptr, nullptr, Nk, nullptr, TK, h.dH2};
+    BcastSeg s0{nullptr, w.dHm1, 2 * H, row_sample, inv_nr, 0, nullptr, T, h.dH1, h.H1};
+    BcastSeg s1{nullptr, w.dHm2, 2 * H, nullptr, nullptr, Nk, nullptr, TK, h.dH2, h.H2};
     CK(launch_relu_bcast_bwd(s0, s1, 2 * H, drop.scale, st), "relu bcast bwd");
   }
   GB16 g(drop, st);
@@ -516,7 +528,7 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
                      rg_fused_supported(D, H, nh, Nk);
   const size_t HH2 = (size_t)H * H;
   if (use16) {
-    if (int e = forward_nodes16(d, P, rg, rg_offsets, kg, B, T, Nk, max_nr, w, attn_rg2kg, attn_kg2rg, drop, st)) return e;
+    if (int e = forward_nodes16(d, P, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, w, attn_rg2kg, attn_kg2rg, drop, st)) return e;
   } else {
   if (P[CAMO_P_KG_PROJ_W]) { g.nt(kg, Dk, P[CAMO_P_KG_PROJ_W], Dk, P[CAMO_P_KG_PROJ_B], w.G, H, TK, H, Dk); G = w.G; }
   if (!fused && P[CAMO_P_RG_PROJ_W]) { g.nt(rg, D, P[CAMO_P_RG_PROJ_W], D, P[CAMO_P_RG_PROJ_B], w.R, H, T, H, D); R = w.R; }
@@ -567,7 +579,9 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
   CK(g.run(), "ffn layer 0");
   }
   // per-sample means of Y and H1d, then the second FFN layer on the means (mean-pool linearity)
-  if (fused) {   // the node-level sums were accumulated by the fused kernel
+  if (use16) {
+    // accumulated by layernorm fwd and the FFN GEMM epilogue
+  } else if (fused) {   // the node-level sums were accumulated by the fused kernel
     SegMean sm[2] = {{w.Y2, H, H, nullptr, Nk, w.Y2mean, H}, {w.H2, 2 * H, 2 * H, nullptr, Nk, w.H2mean, 2 * H}};
     CK(launch_seg_mean(sm, 2, B, Nk, st), "pool (kg)");
   } else {

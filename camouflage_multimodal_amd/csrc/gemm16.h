@@ -31,6 +31,9 @@ struct Gemm16Prob {
   uint32_t drop_site;
   float aux_scale;
   const int* row_sample; const float* inv_nr; int uniform_n;
+  // NT only: colmean[sample(row)][col] += out(row, col) * inv_n(sample(row))  -- the per-sample mean pool of the
+  // result, accumulated with atomics into a zeroed [samples][ldm] buffer (sample(): as for GF_RES_BCAST)
+  float* colmean; int ldm;
   // filled by the launcher
   int tiles_n, ksplit, kchunk, tile_begin;
 };

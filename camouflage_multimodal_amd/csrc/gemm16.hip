@@ -126,7 +126,8 @@ __device__ __forceinline__ void body_nt(const Gemm16Batch& gb, const Gemm16Prob&
   // ---- epilogue.  C^T orientation: lane&31 = output row, registers 4g..4g+3 = columns c0..c0+3,
   // c0 = 32 j + 8 g + 4 (lane>>5)
   const int row = m0 + wr * 32 + l31;
-  if (row >= M) return;
+  const bool rok = row < M;
+  const int rowc = rok ? row : M - 1;
   const int flags = P.flags;
   const float floor_ = (flags & GF_RELU) ? 0.f : -INFINITY;
   const bool dodrop = (flags & GF_DROPOUT) && gb.drop.p > 0.f;
@@ -134,26 +135,29 @@ __device__ __forceinline__ void body_nt(const Gemm16Batch& gb, const Gemm16Prob&
   if (P.res) {
     if (flags & GF_RES_BCAST) {
       int sb;
-      if (P.row_sample) { sb = P.row_sample[row]; rscale = P.inv_nr[sb]; }
-      else { sb = row / P.uniform_n; rscale = 1.0f / (float)P.uniform_n; }
+      if (P.row_sample) { sb = P.row_sample[rowc]; rscale = P.inv_nr[sb]; }
+      else { sb = rowc / P.uniform_n; rscale = 1.0f / (float)P.uniform_n; }
       rrow = P.res + (size_t)sb * P.ldr;
     } else {
-      rrow = P.res + (size_t)row * P.ldr;
+      rrow = P.res + (size_t)rowc * P.ldr;
     }
   }
-  float* crow = P.C ? P.C + (size_t)row * P.ldc : nullptr;
-  unsigned short* hrow = P.C16 ? P.C16 + (size_t)row * P.ldc16 : nullptr;
+  float* crow = P.C ? P.C + (size_t)rowc * P.ldc : nullptr;
+  unsigned short* hrow = P.C16 ? P.C16 + (size_t)rowc * P.ldc16 : nullptr;
+  const bool cm = P.colmean != nullptr;                       // block-uniform
+  constexpr int TP = 132;                                     // fp32 tile pitch: 16-byte row stores stay conflict-free
+  float* tile = reinterpret_cast<float*>(smem);               // 64 x 132 floats (the K loop is done with the LDS)
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int c0 = n0 + wc * 64 + j * 32 + 8 * g + 4 * h;
+      float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
       if (c0 < N) {
-        float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
         if (P.bias) { const float4 bv = *reinterpret_cast<const float4*>(P.bias + c0); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
         v.x = fmaxf(v.x, floor_); v.y = fmaxf(v.y, floor_); v.z = fmaxf(v.z, floor_); v.w = fmaxf(v.w, floor_);
         if (dodrop) {
-          const uint32_t idx = (uint32_t)row * (uint32_t)N + (uint32_t)c0;
+          const uint32_t idx = (uint32_t)rowc * (uint32_t)N + (uint32_t)c0;
           v.x *= drop_mult(gb.drop, P.drop_site, idx); v.y *= drop_mult(gb.drop, P.drop_site, idx + 1);
           v.z *= drop_mult(gb.drop, P.drop_site, idx + 2); v.w *= drop_mult(gb.drop, P.drop_site, idx + 3);
         }
@@ -166,10 +170,43 @@ __device__ __forceinline__ void body_nt(const Gemm16Batch& gb, const Gemm16Prob&
             v.x = fmaf(rv.x, rscale, v.x); v.y = fmaf(rv.y, rscale, v.y); v.z = fmaf(rv.z, rscale, v.z); v.w = fmaf(rv.w, rscale, v.w);
           }
         }
-        if (crow) *reinterpret_cast<float4*>(crow + c0) = v;
-        if (hrow) *reinterpret_cast<uint2*>(hrow + c0) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+        if (rok) {
+          if (crow) *reinterpret_cast<float4*>(crow + c0) = v;
+          if (hrow) *reinterpret_cast<uint2*>(hrow + c0) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+        }
       }
+      if (cm) *reinterpret_cast<float4*>(tile + (wr * 32 + l31) * TP + (c0 - n0)) = v;
     }
+  if (cm) {
+    // per-sample column means of the tile: the rows' sample ids go to LDS once; thread (column t, row half) walks 32
+    // rows of the fp32 tile, flushing whenever the sample changes (a 64-row tile rarely meets more than one
+    // boundary); the two halves meet in LDS when the whole tile is one sample -> one atomic per column per tile
+    int* srow = reinterpret_cast<int*>(tile + 64 * TP);
+    float* hsum = tile + 64 * TP + 64;
+    if (tid < 64) { const int rr = m0 + tid; srow[tid] = rr < M ? (P.row_sample ? P.row_sample[rr] : rr / P.uniform_n) : -1; }
+    __syncthreads();
+    const int t = tid & 127, half = tid >> 7, col = n0 + t;
+    const int s_first = srow[0];
+    const bool one = srow[63] == s_first || (srow[63] < 0 && srow[min(M - 1 - m0, 63)] == s_first);   // block-uniform
+    float sum = 0.f; int cur = -1;
+    for (int r = 0; r < 32; ++r) {
+      const int sm = srow[half * 32 + r];
+      if (sm < 0) break;
+      if (sm != cur) {
+        if (cur >= 0 && col < N) atomicAdd(P.colmean + (size_t)cur * P.ldm + col, sum * (P.row_sample ? P.inv_nr[cur] : 1.0f / (float)P.uniform_n));
+        sum = 0.f; cur = sm;
+      }
+      sum += tile[(half * 32 + r) * TP + t];
+    }
+    if (one) {
+      if (half == 1) hsum[t] = sum;
+      __syncthreads();
+      if (half == 0 && col < N && cur >= 0)
+        atomicAdd(P.colmean + (size_t)cur * P.ldm + col, (sum + hsum[t]) * (P.row_sample ? P.inv_nr[cur] : 1.0f / (float)P.uniform_n));
+    } else if (cur >= 0 && col < N) {
+      atomicAdd(P.colmean + (size_t)cur * P.ldm + col, sum * (P.row_sample ? P.inv_nr[cur] : 1.0f / (float)P.uniform_n));
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ TN
@@ -294,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const Gemm16Batch gb, in
   }
 }
 
+int dev_kmin() { static const int v = [] { const char* e = std::getenv("CAMO_DEV_TN16_KMIN"); const int x = e ? std::atoi(e) : 0; return x >= 2 ? x : 8; }(); return v; }
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -328,14 +366,14 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
       } else {
         if ((p.K % BK) || (p.N & 3) || (p.flags & (GF_ATOMIC | GF_SIGMOID)) || p.bias_grad) return (int)hipErrorInvalidValue;
         if ((p.C && (!al16(p.C) || (p.ldc & 3))) || (p.C16 && ((reinterpret_cast<uintptr_t>(p.C16) & 7) || (p.ldc16 & 3))) ||
-            (p.bias && !al16(p.bias)) || (p.res && (!al16(p.res) || (p.ldr & 3))))
+            (p.bias && !al16(p.bias)) || (p.res && (!al16(p.res) || (p.ldr & 3))) || (p.colmean && !p.row_sample && p.uniform_n < 1))
           return (int)hipErrorInvalidValue;
         p.kchunk = p.K; p.ksplit = 1;
       }
       p.tile_begin = total;
       total += tiles * p.ksplit;
     }
-    if (kcap_env || total >= 384 || kcap <= 4) break;
+    if (kcap_env || total >= 384 || kcap <= dev_kmin()) break;
   }
   static const int dev_pipe = [] { const char* e = std::getenv("CAMO_DEV_PIPE16"); return e ? std::atoi(e) : 0; }();
   const size_t lds = 2 * BUF_BYTES;

@@ -3,7 +3,10 @@
 #include "common.h"
 
 struct LnSeg { const float* U; float* Y; float* stats; const float* gamma; const float* beta; int rows;
-               unsigned short* Y16; /* optional bf16 copy of Y (bf16 schedule) */ };
+               unsigned short* Y16; /* optional bf16 copy of Y (bf16 schedule) */
+               /* optional fused mean pool: mean[sample(row)][c] += Y[row][c] * inv_n (atomics into a zeroed buffer);
+                  sample(row) = row_sample[row] (inv_n[sample]) or row / uniform_n when row_sample is null */
+               float* mean; const int* row_sample; const float* inv_n; int uniform_n; };
 struct LnBwdSeg { const float* U; const float* dY; const float* stats; const float* gamma; float* dU;
                   float* dgamma; float* dbeta; int rows;
                   unsigned short* dU16; /* optional bf16 copy of dU */ };
@@ -11,7 +14,8 @@ struct LnBwdSeg { const float* U; const float* dY; const float* stats; const flo
 struct SegMean { const float* X; int ld, C; const int* offs; int uniform_n; float* out; int ldo; };
 struct BcastSeg { const float* act; const float* v; int ldv; const int* row_sample; const float* inv_n;
                   int uniform_n; float* dst; int rows;
-                  unsigned short* dst16; /* when set the result is written as bf16 here INSTEAD of dst */ };
+                  unsigned short* dst16; /* when set the result is written as bf16 here INSTEAD of dst */
+                  const unsigned short* act16; /* when set the activation is read from this bf16 tensor instead of act */ };
 
 // One launch of small data-movement jobs in front of the bf16 schedule (misc.hip, prep_kernel):
 //   PREP_ZERO  : n bytes at dst := 0                                   (n, dst 16-byte multiples)

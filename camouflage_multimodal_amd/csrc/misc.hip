@@ -20,42 +20,99 @@ __global__ void rowmap_kernel(const int* __restrict__ offs, int* __restrict__ ro
 
 // ---------------------------------------------------------------- LayerNorm forward
 // y = (u - mean) * rstd * gamma + beta, eps 1e-5 (nn.LayerNorm default, fusion_model.py:49-50)
+// A wave owns LNF_R consecutive rows.  Optional fused mean pool (S.mean): the wave keeps per-lane column sums
+// of its rows' outputs, flushed with atomics when the sample changes; at the end the block's four partial sums
+// are combined in LDS when they belong to one sample (the usual case) -> H atomics per 16 rows.
+constexpr int LNF_R = 4;
+constexpr int LNF_W = 4;      // waves per block (8 waves or 8 rows per wave both measured slower)
 template <int HPL>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(LnSeg s0, LnSeg s1, int H, int nb0) {
+__global__ __launch_bounds__(64 * LNF_W) void ln_fwd_kernel(LnSeg s0, LnSeg s1, int H, int nb0) {
+  __shared__ float part[LNF_W][64 * HPL];
+  __shared__ int scur[LNF_W];
   const bool first = (int)blockIdx.x < nb0;
   const LnSeg& S = first ? s0 : s1;
-  const int row = ((first ? blockIdx.x : blockIdx.x - nb0) * 4) + (threadIdx.x >> 6);
-  if (row >= S.rows) return;
-  const int lane = threadIdx.x & 63;
-  const float* u = S.U + (size_t)row * H;
-  float x[HPL];
-  float sum = 0.f;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rbase = ((first ? blockIdx.x : blockIdx.x - nb0) * LNF_W + wave) * LNF_R;
+  const bool pool = S.mean != nullptr;
+  float gam[HPL], bet[HPL], cs[HPL];
 #pragma unroll
   for (int i = 0; i < HPL; ++i) {
     const int c = lane + 64 * i;
-    x[i] = c < H ? u[c] : 0.f;
-    sum += x[i];
+    gam[i] = c < H ? S.gamma[c] : 0.f; bet[i] = c < H ? S.beta[c] : 0.f; cs[i] = 0.f;
   }
-  const float mean = wave_sum(sum) / (float)H;
-  float sq = 0.f;
+  auto flush = [&](int sm) {
+    const float inv = S.row_sample ? S.inv_n[sm] : 1.0f / (float)S.uniform_n;
 #pragma unroll
-  for (int i = 0; i < HPL; ++i) {
-    const int c = lane + 64 * i;
-    const float d = c < H ? x[i] - mean : 0.f;
-    sq = fmaf(d, d, sq);
+    for (int i = 0; i < HPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < H) atomicAdd(S.mean + (size_t)sm * H + c, cs[i] * inv);
+      cs[i] = 0.f;
+    }
+  };
+  int cur = -1;
+  // all rows' loads first (independent), then the per-row reductions
+  float x[LNF_R][HPL];
+#pragma unroll
+  for (int r = 0; r < LNF_R; ++r) {
+    const int row = min(rbase + r, S.rows - 1);
+    const float* u = S.U + (size_t)row * H;
+#pragma unroll
+    for (int i = 0; i < HPL; ++i) { const int c = lane + 64 * i; x[r][i] = c < H ? u[c] : 0.f; }
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + 1e-5f);
-  float* y = S.Y + (size_t)row * H;
 #pragma unroll
-  for (int i = 0; i < HPL; ++i) {
-    const int c = lane + 64 * i;
-    if (c < H) {
-      const float v = (x[i] - mean) * rstd * S.gamma[c] + S.beta[c];
-      y[c] = v;
-      if (S.Y16) S.Y16[(size_t)row * H + c] = f2bf(v);
+  for (int r = 0; r < LNF_R; ++r) {
+    const int row = rbase + r;
+    if (row >= S.rows) break;                                // wave-uniform
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < HPL; ++i) sum += x[r][i];
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < HPL; ++i) {
+      const int c = lane + 64 * i;
+      const float d = c < H ? x[r][i] - mean : 0.f;
+      sq = fmaf(d, d, sq);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + 1e-5f);
+    if (pool) {
+      const int sm = S.row_sample ? S.row_sample[row] : row / S.uniform_n;
+      if (sm != cur) { if (cur >= 0) flush(cur); cur = sm; }
+    }
+    float* y = S.Y + (size_t)row * H;
+#pragma unroll
+    for (int i = 0; i < HPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < H) {
+        const float v = (x[r][i] - mean) * rstd * gam[i] + bet[i];
+        y[c] = v;
+        if (S.Y16) S.Y16[(size_t)row * H + c] = f2bf(v);
+        cs[i] += v;
+      }
+    }
+    if (lane == 0) { S.stats[2 * row] = mean; S.stats[2 * row + 1] = rstd; }
+  }
+  if (pool) {                                                // (block-uniform)
+#pragma unroll
+    for (int i = 0; i < HPL; ++i) part[wave][lane + 64 * i] = cs[i];
+    if (lane == 0) scur[wave] = cur;
+    __syncthreads();
+    const int c0_ = scur[0];
+    bool same = c0_ >= 0;
+#pragma unroll
+    for (int w = 1; w < LNF_W; ++w) same = same && (scur[w] == c0_ || scur[w] < 0);
+    if (same) {
+      const float inv = S.row_sample ? S.inv_n[c0_] : 1.0f / (float)S.uniform_n;
+      for (int c = threadIdx.x; c < H; c += 64 * LNF_W) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < LNF_W; ++w) v += part[w][c];
+        atomicAdd(S.mean + (size_t)c0_ * H + c, v * inv);
+      }
+    } else if (cur >= 0) {
+      flush(cur);
     }
   }
-  if (lane == 0) { S.stats[2 * row] = mean; S.stats[2 * row + 1] = rstd; }
 }
 
 // ---------------------------------------------------------------- LayerNorm backward
@@ -247,7 +304,13 @@ __global__ __launch_bounds__(256) void relu_bcast_bwd_kernel(BcastSeg s0, BcastS
   if (S.row_sample) { sb = S.row_sample[t]; inv = S.inv_n[sb]; } else { sb = t / S.uniform_n; inv = 1.0f / (float)S.uniform_n; }
   inv *= scale;
   if constexpr (W == 4) {
-    const float4 a = *reinterpret_cast<const float4*>(S.act + k);
+    float4 a;
+    if (S.act16) {                                             // bf16 activation: sign and zero survive the rounding
+      const uint2 r = *reinterpret_cast<const uint2*>(S.act16 + k);
+      a = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xFFFF0000u));
+    } else {
+      a = *reinterpret_cast<const float4*>(S.act + k);
+    }
     const float4 v = *reinterpret_cast<const float4*>(S.v + (size_t)sb * S.ldv + c);
     float4 o;
     o.x = a.x > 0.f ? v.x * inv : 0.f; o.y = a.y > 0.f ? v.y * inv : 0.f;
@@ -255,7 +318,7 @@ __global__ __launch_bounds__(256) void relu_bcast_bwd_kernel(BcastSeg s0, BcastS
     if (S.dst16) *reinterpret_cast<uint2*>(S.dst16 + k) = make_uint2(pack2(o.x, o.y), pack2(o.z, o.w));
     else *reinterpret_cast<float4*>(S.dst + k) = o;
   } else {
-    const float a = S.act[k];
+    const float a = S.act16 ? __uint_as_float((uint32_t)S.act16[k] << 16) : S.act[k];
     const float o = a > 0.f ? S.v[(size_t)sb * S.ldv + c] * inv : 0.f;
     if (S.dst16) S.dst16[k] = f2bf(o); else S.dst[k] = o;
   }
@@ -460,10 +523,11 @@ int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int B, int ma
 int ln_supported(int H) { return H >= 1 && H <= 1024; }
 
 int launch_ln_fwd(const LnSeg& s0, const LnSeg& s1, int H, hipStream_t stream) {
-  const int nb0 = (s0.rows + 3) / 4, nb1 = (s1.rows + 3) / 4;
+  const int rpb = LNF_W * LNF_R;
+  const int nb0 = (s0.rows + rpb - 1) / rpb, nb1 = (s1.rows + rpb - 1) / rpb;
   if (nb0 + nb1 == 0) return 0;
-  if (H <= 256) hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3(nb0 + nb1), dim3(256), 0, stream, s0, s1, H, nb0);
-  else          hipLaunchKernelGGL(ln_fwd_kernel<16>, dim3(nb0 + nb1), dim3(256), 0, stream, s0, s1, H, nb0);
+  if (H <= 256) hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3(nb0 + nb1), dim3(64 * LNF_W), 0, stream, s0, s1, H, nb0);
+  else          hipLaunchKernelGGL(ln_fwd_kernel<16>, dim3(nb0 + nb1), dim3(64 * LNF_W), 0, stream, s0, s1, H, nb0);
   return (int)hipGetLastError();
 }
 
@@ -504,7 +568,7 @@ int launch_relu_bcast_bwd(const BcastSeg& s0, const BcastSeg& s1, int C, float s
   if (n0 + n1 == 0) return 0;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool vec = (C & 3) == 0 && (s0.ldv & 3) == 0 && (s1.ldv & 3) == 0 && al16(s0.act) && al16(s0.v) && al16(s0.dst) &&
-                   al16(s1.act) && al16(s1.v) && al16(s1.dst) && al16(s0.dst16) && al16(s1.dst16);
+                   al16(s1.act) && al16(s1.v) && al16(s1.dst) && al16(s0.dst16) && al16(s1.dst16) && al16(s0.act16) && al16(s1.act16);
   if (vec) hipLaunchKernelGGL(relu_bcast_bwd_kernel<4>, dim3((unsigned)(((n0 + n1) / 4 + 255) / 256)), dim3(256), 0, stream, s0, s1, C, n0, scale);
   else     hipLaunchKernelGGL(relu_bcast_bwd_kernel<1>, dim3((unsigned)((n0 + n1 + 255) / 256)), dim3(256), 0, stream, s0, s1, C, n0, scale);
   return (int)hipGetLastError();
