@@ -14,8 +14,9 @@ reference has no RGB+D image encoder; one "image" is one sample = (RG node embed
 Nr drawn from the real 303..530 histogram, 13 KG category embeddings [13,128]); batch 16 per GPU,
 bf16 MFMA operands with fp32 accumulation/activations.  Weak scaling: 16 samples per GPU.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the grouped MFMA GEMM,
->= 98 % of the FLOPs) with HIP events recorded on its launch stream during the timed steps;
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the grouped MFMA GEMM --
+gemm16_kernel on bf16-resident operands in bf16 mode, gemm_grouped_kernel in f32 mode; >= 98 % of the
+FLOPs) with HIP events recorded on its launch stream during the timed steps;
 `cpu_baseline` times the CPU oracle (a numpy port of the reference path) on the same workload.
 """
 import argparse
@@ -178,16 +179,19 @@ def main():
         peak = PEAK_TFLOPS[args.precision]
         # HBM bytes of the same kernel from the PMC passes (profiles/summarize_pmc.py), per launch
         traffic, tnote = None, None
+        kname = "gemm16_kernel" if args.precision == "bf16" else "gemm_grouped_kernel"
         pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        pm = None
         if os.path.exists(pj):
             with open(pj) as f:
                 pm = json.load(f)
+        if pm is not None and pm.get("kernel") == kname:
             traffic = round(pm["hbm_bytes_per_launch"])
             tnote = {"hbm_bytes_per_step": round(pm["hbm_bytes_per_step"]), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                      "separate passes of this bench (profiles/pmc_traffic.json): " + pm["correction"]}
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_note": tnote,
-                "kernel": "gemm_grouped_kernel<%s>" % ("bf16" if args.precision == "bf16" else "f32"),
+                "kernel": kname + ("<bf16-resident operands>" if args.precision == "bf16" else "<f32>"),
                 "launches_per_step": round(n.value / k, 1),
                 "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
                 "kernel_ms_per_step": round(ms.value / k, 4),
