@@ -294,8 +294,12 @@ bool sched16_ok(const camo_dims_t& d, const float* const* P, int precision, int 
 // ---- the four heads (fusion_model.py:208-235), shared by both fusion types -------------------
 // The per-sample ("tail") GEMMs have M = B rows and a negligible FLOP share, so they always run
 // on the exact f32 MFMA; `precision` selects the MFMA type of the node-level (T-row) GEMMs only.
+// labels + outputs of the native training call: when given, the head output layer, the loss and the head output
+// layer's backward run as one kernel (misc.hip, heads_loss_kernel) instead of three launches
+struct FusedLoss { const int64_t* y; const float* e; const float* s; float* terms; int32_t* pred; float* const* head_grads; };
+
 int heads_forward(const camo_dims_t& d, const float* const* hp /*16 pointers*/, const Ws& w, int B, int F,
-                  float* outs, GB& g) {
+                  float* outs, GB& g, const FusedLoss* fl = nullptr) {
   const int Fh = F / 2, C = d.num_classes, Wd = 2 * C + 2;
   const int nout[4] = {C, C, 1, 1}, coff[4] = {0, C, 2 * C, 2 * C + 1};
   for (int x = 0; x < 4; ++x) {
@@ -303,6 +307,13 @@ int heads_forward(const camo_dims_t& d, const float* const* hp /*16 pointers*/, 
     set_drop(p, SITE_HEAD0 + x);
   }
   CK(g.run(), "heads hidden");
+  if (fl) {
+    HeadsOut ho;
+    for (int x = 0; x < 4; ++x) { ho.W[x] = hp[4 * x + 2]; ho.b[x] = hp[4 * x + 3]; ho.gW[x] = fl->head_grads[4 * x + 2]; ho.gb[x] = fl->head_grads[4 * x + 3]; }
+    CK(launch_heads_loss(w.hid, ho, reinterpret_cast<const long long*>(fl->y), fl->e, fl->s, B, C, Fh, g.b.drop.scale, outs, fl->terms,
+                         fl->pred, w.dhid, g.st), "heads out + loss + heads out bwd");
+    return 0;
+  }
   for (int x = 0; x < 4; ++x)
     g.nt(w.hid + x * Fh, 4 * Fh, hp[4 * x + 2], Fh, hp[4 * x + 3], outs + coff[x], Wd, B, nout[x], Fh, x == 3 ? GF_SIGMOID : 0);
   CK(g.run(), "heads out");
@@ -311,18 +322,21 @@ int heads_forward(const camo_dims_t& d, const float* const* hp /*16 pointers*/, 
 
 // d_outs -> dfused (w.dfused, zeroed here) and the 16 head-parameter gradients
 int heads_backward(const camo_dims_t& d, const float* const* hp, float* const* hg, const Ws& w, int B, int F,
-                   const float* outs, const float* d_outs, int pre_activation, const DropCfg& drop, hipStream_t st, GB& g) {
+                   const float* outs, const float* d_outs, int pre_activation, const DropCfg& drop, hipStream_t st, GB& g,
+                   bool heads_out_done = false) {
   const int Fh = F / 2, C = d.num_classes, Wd = 2 * C + 2;
   const int nout[4] = {C, C, 1, 1}, coff[4] = {0, C, 2 * C, 2 * C + 1};
   // (w.dfused was zeroed by the forward's memset of the workspace's zero block)
-  const float* dlog = d_outs;
-  if (!pre_activation) { CK(launch_head_out_grad(outs, d_outs, w.dlog, B, Wd, st), "head_out_grad"); dlog = w.dlog; }
-  for (int x = 0; x < 4; ++x) {
-    GemmProb& p = g.nn(dlog + coff[x], Wd, hp[4 * x + 2], Fh, w.dhid + x * Fh, 4 * Fh, B, Fh, nout[x]);
-    set_relu_bwd(p, w.hid + x * Fh, 4 * Fh, drop.scale);
-    g.tn(dlog + coff[x], Wd, w.hid + x * Fh, 4 * Fh, hg[4 * x + 2], Fh, hg[4 * x + 3], nout[x], Fh, B);
+  if (!heads_out_done) {      // else w.dhid and the output-layer gradients came out of heads_loss_kernel
+    const float* dlog = d_outs;
+    if (!pre_activation) { CK(launch_head_out_grad(outs, d_outs, w.dlog, B, Wd, st), "head_out_grad"); dlog = w.dlog; }
+    for (int x = 0; x < 4; ++x) {
+      GemmProb& p = g.nn(dlog + coff[x], Wd, hp[4 * x + 2], Fh, w.dhid + x * Fh, 4 * Fh, B, Fh, nout[x]);
+      set_relu_bwd(p, w.hid + x * Fh, 4 * Fh, drop.scale);
+      g.tn(dlog + coff[x], Wd, w.hid + x * Fh, 4 * Fh, hg[4 * x + 2], Fh, hg[4 * x + 3], nout[x], Fh, B);
+    }
+    CK(g.run(), "heads out bwd");
   }
-  CK(g.run(), "heads out bwd");
   for (int x = 0; x < 4; ++x) {
     g.nn(w.dhid + x * Fh, 4 * Fh, hp[4 * x], F, w.dfused, F, B, F, Fh, GF_ATOMIC);
     g.tn(w.dhid + x * Fh, 4 * Fh, w.fused, F, hg[4 * x], F, hg[4 * x + 1], Fh, F, B);
@@ -478,11 +492,11 @@ int camo_prepare_batch(const int32_t* rg_offsets, int32_t B, int32_t max_nr, int
   return 0;
 }
 
-int camo_forward(const camo_dims_t* dims, const float* const* params, const float* rg, const int32_t* rg_offsets,
-                 const int32_t* row_sample, const float* inv_nr,
-                 const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace,
-                 size_t workspace_bytes, float* outs, float* attn_rg2kg, float* attn_kg2rg, int32_t training,
-                 uint64_t seed, int32_t precision, void* stream) {
+static int forward_impl(const camo_dims_t* dims, const float* const* params, const float* rg, const int32_t* rg_offsets,
+                        const int32_t* row_sample, const float* inv_nr,
+                        const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace,
+                        size_t workspace_bytes, float* outs, float* attn_rg2kg, float* attn_kg2rg, int32_t training,
+                        uint64_t seed, int32_t precision, void* stream, const FusedLoss* fl) {
   if (int e = check_dims(dims, B, T, Nk)) return e;
   if (!params || !rg || !rg_offsets || !row_sample || !inv_nr || !kg || !workspace || !outs)
     return fail(CAMO_E_ARG, "null pointer argument");
@@ -513,7 +527,7 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
     CK(gt.run(), "late fc3");
     gt.nt(w.a2, F, P[CAMO_PL_W6], F, P[CAMO_PL_B6], w.fused, F, B, F, F);
     CK(gt.run(), "late fc6");
-    return heads_forward(d, P + CAMO_PL_HEADS, w, B, F, outs, gt);
+    return heads_forward(d, P + CAMO_PL_HEADS, w, B, F, outs, gt, fl);
   }
 
   // ---- CrossAttentionFusion.forward, fusion_model.py:75-146
@@ -599,18 +613,30 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
   CK(gt.run(), "fusion layer 0");
   gt.nt(w.F1, H, P[CAMO_P_FU_W3], H, P[CAMO_P_FU_B3], w.fused, H, B, H, H);
   CK(gt.run(), "fusion layer 3");
-  if (int e = heads_forward(d, P + CAMO_P_HEADS, w, B, H, outs, gt)) return e;
-  if (gt.plan) CK(launch_tail(tplan, st), "per-sample tail (persistent)");
+  if (int e = heads_forward(d, P + CAMO_P_HEADS, w, B, H, outs, gt, gt.plan ? nullptr : fl)) return e;
+  if (gt.plan) {
+    CK(launch_tail(tplan, st), "per-sample tail (persistent)");
+    if (fl) return fail(CAMO_E_UNSUPPORTED, "CAMO_TAIL_PERSIST=1 cannot be combined with the fused training call");
+  }
   return 0;
 }
 
-int camo_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
-                  const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr, const float* kg, int32_t B,
-                  int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes, const float* outs,
-                  const float* d_outs, int32_t d_outs_pre_activation, int32_t training, uint64_t seed, int32_t precision,
-                  void* stream) {
+int camo_forward(const camo_dims_t* dims, const float* const* params, const float* rg, const int32_t* rg_offsets,
+                 const int32_t* row_sample, const float* inv_nr,
+                 const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace,
+                 size_t workspace_bytes, float* outs, float* attn_rg2kg, float* attn_kg2rg, int32_t training,
+                 uint64_t seed, int32_t precision, void* stream) {
+  return forward_impl(dims, params, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
+                      attn_rg2kg, attn_kg2rg, training, seed, precision, stream, nullptr);
+}
+
+static int backward_impl(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
+                         const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr, const float* kg, int32_t B,
+                         int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes, const float* outs,
+                         const float* d_outs, int32_t d_outs_pre_activation, int32_t training, uint64_t seed, int32_t precision,
+                         void* stream, bool heads_out_done) {
   if (int e = check_dims(dims, B, T, Nk)) return e;
-  if (!params || !grads || !rg || !rg_offsets || !row_sample || !inv_nr || !kg || !workspace || !outs || !d_outs)
+  if (!params || !grads || !rg || !rg_offsets || !row_sample || !inv_nr || !kg || !workspace || !outs || (!d_outs && !heads_out_done))
     return fail(CAMO_E_ARG, "null pointer argument");
   if (max_nr < 1 || max_nr > T) return fail(CAMO_E_ARG, "max_nr out of range");
   if (precision != CAMO_PREC_F32 && precision != CAMO_PREC_BF16) return fail(CAMO_E_ARG, "unknown precision");
@@ -627,7 +653,7 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
 
   if (d.fusion_type == CAMO_FUSION_LATE) {
     const int F = H / 2, Dc = D + Dk;
-    if (int e = heads_backward(d, P + CAMO_PL_HEADS, Gr + CAMO_PL_HEADS, w, B, F, outs, d_outs, d_outs_pre_activation, drop, st, gt)) return e;
+    if (int e = heads_backward(d, P + CAMO_PL_HEADS, Gr + CAMO_PL_HEADS, w, B, F, outs, d_outs, d_outs_pre_activation, drop, st, gt, heads_out_done)) return e;
     set_relu_bwd(gt.nn(w.dfused, F, P[CAMO_PL_W6], F, w.da2, F, B, F, F), w.a2, F, drop.scale);
     gt.tn(w.dfused, F, w.a2, F, Gr[CAMO_PL_W6], F, Gr[CAMO_PL_B6], F, F, B);
     CK(gt.run(), "late fc6 bwd");
@@ -644,7 +670,7 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
   const float* G = has_kgp ? w.G : kg;
   TailPlan tplan;
   if (tail_persistent_ok(B)) tail_begin(tplan, gt, drop, w.sync + 4);
-  if (int e = heads_backward(d, P + CAMO_P_HEADS, Gr + CAMO_P_HEADS, w, B, H, outs, d_outs, d_outs_pre_activation, drop, st, gt)) return e;
+  if (int e = heads_backward(d, P + CAMO_P_HEADS, Gr + CAMO_P_HEADS, w, B, H, outs, d_outs, d_outs_pre_activation, drop, st, gt, heads_out_done)) return e;
   // fusion layer
   set_relu_bwd(gt.nn(w.dfused, H, P[CAMO_P_FU_W3], H, w.dF1, H, B, H, H), w.F1, H, drop.scale);
   gt.tn(w.dfused, H, w.F1, H, Gr[CAMO_P_FU_W3], H, Gr[CAMO_P_FU_B3], H, H, B);
@@ -701,6 +727,41 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
   if (has_kgp) g.tn(w.dG, H, kg, Dk, Gr[CAMO_P_KG_PROJ_W], Dk, Gr[CAMO_P_KG_PROJ_B], H, Dk, TK);
   CK(g.run(), "input projection bwd");
   return 0;
+}
+
+int camo_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
+                  const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr, const float* kg, int32_t B,
+                  int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes, const float* outs,
+                  const float* d_outs, int32_t d_outs_pre_activation, int32_t training, uint64_t seed, int32_t precision,
+                  void* stream) {
+  return backward_impl(dims, params, grads, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
+                       d_outs, d_outs_pre_activation, training, seed, precision, stream, false);
+}
+
+int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
+                               const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr, const float* kg,
+                               int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes,
+                               const int64_t* y, const float* e, const float* s, float* outs, float* loss_terms, int32_t* pred,
+                               int32_t training, uint64_t seed, int32_t precision, void* stream) {
+  if (!dims || !grads || !y || !e || !s || !outs || !loss_terms) return fail(CAMO_E_ARG, "null pointer argument");
+  const int head0 = dims->fusion_type == CAMO_FUSION_LATE ? CAMO_PL_HEADS : CAMO_P_HEADS;
+  const char* env = std::getenv("CAMO_TAIL_PERSIST");
+  const bool fuse = heads_loss_ok(B, dims->num_classes) && !(env && env[0] == '1');
+  if (fuse) {
+    const FusedLoss fl{y, e, s, loss_terms, pred, grads + head0};
+    if (int rc = forward_impl(dims, params, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
+                              nullptr, nullptr, training, seed, precision, stream, &fl)) return rc;
+    return backward_impl(dims, params, grads, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes,
+                         outs, nullptr, 1, training, seed, precision, stream, true);
+  }
+  // large batches / many classes: the three steps as separate launches, d(loss)/d(pre-activation) staged in the workspace
+  if (int rc = forward_impl(dims, params, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
+                            nullptr, nullptr, training, seed, precision, stream, nullptr)) return rc;
+  const Ws w = carve(*dims, B, T, Nk, workspace);
+  CK(launch_loss(outs, reinterpret_cast<const long long*>(y), e, s, B, dims->num_classes, loss_terms, nullptr, w.dlog, pred,
+                 static_cast<hipStream_t>(stream)), "loss");
+  return backward_impl(dims, params, grads, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes,
+                       outs, w.dlog, 1, training, seed, precision, stream, false);
 }
 
 int camo_loss(const float* outs, const int64_t* y, const float* e, const float* s, int32_t B, int32_t num_classes,

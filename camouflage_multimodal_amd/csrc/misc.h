@@ -36,6 +36,12 @@ int launch_relu_bcast_bwd(const BcastSeg& s0, const BcastSeg& s1, int C, float s
 int launch_head_out_grad(const float* outs, const float* d_outs, float* d_logits, int B, int W, hipStream_t stream);
 int launch_loss(const float* outs, const long long* y, const float* e, const float* s, int B, int C,
                 float* terms, float* d_outs, float* d_pre, int* pred, hipStream_t stream);
+// head output layer + loss + its backward in one kernel (native training call); needs heads_loss_ok(B, C)
+#define HEADS_MAXW 130   /* 2 * num_classes + 2 with num_classes <= 64 (check_dims) */
+struct HeadsOut { const float* W[4]; const float* b[4]; float* gW[4]; float* gb[4]; };
+int heads_loss_ok(int B, int C);
+int launch_heads_loss(const float* hid, const HeadsOut& hp, const long long* y, const float* e, const float* s, int B, int C,
+                      int Fh, float scale, float* outs, float* terms, int* pred, float* dhid, hipStream_t stream);
 int launch_sumsq(const float* g, size_t n, float* out, hipStream_t stream);
 int launch_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sumsq, float max_norm,
                       float lr, float b1, float b2, float eps, float wd, int step, int zero_grads, hipStream_t stream);

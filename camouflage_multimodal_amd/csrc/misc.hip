@@ -338,20 +338,16 @@ __global__ void head_out_grad_kernel(const float* __restrict__ outs, const float
 // ---------------------------------------------------------------- loss
 // per sample: 3*focal(mask,y) + CE(inst,y) + .5*BCEWithLogits(edge,e) + .3*MSE(score,s)
 // (train_multimodal.py:29-57, 256-268), each at batch size 1.
-__global__ void loss_kernel(const float* __restrict__ outs, const long long* __restrict__ y,
-                            const float* __restrict__ e, const float* __restrict__ s, int B, int C,
-                            float* __restrict__ terms, float* __restrict__ d_outs, float* __restrict__ d_pre,
-                            int* __restrict__ pred) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// o: the sample's 2C+2 outputs (score column post-sigmoid).  d_outs / d_pre rows may be null; they must not alias o.
+__device__ __forceinline__ void loss_sample(const float* __restrict__ o, int yb, float eb, float sb, int C,
+                                            float* __restrict__ terms4, float* __restrict__ d_outs, float* __restrict__ d_pre,
+                                            int* __restrict__ pred) {
   const int W = 2 * C + 2;
-  const float* o = outs + (size_t)b * W;
   const float sc = o[W - 1];
   auto put = [&](int k, float val) {        // gradient w.r.t. output k; d_pre: score column w.r.t. the pre-sigmoid value
-    if (d_outs) d_outs[(size_t)b * W + k] = val;
-    if (d_pre) d_pre[(size_t)b * W + k] = (k == W - 1) ? val * sc * (1.0f - sc) : val;
+    if (d_outs) d_outs[k] = val;
+    if (d_pre) d_pre[k] = (k == W - 1) ? val * sc * (1.0f - sc) : val;
   };
-  const int yb = (int)y[b];
   // focal on mask logits
   {
     float mx = -INFINITY; int am = 0;
@@ -362,13 +358,13 @@ __global__ void loss_kernel(const float* __restrict__ outs, const long long* __r
     const float ce = -logf(pt);
     const float at = yb == 1 ? 0.75f : 0.25f;
     const float om = 1.0f - pt;
-    terms[4 * b + 0] = 3.0f * at * om * om * om * ce;
+    terms4[0] = 3.0f * at * om * om * om * ce;
     const float dl_dpt = at * (-3.0f * om * om * ce - om * om * om / pt);
     for (int k = 0; k < C; ++k) {
       const float pk = expf(o[k] - mx) / z;
       put(k, 3.0f * dl_dpt * pt * ((k == yb ? 1.0f : 0.0f) - pk));
     }
-    if (pred) pred[b] = am;
+    if (pred) *pred = am;
   }
   // cross entropy on instance logits
   {
@@ -377,21 +373,74 @@ __global__ void loss_kernel(const float* __restrict__ outs, const long long* __r
     for (int k = 0; k < C; ++k) mx = fmaxf(mx, oi[k]);
     float z = 0.f;
     for (int k = 0; k < C; ++k) z += expf(oi[k] - mx);
-    terms[4 * b + 1] = -(oi[yb] - mx - logf(z));
+    terms4[1] = -(oi[yb] - mx - logf(z));
     for (int k = 0; k < C; ++k) put(C + k, expf(oi[k] - mx) / z - (k == yb ? 1.0f : 0.0f));
   }
   // BCE with logits on edge
   {
-    const float x = o[2 * C], t = e[b];
-    terms[4 * b + 2] = 0.5f * (fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))));
+    const float x = o[2 * C], t = eb;
+    terms4[2] = 0.5f * (fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))));
     put(2 * C, 0.5f * (1.0f / (1.0f + expf(-x)) - t));
   }
   // MSE on the (post-sigmoid) score
   {
-    const float x = o[2 * C + 1], t = s[b];
-    terms[4 * b + 3] = 0.3f * (x - t) * (x - t);
+    const float x = o[2 * C + 1], t = sb;
+    terms4[3] = 0.3f * (x - t) * (x - t);
     put(2 * C + 1, 0.6f * (x - t));
   }
+}
+
+__global__ void loss_kernel(const float* __restrict__ outs, const long long* __restrict__ y,
+                            const float* __restrict__ e, const float* __restrict__ s, int B, int C,
+                            float* __restrict__ terms, float* __restrict__ d_outs, float* __restrict__ d_pre,
+                            int* __restrict__ pred) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int W = 2 * C + 2;
+  loss_sample(outs + (size_t)b * W, (int)y[b], e[b], s[b], C, terms + 4 * b, d_outs ? d_outs + (size_t)b * W : nullptr,
+              d_pre ? d_pre + (size_t)b * W : nullptr, pred ? pred + b : nullptr);
+}
+
+// ---------------------------------------------------------------- head output layer + loss + its backward
+// The last forward launch (four [B, Fh] x [nout, Fh]^T products, nout in {C, C, 1, 1}), the loss and the first
+// backward launch (d hidden = (d logits . W) * relu/dropout mask, dW = d logits^T . hidden, db) are 100 kFLOP in
+// all; as three launches they cost three launch floors.  One block per sample, wave x owns head x; only the
+// output-layer weight gradients cross samples (atomics).
+__global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict__ hid, HeadsOut hp,
+                                                         const long long* __restrict__ y, const float* __restrict__ e,
+                                                         const float* __restrict__ s, int C, int Fh, float scale,
+                                                         float* __restrict__ outs, float* __restrict__ terms,
+                                                         int* __restrict__ pred, float* __restrict__ dhid) {
+  __shared__ float so[HEADS_MAXW], sd[HEADS_MAXW];
+  const int b = blockIdx.x, x = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int W = 2 * C + 2, nout = x < 2 ? C : 1, coff = x == 0 ? 0 : (x == 1 ? C : (x == 2 ? 2 * C : 2 * C + 1));
+  const float* Wx = hp.W[x];
+  const float* h = hid + (size_t)b * 4 * Fh + x * Fh;
+  for (int o = 0; o < nout; ++o) {
+    float acc = 0.f;
+    for (int c = lane; c < Fh; c += 64) acc = fmaf(h[c], Wx[(size_t)o * Fh + c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float v = acc + hp.b[x][o];
+      if (x == 3) v = 1.0f / (1.0f + __expf(-v));
+      so[coff + o] = v;
+      outs[(size_t)b * W + coff + o] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) loss_sample(so, (int)y[b], e[b], s[b], C, terms + 4 * b, nullptr, sd, pred ? pred + b : nullptr);
+  __syncthreads();
+  for (int c = lane; c < Fh; c += 64) {
+    const float hv = h[c];
+    float dh = 0.f;
+    for (int o = 0; o < nout; ++o) {
+      const float d = sd[coff + o];
+      dh = fmaf(d, Wx[(size_t)o * Fh + c], dh);
+      atomicAdd(hp.gW[x] + (size_t)o * Fh + c, d * hv);
+    }
+    dhid[(size_t)b * 4 * Fh + x * Fh + c] = hv > 0.f ? dh * scale : 0.f;
+  }
+  if (lane < nout) atomicAdd(hp.gb[x] + lane, sd[coff + lane]);
 }
 
 // ---------------------------------------------------------------- optimizer
@@ -582,6 +631,14 @@ int launch_head_out_grad(const float* outs, const float* d_outs, float* d_logits
 int launch_loss(const float* outs, const long long* y, const float* e, const float* s, int B, int C,
                 float* terms, float* d_outs, float* d_pre, int* pred, hipStream_t stream) {
   hipLaunchKernelGGL(loss_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, outs, y, e, s, B, C, terms, d_outs, d_pre, pred);
+  return (int)hipGetLastError();
+}
+
+int heads_loss_ok(int B, int C) { return B >= 1 && C >= 1 && 2 * C + 2 <= HEADS_MAXW; }
+int launch_heads_loss(const float* hid, const HeadsOut& hp, const long long* y, const float* e, const float* s, int B, int C,
+                      int Fh, float scale, float* outs, float* terms, int* pred, float* dhid, hipStream_t stream) {
+  if (!heads_loss_ok(B, C)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(heads_loss_kernel, dim3(B), dim3(256), 0, stream, hid, hp, y, e, s, C, Fh, scale, outs, terms, pred, dhid);
   return (int)hipGetLastError();
 }
 

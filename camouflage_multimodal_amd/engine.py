@@ -203,6 +203,24 @@ class FusionEngine:
                                       _stream_ptr())
         _lib.check(rc, "camo_backward")
 
+    def train_raw(self, batch, ws, mask_label, edge_label, score_label, training, seed, gtab):
+        """The native training call (camo_forward_loss_backward): forward, the reference's 4-term loss and backward into
+        the flat gradient buffer in one library call.  Returns (outs [B, 2C+2], loss_terms [B, 4], pred int32 [B])."""
+        mod = self.module()
+        dev = batch.rg.device
+        y = mask_label.to(device=dev, dtype=torch.int64).contiguous()
+        e = edge_label.to(device=dev, dtype=torch.float32).contiguous()
+        s = score_label.to(device=dev, dtype=torch.float32).contiguous()
+        outs = torch.empty(batch.B, self.out_width, dtype=torch.float32, device=dev)
+        terms = torch.empty(batch.B, 4, dtype=torch.float32, device=dev)
+        pred = torch.empty(batch.B, dtype=torch.int32, device=dev)
+        rc = _lib.lib().camo_forward_loss_backward(
+            C.byref(self.dims), self._ptab, gtab, _ptr(batch.rg), _ptr(batch.offsets), _ptr(batch.row_sample), _ptr(batch.inv_nr),
+            _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(y), _ptr(e), _ptr(s),
+            _ptr(outs), _ptr(terms), _ptr(pred), int(bool(training)), seed, _PREC[mod.precision], _stream_ptr())
+        _lib.check(rc, "camo_forward_loss_backward")
+        return outs, terms, pred
+
     # ------------------------------------------------------------------ autograd (drop-in) mode
     def forward_autograd(self, rg_packed, nrs, kg, want_attention=False):
         mod = self.module()

@@ -61,12 +61,13 @@ def pack_samples(batch, device):
 class NativeTrainer:
     """One optimizer step = one packed minibatch through the HIP path."""
 
-    def __init__(self, model, lr=5e-4, weight_decay=1e-4, max_norm=1.0, grad_allreduce=None, keep_grads=False):
+    def __init__(self, model, lr=5e-4, weight_decay=1e-4, max_norm=1.0, grad_allreduce=None, keep_grads=False, fused_call=True):
         """``keep_grads``: leave the clipped gradients in ``param.grad`` after the step, as the reference's
         clip_grad_norm_ does (costs one extra clearing pass per step); by default the optimizer kernel
         clears the gradient buffer itself, which is the reference's per-minibatch ``zero_grad()`` [:239]
         moved to the end of the previous step."""
         self.keep_grads = keep_grads
+        self.fused_call = fused_call      # one camo_forward_loss_backward instead of forward / loss / backward calls
         self.model = model
         self.engine = model._engine
         self.opt = FusedClipAdamW(model, lr=lr, weight_decay=weight_decay, max_norm=max_norm)
@@ -81,12 +82,15 @@ class NativeTrainer:
         ws = eng.workspace(batch)
         seed = eng.next_seed() if seed is None else seed
         training = self.model.training
-        outs, _ = eng.forward_raw(batch, ws, training, seed)
-        terms, d_pre, pred = multitask_loss(outs, mask_label, edge_label, score_label, self.num_classes, pre_activation=True)
         g = eng.ensure_flat_grads(attach=False)
         if self.keep_grads or not self._grads_clean:
             g.zero_()                                       # optimizer.zero_grad() per minibatch [:239]
-        eng.backward_raw(batch, ws, outs, d_pre, training, seed, eng._gtab, pre_activation=True)
+        if self.fused_call:
+            _, terms, pred = eng.train_raw(batch, ws, mask_label, edge_label, score_label, training, seed, eng._gtab)
+        else:
+            outs, _ = eng.forward_raw(batch, ws, training, seed)
+            terms, d_pre, pred = multitask_loss(outs, mask_label, edge_label, score_label, self.num_classes, pre_activation=True)
+            eng.backward_raw(batch, ws, outs, d_pre, training, seed, eng._gtab, pre_activation=True)
         self.opt.step(allreduce=self.grad_allreduce, zero_grads=not self.keep_grads)
         self._grads_clean = not self.keep_grads
         return terms, pred

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CAMO_ABI_VERSION 2
+#define CAMO_ABI_VERSION 3
 
 enum {
   CAMO_OK = 0,
@@ -158,6 +158,18 @@ int camo_grad_sumsq(const float* g, size_t n, float* sumsq, void* stream);
 int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sumsq,
                     float max_norm, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int32_t step, int32_t zero_grads, void* stream);
+
+/* camo_forward_loss_backward: the native training call = camo_forward (training / seed / precision as there),
+ * camo_loss on its outputs with the labels y [B] (int64), e [B], s [B], and camo_backward on the loss gradient:
+ * same results, fewer launches (the head output layer, the loss and that layer's backward run as one kernel).
+ * Writes outs [B, 2C+2], loss_terms [B, 4], pred [B] (may be null) and ACCUMULATES into grads like
+ * camo_backward.  Stands behind the body of the per-minibatch loop of train_epoch_fixed
+ * (train_multimodal.py:245-270) for one packed minibatch. */
+int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
+                               const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr, const float* kg,
+                               int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes,
+                               const int64_t* y, const float* e, const float* s, float* outs, float* loss_terms, int32_t* pred,
+                               int32_t training, uint64_t seed, int32_t precision, void* stream);
 
 /* ---- testing hooks ---------------------------------------------------------
  * Not part of the operator surface; used by tests/ to check kernels in isolation.

@@ -398,3 +398,28 @@ def test_bf16_resident_schedule_matches_fp32_operand_schedule(training, kg_real,
         assert float(np.abs(a - b).mean()) <= 5e-5 * scale, f"{k}: mean diff {np.abs(a - b).mean():.3e} (scale {scale:.3e})"
     worst.sort(reverse=True)
     print("sched16 vs general, worst relative max-diffs:", [(f"{e:.2e}", k) for e, k in worst[:5]])
+
+
+@pytest.mark.parametrize("name,precision", [("default", "bf16"), ("default", "f32"), ("small_cls3", "f32"), ("late", "f32")])
+def test_fused_training_call_matches_forward_loss_backward(name, precision):
+    """camo_forward_loss_backward (head output layer + loss + its backward in one kernel) against the three separate
+    calls: same loss terms, predictions and gradients up to fp32 summation order."""
+    from camouflage_multimodal_amd import NativeTrainer
+    cfg, seed, nrs, nk, kg_fixed, _ = train_case(name)
+    rg, kg, y, e, s = train_batch(cfg, seed, nrs, nk, kg_fixed, 0)
+    res = []
+    for fused in (True, False):
+        m = make_model(cfg, seed, precision).train()
+        tr = NativeTrainer(m, keep_grads=True, fused_call=fused)
+        terms, pred = tr.step(torch.from_numpy(np.concatenate(rg)).cuda(), list(nrs), torch.from_numpy(kg).cuda(),
+                              torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s), seed=1234)
+        tr.engine.ensure_flat_grads(attach=True)
+        res.append((t2n(terms), t2n(pred), {k: t2n(p.grad).copy() for k, p in m.named_parameters()}, t2n(tr.opt.grad_norm())))
+    (ta, pa, ga, na), (tb, pb, gb, nb) = res
+    assert_close(ta, tb, 1e-6, 1e-5, "loss terms")
+    assert np.array_equal(pa, pb)
+    assert_close(na, nb, 0, 1e-4, "grad norm")
+    for k in ga:
+        scale = max(float(np.abs(gb[k]).max()), 1e-8)
+        tol = (4e-3 if precision == "bf16" else 2e-5) * scale      # bf16: a 1-ulp fp32 change upstream can flip a bf16 rounding
+        assert float(np.abs(ga[k] - gb[k]).max()) <= tol, k
