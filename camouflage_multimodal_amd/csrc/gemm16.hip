@@ -6,8 +6,10 @@
 // masks and no conversions inside the K loop), double-buffered LDS, one barrier per K step.
 //
 // LDS images (bank rules: MI355X_MICROARCH.md, LDS):
-//   NT  : both operands k-contiguous.  [row][64 k] bf16 with a 144-byte pitch (128 + 16): the sixteen rows of
-//         a ds_read_b128 lane group start 144*r bytes apart = sixteen distinct 16-byte bank quads.
+//   NT  : both operands k-contiguous.  [row][64 k] bf16, dense 128-byte rows whose eight 16-byte chunks are
+//         XOR-swizzled by (row >> 1) & 7: the sixteen rows of a ds_read_b128 lane group ({0-3,12-15,20-27}, ...)
+//         then cover sixteen distinct 16-byte bank quads, a row's eight chunks still fill one 128-byte line for
+//         the stores, and two stages are 48 KB -- three blocks per CU for the forward (NT-only) launches.
 //   TN  : both operands are stored [k][m] / [k][n] (the contraction runs over ROWS of dy and x).  The tile is
 //         written as it is read from HBM, [k row][m] with pitch 192 B (A, 64 m) / 320 B (B, 128 n), and the
 //         MFMA fragments (8 consecutive k per lane) come out of ds_read_b64_tr_b16, the hardware transposing
@@ -23,11 +25,12 @@
 namespace {
 
 constexpr int BM = 64, BN = 128, BK = 64;
-constexpr int PM = 144;                 // row pitch (bytes) of a k-contiguous image
+constexpr int PM = 128;                 // row pitch (bytes) of a k-contiguous image: dense rows, chunks XOR-swizzled
 constexpr int PKA = 192, PKB = 320;     // k-row pitch (bytes) of the k-major images
-constexpr int A_NT_BYTES = BM * PM;     // 9216
+constexpr int A_NT_BYTES = BM * PM;     // 8192
 constexpr int A_TN_BYTES = BK * PKA;    // 12288
-constexpr int BUF_BYTES = 32768;        // >= 9216 + 128*144 = 27648 (NT), = 12288 + 64*320 (TN)
+constexpr int NT_BUF_BYTES = (BM + BN) * PM;   // 24576: two stages = 48 KB, three blocks per CU
+constexpr int BUF_BYTES = 32768;        // TN stage: 12288 + 64*320
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -73,13 +76,13 @@ __device__ __forceinline__ void body_nt(const Gemm16Batch& gb, const Gemm16Prob&
   for (int i = 0; i < 2; ++i) {
     const int s = tid + 256 * i, row = s >> 3, c = s & 7;
     goa[i] = ((uint32_t)min(m0 + row, M - 1) * (uint32_t)P.lda + 8u * c) * 2u;
-    la[i] = row * PM + 16 * c;
+    la[i] = row * PM + 16 * (c ^ ((row >> 1) & 7));
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int s = tid + 256 * i, row = s >> 3, c = s & 7;
     gob[i] = ((uint32_t)min(n0 + row, N - 1) * (uint32_t)P.ldb + 8u * c) * 2u;
-    lb[i] = A_NT_BYTES + row * PM + 16 * c;
+    lb[i] = A_NT_BYTES + row * PM + 16 * (c ^ ((row >> 1) & 7));
   }
   const char* Ab = reinterpret_cast<const char*>(P.A);
   const char* Bb = reinterpret_cast<const char*>(P.B);
@@ -101,22 +104,28 @@ __device__ __forceinline__ void body_nt(const Gemm16Batch& gb, const Gemm16Prob&
     for (int i = 0; i < 4; ++i) r.b[i] = *reinterpret_cast<const u32x4*>(b + gob[i]);
   };
   auto sstore = [&](const Stage& r, int buf) {
-    char* base = smem + buf * BUF_BYTES;
+    char* base = smem + buf * NT_BUF_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(base + la[i]) = r.a[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(base + lb[i]) = r.b[i];
   };
-  // lane (l31, h) of MFMA step s holds k = 16 s + 8 h .. + 7 of its row: byte 32 s + 16 h
-  const int fa = (wr * 32 + l31) * PM + 16 * h;
-  const int fb = A_NT_BYTES + (wc * 64 + l31) * PM + 16 * h;
-  auto compute = [&](int buf) {
-    const char* base = smem + buf * BUF_BYTES;
+  // lane (l31, h) of MFMA step s holds k = 16 s + 8 h .. + 7 of its row: logical chunk 2 s + h, swizzled by the row
+  // (rows r and r + 32 share the swizzle, so the second B fragment is a fixed 32 rows further)
+  const int ra = wr * 32 + l31, rb = wc * 64 + l31;
+  int fa[4], fb[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(base + fa + 32 * s);
-      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(base + fb + 32 * s);
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(base + fb + 32 * PM + 32 * s);
+  for (int s_ = 0; s_ < 4; ++s_) {
+    fa[s_] = ra * PM + 16 * ((2 * s_ + h) ^ ((ra >> 1) & 7));
+    fb[s_] = A_NT_BYTES + rb * PM + 16 * ((2 * s_ + h) ^ ((rb >> 1) & 7));
+  }
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * NT_BUF_BYTES;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(base + fa[s_]);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(base + fb[s_]);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(base + fb[s_] + 32 * PM);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, acc[0], 0, 0, 0);   // C^T
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[1], 0, 0, 0);
     }
@@ -306,7 +315,7 @@ __device__ __forceinline__ void body_tn(const Gemm16Prob& P, int m0, int n0, int
 }
 
 template <int PIPE>
-__global__ __launch_bounds__(256, 2) void gemm16_kernel(const Gemm16Batch gb, int total_tiles) {
+__global__ __launch_bounds__(256, 3) void gemm16_kernel(const Gemm16Batch gb, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // XCD-aware block remap (bijective): blocks that share an XCD (bid % 8) take a contiguous run of tiles
   int bid = blockIdx.x;
@@ -375,20 +384,19 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
     }
     if (kcap_env || total >= 384 || kcap <= dev_kmin()) break;
   }
-  static const int dev_pipe = [] { const char* e = std::getenv("CAMO_DEV_PIPE16"); return e ? std::atoi(e) : 0; }();
-  const size_t lds = 2 * BUF_BYTES;
+  bool has_tn = false;
+  for (int i = 0; i < gb.n; ++i) has_tn = has_tn || (gb.p[i].flags & GF_A_KMAJOR);
+  const size_t lds = has_tn ? 2 * BUF_BYTES : 2 * NT_BUF_BYTES;     // 64 KB / 48 KB
   static const bool attr_ok = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
     return true;
   }();
   (void)attr_ok;
-  const int pipe = dev_pipe ? dev_pipe : 2;     // (4 register stages measured slower on every launch of the step)
   double fl = 0.0;
   for (int i = 0; i < gb.n; ++i) fl += 2.0 * gb.p[i].M * (double)gb.p[i].N * gb.p[i].K;
   const int prof = gemm_prof_open(stream, fl);
-  if (pipe == 4) hipLaunchKernelGGL(gemm16_kernel<4>, dim3(total), dim3(256), lds, stream, gb, total);
-  else           hipLaunchKernelGGL(gemm16_kernel<2>, dim3(total), dim3(256), lds, stream, gb, total);
+  // two register stages (four measured slower on every launch of the step)
+  hipLaunchKernelGGL(gemm16_kernel<2>, dim3(total), dim3(256), lds, stream, gb, total);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
