@@ -198,6 +198,9 @@ def main():
                 "algorithmic_gflop_per_step": round(alg / k / 1e9, 3),
                 "executed_gflop_per_step": round(fl.value / k / 1e9, 3),
                 "share_of_step_time": round(gemm_s / t_prof, 3)}
+        if traffic:      # the same launches seen from the other roof: measured HBM bytes / launch time vs 8 TB/s
+            gbps = traffic / (ms.value * 1e-3 / max(n.value, 1)) / 1e9
+            roof["hbm_view"] = {"achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
     if world > 1:
         dist.barrier()
 

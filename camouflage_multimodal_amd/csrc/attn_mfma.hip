@@ -628,10 +628,9 @@ union PairLds {
 __global__ __launch_bounds__(64 * NW) void attn_fwd_pair_kernel(
     const float* __restrict__ Q, const float* __restrict__ KV, const float* __restrict__ Q2, const float* __restrict__ KV2,
     const int* __restrict__ offs, float* __restrict__ P, float* __restrict__ P2, float* __restrict__ O, float* __restrict__ O2,
-    Bf16Dst o16, Bf16Dst o2_16, int H, int nh, int Nk, int B, int nbx, float scale, DropCfg drop, int dev) {
+    Bf16Dst o16, Bf16Dst o2_16, int H, int nh, int Nk, int B, int nbx, float scale, DropCfg drop) {
   __shared__ PairLds lds;
   const int bid = blockIdx.x;
-  if ((dev == 1 && bid >= nh * B) || (dev == 2 && bid < nh * B)) return;
   if (bid < nh * B) {
     kg2rg_fwd_body(Q2, KV2, offs, P2, O2, o2_16, H, nh, Nk, scale, drop, bid % nh, bid / nh, lds.k.red, lds.k.ored);
   } else {
@@ -644,10 +643,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_pair_kernel(
     const float* __restrict__ Q, const float* __restrict__ KV, const float* __restrict__ P, const float* __restrict__ dO,
     const float* __restrict__ Q2, const float* __restrict__ KV2, const float* __restrict__ P2, const float* __restrict__ dO2,
     const int* __restrict__ offs, Bf16Dst dq16, Bf16Dst dkv16, Bf16Dst dq2_16, Bf16Dst dkv2_16,
-    int H, int nh, int Nk, int B, float scale, DropCfg drop, int dev) {
+    int H, int nh, int Nk, int B, float scale, DropCfg drop) {
   __shared__ PairLds lds;
   const int bid = blockIdx.x;
-  if ((dev == 1 && bid >= nh * B) || (dev == 2 && bid < nh * B)) return;
   if (bid < nh * B) {
     kg2rg_bwd_body(Q2, KV2, P2, dO2, offs, nullptr, nullptr, dq2_16, dkv2_16, nullptr, Bf16Dst{nullptr, 0}, H, nh, Nk, scale, drop,
                    bid % nh, bid / nh, lds.k.red, lds.k.ored);
@@ -659,14 +657,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_pair_kernel(
 
 }  // namespace
 
-static int dev_pair() { static const int v = [] { const char* e = std::getenv("CAMO_DEV_PAIR"); return e ? std::atoi(e) : 0; }(); return v; }
-
 int launch_attn_fwd_pair(const float* Q, const float* KV, const float* Q2, const float* KV2, const int* offs, float* P,
                          float* P2, Bf16Dst o16, Bf16Dst o2_16, int B, int max_nr, int H, int nh, int Nk, DropCfg drop,
                          hipStream_t stream) {
   const int tasks = ((max_nr + 15) / 16) * nh, nbx = (tasks + NW - 1) / NW;
   hipLaunchKernelGGL(attn_fwd_pair_kernel, dim3(nh * B + nbx * B), dim3(64 * NW), 0, stream, Q, KV, Q2, KV2, offs, P, P2,
-                     (float*)nullptr, (float*)nullptr, o16, o2_16, H, nh, Nk, B, nbx, 1.0f / sqrtf((float)DH), drop, dev_pair());
+                     (float*)nullptr, (float*)nullptr, o16, o2_16, H, nh, Nk, B, nbx, 1.0f / sqrtf((float)DH), drop);
   return (int)hipGetLastError();
 }
 
@@ -674,7 +670,7 @@ int launch_attn_bwd_pair(const float* Q, const float* KV, const float* P, const 
                          const float* P2, const float* dO2, const int* offs, Bf16Dst dq16, Bf16Dst dkv16, Bf16Dst dq2_16,
                          Bf16Dst dkv2_16, int B, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
   hipLaunchKernelGGL(attn_bwd_pair_kernel, dim3(2 * nh * B), dim3(64 * NW), 0, stream, Q, KV, P, dO, Q2, KV2, P2, dO2, offs,
-                     dq16, dkv16, dq2_16, dkv2_16, H, nh, Nk, B, 1.0f / sqrtf((float)DH), drop, dev_pair());
+                     dq16, dkv16, dq2_16, dkv2_16, H, nh, Nk, B, 1.0f / sqrtf((float)DH), drop);
   return (int)hipGetLastError();
 }
 

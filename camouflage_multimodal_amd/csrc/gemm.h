@@ -38,7 +38,6 @@ struct GemmBatch {
   GemmProb p[GEMM_MAXP];
   int n;
   DropCfg drop;
-  int dev;   // developer experiments (CAMO_DEV_EPI), 0 in production
 };
 
 // The per-sample tail as one persistent launch (gemm.hip, tail_persistent_kernel): up to TAIL_MAXPH dependent

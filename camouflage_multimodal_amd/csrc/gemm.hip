@@ -404,11 +404,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmBatch& gb, const GemmPr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rowb + (r & 3) + 8 * (r >> 2);
-          if (row < M) {
-            if (gb.dev == 0) atomicAdd(cp + (size_t)row * P.ldc, acc[j][r] + bv);
-            else if (gb.dev == 1) cp[(size_t)row * P.ldc] = acc[j][r] + bv;
-            else if (acc[j][r] == 12345.678f) cp[(size_t)row * P.ldc] = acc[j][r] + bv;
-          }
+          if (row < M) atomicAdd(cp + (size_t)row * P.ldc, acc[j][r] + bv);
         }
       } else {
 #pragma unroll 4
@@ -557,7 +553,7 @@ __device__ __forceinline__ void skinny_tile_body(const GemmProb& P, const DropCf
   const int m0 = tm * 16, n0 = tn * 16;
   const bool live = m0 < M;               // (only the a-wave-per-tile mode can run past the last tile)
   float bsum = 0.f;
-  if (live && !(P.flags & (1 << 20))) {
+  if (live) {
     const int nkb = (K + 15) >> 4;
     auto lda_ = [&](int kb) { const int k = kb * 16 + 4 * q; if constexpr (akm) return raw_ks(oa, m0 + x, k); else return raw_mm<VEC>(oa, m0 + x, k); };
     auto ldb_ = [&](int kb) { const int k = kb * 16 + 4 * q; if constexpr (bkm) return raw_ks(ob, n0 + x, k); else return raw_mm<VEC>(ob, n0 + x, k); };
@@ -755,14 +751,9 @@ void gemm_prof_close(int slot, hipStream_t stream) {
 
 static int launch_skinny(GemmBatch& gb, hipStream_t stream) {
   int total = 0;
-  // launches made only of C = x.W^T problems with a long K (the forward tail): 8 waves split K further
-  // (16-wave blocks measured 17 us against 8-13 us with 4 waves)
-  static const int dev_nw = [] { const char* e = std::getenv("CAMO_DEV_SKINNY_NW"); return e ? std::atoi(e) : 0; }();
-  static const bool dev_nok = [] { const char* e = std::getenv("CAMO_DEV_SKINNY_NOK"); return e && e[0] == '1'; }();
-  if (dev_nok) for (int i = 0; i < gb.n; ++i) gb.p[i].flags |= (1 << 20);      // timing experiment: skip the K loop
-  bool wide = dev_nw == 8;
-  for (int i = 0; i < gb.n; ++i) wide = wide && !(gb.p[i].flags & GF_A_KMAJOR) && gb.p[i].K >= 256;
-  const int nw = wide ? 8 : 4;
+  // (4 waves per block: 8- and 16-wave blocks for the long-K forward problems measured slower; with its K loop
+  // removed a launch still takes 4.7 us -- the floor these launches sit on)
+  const int nw = 4;
   for (int i = 0; i < gb.n; ++i) {
     GemmProb& p = gb.p[i];
     p.tiles_n = (p.N + 15) / 16;
@@ -772,8 +763,7 @@ static int launch_skinny(GemmBatch& gb, hipStream_t stream) {
     total += (p.flags & GF_A_KMAJOR) ? (tiles + nw - 1) / nw : tiles;
   }
   if (total == 0) return 0;
-  if (wide) hipLaunchKernelGGL(gemm_skinny_kernel<8>, dim3(total), dim3(512), 0, stream, gb);
-  else      hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(total), dim3(256), 0, stream, gb);
+  hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(total), dim3(256), 0, stream, gb);
   return (int)hipGetLastError();
 }
 
@@ -823,8 +813,6 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
   }
   // (developer knob for sweeps: K tiles per split-K block of a weight-gradient problem)
   static const int kcap = [] { const char* e = std::getenv("CAMO_DEV_TN_KCAP"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 12; }();
-  static const int dev_epi = [] { const char* e = std::getenv("CAMO_DEV_EPI"); return e ? std::atoi(e) : 0; }();
-  gb.dev = dev_epi;
   // tiles without split-K
   for (int i = 0; i < gb.n; ++i) {
     GemmProb& p = gb.p[i];
@@ -862,10 +850,7 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
     if (deep) hipLaunchKernelGGL((gemm_grouped_kernel<0, 4>), dim3(total), dim3(256), lds, stream, gb, total);
     else      hipLaunchKernelGGL((gemm_grouped_kernel<0, 2>), dim3(total), dim3(256), lds, stream, gb, total);
   } else {
-    static const int dev_pipe = [] { const char* e = std::getenv("CAMO_DEV_PIPE"); return e ? std::atoi(e) : 0; }();
-    if (deep && dev_pipe == 8) hipLaunchKernelGGL((gemm_grouped_kernel<1, 8>), dim3(total), dim3(256), lds, stream, gb, total);
-    else if (deep && dev_pipe == 6) hipLaunchKernelGGL((gemm_grouped_kernel<1, 6>), dim3(total), dim3(256), lds, stream, gb, total);
-    else if (deep) hipLaunchKernelGGL((gemm_grouped_kernel<1, 4>), dim3(total), dim3(256), lds, stream, gb, total);
+    if (deep) hipLaunchKernelGGL((gemm_grouped_kernel<1, 4>), dim3(total), dim3(256), lds, stream, gb, total);
     else      hipLaunchKernelGGL((gemm_grouped_kernel<1, 2>), dim3(total), dim3(256), lds, stream, gb, total);
   }
   gemm_prof_close(prof, stream);

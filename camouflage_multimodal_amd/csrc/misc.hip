@@ -582,9 +582,7 @@ int launch_ln_fwd(const LnSeg& s0, const LnSeg& s1, int H, hipStream_t stream) {
 
 int launch_ln_bwd(const LnBwdSeg& s0_, const LnBwdSeg& s1_, int H, hipStream_t stream) {
   static const int rpb = [] { const char* e = std::getenv("CAMO_DEV_LNB_ROWS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 32; }();
-  static const bool noatom = [] { const char* e = std::getenv("CAMO_DEV_LNB_NOATOM"); return e && e[0] == '1'; }();
-  LnBwdSeg s0 = s0_, s1 = s1_;
-  if (noatom) { s0.dgamma = nullptr; s1.dgamma = nullptr; }
+  const LnBwdSeg& s0 = s0_; const LnBwdSeg& s1 = s1_;
   auto nblk = [](int rows) { int b = (rows + rpb - 1) / rpb; return rows == 0 ? 0 : (b > 2048 ? 2048 : (b < 1 ? 1 : b)); };
   const int nb0 = nblk(s0.rows), nb1 = nblk(s1.rows);
   if (nb0 + nb1 == 0) return 0;
