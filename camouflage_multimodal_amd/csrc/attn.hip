@@ -528,11 +528,11 @@ int launch_attn_kg2rg_fwd(const float* Q2, const float* KV2, const int* offs, fl
   return (int)hipGetLastError();
 }
 
-int launch_attn_kg2rg_bwd(const float* Q2, const float* KV2, const float* P2, const float* dO2, const int* offs,
+int launch_attn_kg2rg_bwd(const float* Q2, const float* KV2, const float* P2, const float* dO2, const float* O2, const int* offs,
                           float* dQ2, float* dKV2, float* dS2, int B, int max_nr, int H, int nh, int Nk, DropCfg drop,
                           hipStream_t stream) {
   if (attn_mfma_ok(H, nh, Nk, max_nr, true))
-    return launch_kg2rg_bwd_mfma(Q2, KV2, P2, dO2, offs, dQ2, dKV2, B, H, nh, Nk, drop, stream);
+    return launch_kg2rg_bwd_mfma(Q2, KV2, P2, dO2, O2, offs, dQ2, dKV2, B, H, nh, Nk, drop, stream);
   if (attn_fast_ok(H, nh, Nk, max_nr, true, true))
     return launch_kg2rg_bwd32(Q2, KV2, P2, dO2, offs, dQ2, dKV2, B, max_nr, H, nh, Nk, drop, stream);
   const dim3 grid(nh, B);

@@ -378,7 +378,8 @@ __device__ __forceinline__ void kg2rg_fwd_body(
         for (int w = 0; w < NW - 1; ++w) v += ored[w][n][r][lane];
         if (4 * q + r < Nk) {
           const size_t rw = (size_t)(b * Nk + 4 * q + r); const int cl = h * DH + 16 * n + x;
-          if (o16.p) o16.p[rw * o16.ld + cl] = f2bf(v); else O2[rw * H + cl] = v;
+          if (o16.p) o16.p[rw * o16.ld + cl] = f2bf(v);
+          if (O2) O2[rw * H + cl] = v;             // (fp32 copy: the backward takes its row-dots from dO2 . O2)
         }
       }
   }
@@ -397,8 +398,8 @@ __device__ __forceinline__ void kg2rg_bwd_body(
     const float* __restrict__ Q2, const float* __restrict__ KV2, const float* __restrict__ P2,
     const float* __restrict__ dO2, const int* __restrict__ offs,
     float* __restrict__ dQ2, float* __restrict__ dKV2, Bf16Dst dq2_16, Bf16Dst dkv2_16,
-    const float* __restrict__ dKV_done, Bf16Dst dkv_16, int H, int nh, int Nk, float scale, const DropCfg& drop,
-    int h, int b, float (*red)[16], float (*ored)[2][4][64]) {
+    const float* __restrict__ dKV_done, Bf16Dst dkv_16, const float* __restrict__ O2, int H, int nh, int Nk, float scale,
+    const DropCfg& drop, int h, int b, float (*red)[16], float (*ored)[2][4][64]) {
   // bf16 schedule: dK|dV of the OTHER attention block (complete: its kernel ran before this one) is the next
   // GEMM's operand; this block converts the slice of its (sample, head)
   if (dkv_16.p) {
@@ -415,62 +416,51 @@ __device__ __forceinline__ void kg2rg_bwd_body(
   const float* q2p = Q2 + (size_t)b * Nk * H + h * DH;
   const float* g2p = dO2 + (size_t)b * Nk * H + h * DH;
   const Frag8 g2f = load_row8(g2p + (size_t)min(x, Nk - 1) * H, q, x < Nk);
-  // ---- phase 1, orientation T (rows = keys 4q+r, col = query x): dP, row-dots, dS, dQ2
-  // (all loads of a phase are issued up front, unconditionally, from clamped rows -- see kg2rg forward)
-  f4 ds[MAXT], pT[MAXT];
-  float dot = 0.f;
+  // row-dot of query x, sum_t P.dP over ALL keys, without a pass over the keys: sum_t Pd[x,t] (dO2[x] . V[t]) =
+  // dO2[x] . O2[x] (O2 = the forward's attention output of this head, dropout included)
+  float dot;
   {
-    Frag8 vf[MAXT];
-    f4 pld[MAXT];
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int t0 = (wave + NW * i) * 16;
-      vf[i] = load_row8(kv + (size_t)min(t0 + x, nr - 1) * 2 * H + H + h * DH, q, true);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = t0 + 4 * q + r;
-        pld[i][r] = P2[((size_t)(r0 + min(t, nr - 1)) * nh + h) * Nk + min(x, Nk - 1)];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int t0 = (wave + NW * i) * 16;
-      ds[i] = mma_nt32(vf[i], g2f, f4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = t0 + 4 * q + r;
-        const bool ok = t < nr && x < Nk;
-        const size_t idx = ((size_t)(r0 + min(t, nr - 1)) * nh + h) * Nk + min(x, Nk - 1);
-        pT[i][r] = ok ? pld[i][r] : 0.f;
-        const float mk = (ok && drop.p > 0.f) ? drop_mult(drop, SITE_ATTN_KG2RG, (uint32_t)idx) : 1.0f;
-        ds[i][r] = ok ? ds[i][r] * mk : 0.f;
-        dot = fmaf(pT[i][r], ds[i][r], dot);
-      }
-    }
+    const Frag8 o2f = load_row8(O2 + (size_t)(b * Nk + min(x, Nk - 1)) * H + h * DH, q, x < Nk);
+    dot = (g2f.lo.x * o2f.lo.x + g2f.lo.y * o2f.lo.y) + (g2f.lo.z * o2f.lo.z + g2f.lo.w * o2f.lo.w) +
+          (g2f.hi.x * o2f.hi.x + g2f.hi.y * o2f.hi.y) + (g2f.hi.z * o2f.hi.z + g2f.hi.w * o2f.hi.w);
+    dot = group_sum(dot);
   }
-  f4 kb[MAXT][2];
+  // ---- orientation T (rows = keys 4q+r, col = query x): dP, dS, dQ2.  All loads of the kernel are issued up front,
+  // unconditionally, from clamped rows (see kg2rg forward)
+  Frag8 vf[MAXT];
+  f4 pld[MAXT], pl2[MAXT], kb[MAXT][2];
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int t0 = (wave + NW * i) * 16;
+    const int key = min(t0 + x, nr - 1);
+    vf[i] = load_row8(kv + (size_t)key * 2 * H + H + h * DH, q, true);
+    const size_t pb = ((size_t)(r0 + key) * nh + h) * Nk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = t0 + 4 * q + r;
+      pld[i][r] = P2[((size_t)(r0 + min(t, nr - 1)) * nh + h) * Nk + min(x, Nk - 1)];
+      pl2[i][r] = P2[pb + min(4 * q + r, Nk - 1)];
+    }
 #pragma unroll
     for (int n = 0; n < 2; ++n) kb[i][n] = load_col4(kv + h * DH + 16 * n, (size_t)2 * H, min(t0, nr - 1), q, nr - 1, x);
   }
-  dot = group_sum(dot);
-  if (q == 0) red[wave][x] = dot;
-  __syncthreads();
-  { float tot = red[0][x];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) tot += red[w][x];
-    dot = tot; }                                             // row-dot of query x
   f4 dq[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
+    const int t0 = (wave + NW * i) * 16;
+    if (wave + NW * i >= ntiles) continue;                   // wave-uniform; nothing below loads
+    f4 ds = mma_nt32(vf[i], g2f, f4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ds[i][r] = pT[i][r] * (ds[i][r] - dot) * scale;       // 0 on masked entries (pT = 0)
-    if (wave + NW * i < ntiles) {                            // (wave-uniform; skips only MFMAs on zeros)
-#pragma unroll
-      for (int n = 0; n < 2; ++n) dq[n] = mma_acc16(ds[i], kb[i][n], dq[n]);           // rows = queries 4q+r, col = 16n + x
+    for (int r = 0; r < 4; ++r) {
+      const int t = t0 + 4 * q + r;
+      const bool ok = t < nr && x < Nk;
+      const size_t idx = ((size_t)(r0 + min(t, nr - 1)) * nh + h) * Nk + min(x, Nk - 1);
+      const float p = ok ? pld[i][r] : 0.f;
+      const float mk = (ok && drop.p > 0.f) ? drop_mult(drop, SITE_ATTN_KG2RG, (uint32_t)idx) : 1.0f;
+      ds[r] = p * (ds[r] * mk - dot) * scale;                // 0 on masked entries (p = 0)
     }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) dq[n] = mma_acc16(ds, kb[i][n], dq[n]);                // rows = queries 4q+r, col = 16n + x
   }
   if (wave > 0) {
 #pragma unroll
@@ -503,23 +493,13 @@ __device__ __forceinline__ void kg2rg_bwd_body(
   float dotq[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) dotq[r] = __shfl(dot, 4 * q + r, 64);  // row-dot of query 4q+r
-  Frag8 vf2[MAXT];
-  f4 pl2[MAXT];
-#pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
-    const int key = min((wave + NW * i) * 16 + x, nr - 1);
-    vf2[i] = load_row8(kv + (size_t)key * 2 * H + H + h * DH, q, true);
-    const size_t pb = ((size_t)(r0 + key) * nh + h) * Nk;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pl2[i][r] = P2[pb + min(4 * q + r, Nk - 1)];
-  }
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int t0 = (wave + NW * i) * 16;
     if (wave + NW * i >= ntiles) continue;                   // wave-uniform; nothing below loads
     const int key = min(t0 + x, nr - 1);
     const bool key_ok = t0 + x < nr;
-    const f4 dpN = mma_nt32(g2f, vf2[i], f4{0.f, 0.f, 0.f, 0.f});
+    const f4 dpN = mma_nt32(g2f, vf[i], f4{0.f, 0.f, 0.f, 0.f});
     const size_t pb = ((size_t)(r0 + key) * nh + h) * Nk;
     f4 dsN, pdN;
 #pragma unroll
@@ -558,10 +538,11 @@ __global__ __launch_bounds__(64 * NW) void kg2rg_bwd_mfma_kernel(
     const float* __restrict__ Q2, const float* __restrict__ KV2, const float* __restrict__ P2,
     const float* __restrict__ dO2, const int* __restrict__ offs,
     float* __restrict__ dQ2, float* __restrict__ dKV2, Bf16Dst dq2_16, Bf16Dst dkv2_16,
-    const float* __restrict__ dKV_done, Bf16Dst dkv_16, int H, int nh, int Nk, float scale, DropCfg drop) {
+    const float* __restrict__ dKV_done, Bf16Dst dkv_16, const float* __restrict__ O2, int H, int nh, int Nk, float scale,
+    DropCfg drop) {
   __shared__ float red[NW][16];
   __shared__ float ored[NW - 1][2][4][64];
-  kg2rg_bwd_body(Q2, KV2, P2, dO2, offs, dQ2, dKV2, dq2_16, dkv2_16, dKV_done, dkv_16, H, nh, Nk, scale, drop,
+  kg2rg_bwd_body(Q2, KV2, P2, dO2, offs, dQ2, dKV2, dq2_16, dkv2_16, dKV_done, dkv_16, O2, H, nh, Nk, scale, drop,
                  blockIdx.x, blockIdx.y, red, ored);
 }
 
@@ -642,12 +623,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_pair_kernel(
 __global__ __launch_bounds__(64 * NW) void attn_bwd_pair_kernel(
     const float* __restrict__ Q, const float* __restrict__ KV, const float* __restrict__ P, const float* __restrict__ dO,
     const float* __restrict__ Q2, const float* __restrict__ KV2, const float* __restrict__ P2, const float* __restrict__ dO2,
-    const int* __restrict__ offs, Bf16Dst dq16, Bf16Dst dkv16, Bf16Dst dq2_16, Bf16Dst dkv2_16,
+    const int* __restrict__ offs, Bf16Dst dq16, Bf16Dst dkv16, Bf16Dst dq2_16, Bf16Dst dkv2_16, const float* __restrict__ O2,
     int H, int nh, int Nk, int B, float scale, DropCfg drop) {
   __shared__ PairLds lds;
   const int bid = blockIdx.x;
   if (bid < nh * B) {
-    kg2rg_bwd_body(Q2, KV2, P2, dO2, offs, nullptr, nullptr, dq2_16, dkv2_16, nullptr, Bf16Dst{nullptr, 0}, H, nh, Nk, scale, drop,
+    kg2rg_bwd_body(Q2, KV2, P2, dO2, offs, nullptr, nullptr, dq2_16, dkv2_16, nullptr, Bf16Dst{nullptr, 0}, O2, H, nh, Nk, scale, drop,
                    bid % nh, bid / nh, lds.k.red, lds.k.ored);
   } else {
     const int r = bid - nh * B;
@@ -658,19 +639,19 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_pair_kernel(
 }  // namespace
 
 int launch_attn_fwd_pair(const float* Q, const float* KV, const float* Q2, const float* KV2, const int* offs, float* P,
-                         float* P2, Bf16Dst o16, Bf16Dst o2_16, int B, int max_nr, int H, int nh, int Nk, DropCfg drop,
+                         float* P2, Bf16Dst o16, Bf16Dst o2_16, float* O2, int B, int max_nr, int H, int nh, int Nk, DropCfg drop,
                          hipStream_t stream) {
   const int tasks = ((max_nr + 15) / 16) * nh, nbx = (tasks + NW - 1) / NW;
   hipLaunchKernelGGL(attn_fwd_pair_kernel, dim3(nh * B + nbx * B), dim3(64 * NW), 0, stream, Q, KV, Q2, KV2, offs, P, P2,
-                     (float*)nullptr, (float*)nullptr, o16, o2_16, H, nh, Nk, B, nbx, 1.0f / sqrtf((float)DH), drop);
+                     (float*)nullptr, O2, o16, o2_16, H, nh, Nk, B, nbx, 1.0f / sqrtf((float)DH), drop);
   return (int)hipGetLastError();
 }
 
 int launch_attn_bwd_pair(const float* Q, const float* KV, const float* P, const float* dO, const float* Q2, const float* KV2,
                          const float* P2, const float* dO2, const int* offs, Bf16Dst dq16, Bf16Dst dkv16, Bf16Dst dq2_16,
-                         Bf16Dst dkv2_16, int B, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
+                         Bf16Dst dkv2_16, const float* O2, int B, int H, int nh, int Nk, DropCfg drop, hipStream_t stream) {
   hipLaunchKernelGGL(attn_bwd_pair_kernel, dim3(2 * nh * B), dim3(64 * NW), 0, stream, Q, KV, P, dO, Q2, KV2, P2, dO2, offs,
-                     dq16, dkv16, dq2_16, dkv2_16, H, nh, Nk, B, 1.0f / sqrtf((float)DH), drop);
+                     dq16, dkv16, dq2_16, dkv2_16, O2, H, nh, Nk, B, 1.0f / sqrtf((float)DH), drop);
   return (int)hipGetLastError();
 }
 
@@ -709,11 +690,11 @@ int launch_kg2rg_fwd_mfma(const float* Q2, const float* KV2, const int* offs, fl
   return (int)hipGetLastError();
 }
 
-int launch_kg2rg_bwd_mfma(const float* Q2, const float* KV2, const float* P2, const float* dO2, const int* offs, float* dQ2,
-                          float* dKV2, int B, int H, int nh, int Nk, DropCfg drop, hipStream_t stream, Bf16Dst dq2_16,
+int launch_kg2rg_bwd_mfma(const float* Q2, const float* KV2, const float* P2, const float* dO2, const float* O2, const int* offs,
+                          float* dQ2, float* dKV2, int B, int H, int nh, int Nk, DropCfg drop, hipStream_t stream, Bf16Dst dq2_16,
                           Bf16Dst dkv2_16, const float* dKV_done, Bf16Dst dkv_16) {
   hipLaunchKernelGGL(kg2rg_bwd_mfma_kernel, dim3(nh, B), dim3(64 * NW), 0, stream, Q2, KV2, P2, dO2, offs, dQ2, dKV2,
-                     dq2_16, dkv2_16, dKV_done, dkv_16, H, nh, Nk,
+                     dq2_16, dkv2_16, dKV_done, dkv_16, O2, H, nh, Nk,
                      1.0f / sqrtf((float)DH), drop);
   return (int)hipGetLastError();
 }

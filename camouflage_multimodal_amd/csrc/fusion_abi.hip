@@ -394,7 +394,7 @@ int forward_nodes16(const camo_dims_t& d, const float* const* P, const float* rg
   g.nt(h.G, H, h.Win2, H, P[CAMO_P_A2_IN_B], w.Q2, H, nullptr, 0, TK, H, H);
   CK(g.run(), "attention in-projections");
   // both attention directions in one launch; their outputs are GEMM operands only, so they are written as bf16
-  CK(launch_attn_fwd_pair(w.Q, w.KV, w.Q2, w.KV2, rg_offsets, w.P, w.P2, Bf16Dst{h.O, H}, Bf16Dst{h.O2, H}, B, max_nr, H, nh, Nk,
+  CK(launch_attn_fwd_pair(w.Q, w.KV, w.Q2, w.KV2, rg_offsets, w.P, w.P2, Bf16Dst{h.O, H}, Bf16Dst{h.O2, H}, w.O2, B, max_nr, H, nh, Nk,
                           drop, st), "attention fwd (both directions)");
   if (attn_rg2kg) CK(launch_attn_avg_site(w.P, attn_rg2kg, T, nh, Nk, SITE_ATTN_RG2KG, drop, st), "attn avg rg2kg");
   if (attn_kg2rg) CK(launch_attn_avg(w.P2, attn_kg2rg, T, nh, Nk, drop, st), "attn avg");
@@ -457,7 +457,7 @@ int backward_nodes16(const camo_dims_t& d, const float* const* P, float* const* 
   // concatenated [dQ | dK2 | dV2] (rg rows) and [dQ2 | dK | dV] (kg rows) operands of the in-projection backward.
   // Both directions run in one launch, each (head, sample) owned by one block, so nothing is accumulated with atomics.
   CK(launch_attn_bwd_pair(w.Q, w.KV, w.P, w.dO, w.Q2, w.KV2, w.P2, w.dO2, rg_offsets, Bf16Dst{h.dQKV, 3 * H},
-                          Bf16Dst{h.dQKVkg + H, 3 * H}, Bf16Dst{h.dQKVkg, 3 * H}, Bf16Dst{h.dQKV + H, 3 * H}, B, H, nh, Nk, drop, st),
+                          Bf16Dst{h.dQKVkg + H, 3 * H}, Bf16Dst{h.dQKVkg, 3 * H}, Bf16Dst{h.dQKV + H, 3 * H}, w.O2, B, H, nh, Nk, drop, st),
      "attention bwd (both directions)");
   // in-projections: one K = 3H product per side for the input gradient (dR = dU + [dQ|dK2|dV2].[Wq1;Wk2;Wv2]),
   // and the four weight gradients
@@ -710,7 +710,7 @@ static int backward_impl(const camo_dims_t* dims, const float* const* params, fl
   g.tn(w.dU2, H, w.O2, H, Gr[CAMO_P_A2_OUT_W], H, Gr[CAMO_P_A2_OUT_B], H, H, TK);
   CK(g.run(), "out-projection bwd");
   CK(launch_attn_rg2kg_bwd(w.Q, w.KV, w.P, w.dO, rg_offsets, w.dQ, w.dKV, B, max_nr, H, nh, Nk, drop, st), "attn rg2kg bwd");
-  CK(launch_attn_kg2rg_bwd(w.Q2, w.KV2, w.P2, w.dO2, rg_offsets, w.dQ2, w.dKV2, w.dS2, B, max_nr, H, nh, Nk, drop, st), "attn kg2rg bwd");
+  CK(launch_attn_kg2rg_bwd(w.Q2, w.KV2, w.P2, w.dO2, w.O2, rg_offsets, w.dQ2, w.dKV2, w.dS2, B, max_nr, H, nh, Nk, drop, st), "attn kg2rg bwd");
   // in-projection weight gradients, and the gradients flowing into R and G
   const size_t HH = (size_t)H * H;
   g.tn(w.dQ, H, R, H, Gr[CAMO_P_A1_IN_W], H, Gr[CAMO_P_A1_IN_B], H, H, T);

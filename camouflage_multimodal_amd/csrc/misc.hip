@@ -416,9 +416,15 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict
   const int W = 2 * C + 2, nout = x < 2 ? C : 1, coff = x == 0 ? 0 : (x == 1 ? C : (x == 2 ? 2 * C : 2 * C + 1));
   const float* Wx = hp.W[x];
   const float* h = hid + (size_t)b * 4 * Fh + x * Fh;
+  constexpr int HC = 4;                                       // hidden values cached per lane (Fh <= 256), else re-read
+  float hv[HC];
+#pragma unroll
+  for (int i = 0; i < HC; ++i) { const int c = lane + 64 * i; hv[i] = c < Fh ? h[c] : 0.f; }
   for (int o = 0; o < nout; ++o) {
     float acc = 0.f;
-    for (int c = lane; c < Fh; c += 64) acc = fmaf(h[c], Wx[(size_t)o * Fh + c], acc);
+#pragma unroll
+    for (int i = 0; i < HC; ++i) { const int c = lane + 64 * i; if (c < Fh) acc = fmaf(hv[i], Wx[(size_t)o * Fh + c], acc); }
+    for (int c = lane + 64 * HC; c < Fh; c += 64) acc = fmaf(h[c], Wx[(size_t)o * Fh + c], acc);
     acc = wave_sum(acc);
     if (lane == 0) {
       float v = acc + hp.b[x][o];
@@ -430,15 +436,15 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict
   __syncthreads();
   if (threadIdx.x == 0) loss_sample(so, (int)y[b], e[b], s[b], C, terms + 4 * b, nullptr, sd, pred ? pred + b : nullptr);
   __syncthreads();
-  for (int c = lane; c < Fh; c += 64) {
-    const float hv = h[c];
+  for (int c = lane, i = 0; c < Fh; c += 64, ++i) {
+    const float hval = i < HC ? hv[i < HC ? i : 0] : h[c];
     float dh = 0.f;
     for (int o = 0; o < nout; ++o) {
       const float d = sd[coff + o];
       dh = fmaf(d, Wx[(size_t)o * Fh + c], dh);
-      atomicAdd(hp.gW[x] + (size_t)o * Fh + c, d * hv);
+      atomicAdd(hp.gW[x] + (size_t)o * Fh + c, d * hval);
     }
-    dhid[(size_t)b * 4 * Fh + x * Fh + c] = hv > 0.f ? dh * scale : 0.f;
+    dhid[(size_t)b * 4 * Fh + x * Fh + c] = hval > 0.f ? dh * scale : 0.f;
   }
   if (lane < nout) atomicAdd(hp.gb[x] + lane, sd[coff + lane]);
 }
