@@ -416,6 +416,8 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict
   const int W = 2 * C + 2, nout = x < 2 ? C : 1, coff = x == 0 ? 0 : (x == 1 ? C : (x == 2 ? 2 * C : 2 * C + 1));
   const float* Wx = hp.W[x];
   const float* h = hid + (size_t)b * 4 * Fh + x * Fh;
+  // labels first: their load latency hides under the dot products instead of following the barrier
+  const int yb = (int)y[b]; const float eb = e[b], sb = s[b];
   constexpr int HC = 4;                                       // hidden values cached per lane (Fh <= 256), else re-read
   float hv[HC];
 #pragma unroll
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) loss_sample(so, (int)y[b], e[b], s[b], C, terms + 4 * b, nullptr, sd, pred ? pred + b : nullptr);
+  if (threadIdx.x == 0) loss_sample(so, yb, eb, sb, C, terms + 4 * b, nullptr, sd, pred ? pred + b : nullptr);
   __syncthreads();
   for (int c = lane, i = 0; c < Fh; c += 64, ++i) {
     const float hval = i < HC ? hv[i < HC ? i : 0] : h[c];

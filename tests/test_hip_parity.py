@@ -423,3 +423,33 @@ def test_fused_training_call_matches_forward_loss_backward(name, precision):
         scale = max(float(np.abs(gb[k]).max()), 1e-8)
         tol = (4e-3 if precision == "bf16" else 2e-5) * scale      # bf16: a 1-ulp fp32 change upstream can flip a bf16 rounding
         assert float(np.abs(ga[k] - gb[k]).max()) <= tol, k
+
+
+@pytest.mark.parametrize("nrs", [[768, 5], [769, 5], [128] * 4, [1], [300] * 33])
+def test_bf16_schedules_agree_on_boundary_batches(nrs, kg_real, monkeypatch):
+    """Boundary batches of the bf16-resident schedule: the largest sample it takes (768 nodes), one node more (the
+    call must fall back to the general schedule by itself), row counts that are exact multiples of the 128-row
+    padding, a single one-node sample, an odd batch above 32.  One training call on the default configuration in
+    bf16 mode against the same call forced onto the general schedule."""
+    from camouflage_multimodal_amd import NativeTrainer
+    cfg = OP.full_cfg()
+    B = len(nrs)
+    rg = np.concatenate([OP.make_rg(n, 128, seed=500 + i) for i, n in enumerate(nrs)])
+    kg = np.stack([kg_real] * B)
+    y, e, s = OP.make_labels(B, seed=9)
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CAMO_SCHED16", mode)
+        m = make_model(cfg, 3, "bf16").train()
+        tr = NativeTrainer(m, keep_grads=True)
+        terms, pred = tr.step(torch.from_numpy(rg).cuda(), list(nrs), torch.from_numpy(kg).cuda(), torch.from_numpy(y),
+                              torch.from_numpy(e), torch.from_numpy(s), seed=77)
+        tr.engine.ensure_flat_grads(attach=True)
+        res.append((t2n(terms), {k: t2n(p.grad).copy() for k, p in m.named_parameters()}))
+    monkeypatch.delenv("CAMO_SCHED16", raising=False)
+    (ta, ga), (tb, gb) = res
+    assert np.isfinite(ta).all() and all(np.isfinite(v).all() for v in ga.values())
+    assert_close(ta, tb, 2e-4, 2e-3, "loss terms")
+    for k in ga:
+        scale = max(float(np.abs(gb[k]).max()), 1e-8)
+        assert float(np.abs(ga[k] - gb[k]).max()) <= 6e-3 * scale, (k, float(np.abs(ga[k] - gb[k]).max()), scale)
