@@ -398,11 +398,22 @@ int forward_nodes16(const camo_dims_t& d, const float* const* P, const float* rg
                           drop, st), "attention fwd (both directions)");
   if (attn_rg2kg) CK(launch_attn_avg_site(w.P, attn_rg2kg, T, nh, Nk, SITE_ATTN_RG2KG, drop, st), "attn avg rg2kg");
   if (attn_kg2rg) CK(launch_attn_avg(w.P2, attn_kg2rg, T, nh, Nk, drop, st), "attn avg");
-  // out-projection + residual (fusion_model.py:119,130), then LayerNorm
-  set_res(g.nt(h.O, H, h.Wo1, H, P[CAMO_P_A1_OUT_B], w.U, H, nullptr, 0, T, H, H), w.R, H);
-  set_res(g.nt(h.O2, H, h.Wo2, H, P[CAMO_P_A2_OUT_B], w.U2, H, nullptr, 0, TK, H, H), w.G, H);
-  CK(g.run(), "attention out-projections");
-  {
+  // out-projection + residual (fusion_model.py:119,130), then LayerNorm.  At hidden_dim 256 a block of the GEMM owns
+  // whole rows and the LayerNorm (with the mean pool of its output) is its epilogue.
+  if (H == 256) {
+    Gemm16Prob& p1 = g.nt(h.O, H, h.Wo1, H, P[CAMO_P_A1_OUT_B], w.U, H, h.Y, H, T, H, H);
+    set_res(p1, w.R, H);
+    p1.ln_mode = 1; p1.ln_gamma = P[CAMO_P_LN1_W]; p1.ln_beta = P[CAMO_P_LN1_B]; p1.ln_stats = w.st1;
+    p1.colmean = w.Ymean; p1.ldm = H; p1.row_sample = row_sample; p1.inv_nr = inv_nr;
+    Gemm16Prob& p2 = g.nt(h.O2, H, h.Wo2, H, P[CAMO_P_A2_OUT_B], w.U2, H, h.Y2, H, TK, H, H);
+    set_res(p2, w.G, H);
+    p2.ln_mode = 1; p2.ln_gamma = P[CAMO_P_LN2_W]; p2.ln_beta = P[CAMO_P_LN2_B]; p2.ln_stats = w.st2;
+    p2.colmean = w.Y2mean; p2.ldm = H; p2.uniform_n = Nk;
+    CK(g.run(), "attention out-projections + layernorm");
+  } else {
+    set_res(g.nt(h.O, H, h.Wo1, H, P[CAMO_P_A1_OUT_B], w.U, H, nullptr, 0, T, H, H), w.R, H);
+    set_res(g.nt(h.O2, H, h.Wo2, H, P[CAMO_P_A2_OUT_B], w.U2, H, nullptr, 0, TK, H, H), w.G, H);
+    CK(g.run(), "attention out-projections");
     // (the mean pools of Y and of the FFN activations are accumulated by the kernels that produce them)
     LnSeg s0{w.U, w.Y, w.st1, P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], T, h.Y, w.Ymean, row_sample, inv_nr, 0};
     LnSeg s1{w.U2, w.Y2, w.st2, P[CAMO_P_LN2_W], P[CAMO_P_LN2_B], TK, h.Y2, w.Y2mean, nullptr, nullptr, Nk};
@@ -436,13 +447,25 @@ int backward_nodes16(const camo_dims_t& d, const float* const* P, float* const* 
     CK(launch_relu_bcast_bwd(s0, s1, 2 * H, drop.scale, st), "relu bcast bwd");
   }
   GB16 g(drop, st);
-  // first FFN layer: dY = bcast(dpool)/n + dH1.W1 ; dW1 += dH1^T.Y
-  set_bcast(g.nt(h.dH1, 2 * H, h.W1T, 2 * H, nullptr, w.dY, H, nullptr, 0, T, H, 2 * H), w.dcomb, 2 * H, row_sample, inv_nr, 0);
-  set_bcast(g.nt(h.dH2, 2 * H, h.W2T, 2 * H, nullptr, w.dY2, H, nullptr, 0, TK, H, 2 * H), w.dcomb + H, 2 * H, nullptr, nullptr, Nk);
+  // first FFN layer: dY = bcast(dpool)/n + dH1.W1 ; dW1 += dH1^T.Y -- and, at hidden_dim 256, the LayerNorm backward
+  // dY -> dU (+ dgamma, dbeta) as the epilogue of the dY product (whole-row tiles)
+  if (H == 256) {
+    Gemm16Prob& p1 = g.nt(h.dH1, 2 * H, h.W1T, 2 * H, nullptr, w.dU, H, h.dU, H, T, H, 2 * H);
+    set_bcast(p1, w.dcomb, 2 * H, row_sample, inv_nr, 0);
+    p1.ln_mode = 2; p1.ln_gamma = P[CAMO_P_LN1_W]; p1.ln_stats = w.st1; p1.ln_x = w.U;
+    p1.ln_dgamma = Gr[CAMO_P_LN1_W]; p1.ln_dbeta = Gr[CAMO_P_LN1_B];
+    Gemm16Prob& p2 = g.nt(h.dH2, 2 * H, h.W2T, 2 * H, nullptr, w.dU2, H, h.dU2, H, TK, H, 2 * H);
+    set_bcast(p2, w.dcomb + H, 2 * H, nullptr, nullptr, Nk);
+    p2.ln_mode = 2; p2.ln_gamma = P[CAMO_P_LN2_W]; p2.ln_stats = w.st2; p2.ln_x = w.U2;
+    p2.ln_dgamma = Gr[CAMO_P_LN2_W]; p2.ln_dbeta = Gr[CAMO_P_LN2_B];
+  } else {
+    set_bcast(g.nt(h.dH1, 2 * H, h.W1T, 2 * H, nullptr, w.dY, H, nullptr, 0, T, H, 2 * H), w.dcomb, 2 * H, row_sample, inv_nr, 0);
+    set_bcast(g.nt(h.dH2, 2 * H, h.W2T, 2 * H, nullptr, w.dY2, H, nullptr, 0, TK, H, 2 * H), w.dcomb + H, 2 * H, nullptr, nullptr, Nk);
+  }
   g.tn(h.dH1, 2 * H, h.Y, H, Gr[CAMO_P_F1_W0], H, Gr[CAMO_P_F1_B0], 2 * H, H, T);
   g.tn(h.dH2, 2 * H, h.Y2, H, Gr[CAMO_P_F2_W0], H, Gr[CAMO_P_F2_B0], 2 * H, H, TK);
   CK(g.run(), "ffn layer 0 bwd");
-  {
+  if (H != 256) {
     LnBwdSeg s0{w.U, w.dY, w.st1, P[CAMO_P_LN1_W], w.dU, Gr[CAMO_P_LN1_W], Gr[CAMO_P_LN1_B], T, h.dU};
     LnBwdSeg s1{w.U2, w.dY2, w.st2, P[CAMO_P_LN2_W], w.dU2, Gr[CAMO_P_LN2_W], Gr[CAMO_P_LN2_B], TK, h.dU2};
     CK(launch_ln_bwd(s0, s1, H, st), "layernorm bwd");

@@ -34,6 +34,13 @@ struct Gemm16Prob {
   // NT only: colmean[sample(row)][col] += out(row, col) * inv_n(sample(row))  -- the per-sample mean pool of the
   // result, accumulated with atomics into a zeroed [samples][ldm] buffer (sample(): as for GF_RES_BCAST)
   float* colmean; int ldm;
+  // NT only, N == 256: a LayerNorm over the output rows fused into the epilogue (the block owns whole rows).
+  //   ln_mode 1 (forward):  u = A.B^T + bias + res  -> C (fp32);  y = LN(u) * ln_gamma + ln_beta -> C16 (bf16), its
+  //                         per-sample mean pool -> colmean, (mean, rstd) of every row -> ln_stats
+  //   ln_mode 2 (backward): dy = A.B^T (+ broadcast residual); with x = ln_x (the forward's u) and ln_stats:
+  //                         du = LN_backward(dy) -> C (fp32) and C16 (bf16); ln_dgamma += sum dy*xhat, ln_dbeta += sum dy
+  int ln_mode;
+  const float* ln_gamma; const float* ln_beta; float* ln_stats; const float* ln_x; float* ln_dgamma; float* ln_dbeta;
   // filled by the launcher
   int tiles_n, ksplit, kchunk, tile_begin;
 };

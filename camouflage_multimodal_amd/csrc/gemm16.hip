@@ -314,8 +314,208 @@ __device__ __forceinline__ void body_tn(const Gemm16Prob& P, int m0, int n0, int
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ NT, whole-row tiles
+// 32 rows x 256 columns per block (4 waves side by side, 64 columns each), so a row's LayerNorm statistics are
+// inside the block: the LayerNorm forward rides on the out-projection, the LayerNorm backward on the FFN input
+// gradient, and neither needs a launch or a round trip of its input through HBM.
+constexpr int RM = 32, RN = 256;
+constexpr int A_ROW_BYTES = RM * PM;                 // 4096
+constexpr int ROW_BUF_BYTES = (RM + RN) * PM;        // 36864 per stage
+constexpr int TPR = RN + 4;                          // fp32 tile pitch of the column passes
+struct StageR { u32x4 a; u32x4 b[8]; };
+
 template <int PIPE>
-__global__ __launch_bounds__(256, 3) void gemm16_kernel(const Gemm16Batch gb, int total_tiles) {
+__device__ __forceinline__ void body_nt_row(const Gemm16Batch& gb, const Gemm16Prob& P, int m0, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int M = P.M, N = RN;
+  const int nt = P.K / BK;
+  uint32_t goa, gob[8];
+  int la, lb[8];
+  {
+    const int row = tid >> 3, c = tid & 7;
+    goa = ((uint32_t)min(m0 + row, M - 1) * (uint32_t)P.lda + 8u * c) * 2u;
+    la = row * PM + 16 * (c ^ ((row >> 1) & 7));
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int s_ = tid + 256 * i, row = s_ >> 3, c = s_ & 7;
+    gob[i] = ((uint32_t)row * (uint32_t)P.ldb + 8u * c) * 2u;
+    lb[i] = A_ROW_BYTES + row * PM + 16 * (c ^ ((row >> 1) & 7));
+  }
+  const char* Ab = reinterpret_cast<const char*>(P.A);
+  const char* Bb = reinterpret_cast<const char*>(P.B);
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  StageR st[PIPE];
+  auto gload = [&](StageR& r, int kt) {
+    const int k = min(kt, nt - 1);
+    const char* a = Ab + (size_t)k * (BK * 2);
+    const char* b = Bb + (size_t)k * (BK * 2);
+    r.a = *reinterpret_cast<const u32x4*>(a + goa);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.b[i] = *reinterpret_cast<const u32x4*>(b + gob[i]);
+  };
+  auto sstore = [&](const StageR& r, int buf) {
+    char* base = smem + buf * ROW_BUF_BYTES;
+    *reinterpret_cast<u32x4*>(base + la) = r.a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(base + lb[i]) = r.b[i];
+  };
+  const int rb = w * 64 + l31;
+  int fa[4], fb[4];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    fa[s_] = l31 * PM + 16 * ((2 * s_ + h) ^ ((l31 >> 1) & 7));
+    fb[s_] = A_ROW_BYTES + rb * PM + 16 * ((2 * s_ + h) ^ ((rb >> 1) & 7));
+  }
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * ROW_BUF_BYTES;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(base + fa[s_]);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(base + fb[s_]);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(base + fb[s_] + 32 * PM);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, acc[0], 0, 0, 0);   // C^T: lane = row
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[1], 0, 0, 0);
+    }
+  };
+  G16_PIPELINE_LOOP
+
+  // ---- epilogue: lane (l31, h) holds row m0 + l31, columns 64 w + 32 j + 8 g + 4 h + i (register 4 g + i of acc[j])
+  const int row = m0 + l31;
+  const bool rok = row < M;
+  const int rowc = rok ? row : M - 1;
+  float* red = reinterpret_cast<float*>(smem);        // [2][4][32]
+  float* tile0 = red + 256;                           // [32][TPR]
+  float* tile1 = tile0 + RM * TPR;                    // [32][TPR] (backward only)
+  const float invN = 1.0f / (float)N;
+  // sum of the lane's 32 values + the other half-wave's = this wave's 64 columns of the row; then the 4 waves
+  auto row_total = [&](float part, int slot) {
+    part += __shfl_xor(part, 32, 64);
+    if (h == 0) red[slot * 128 + w * 32 + l31] = part;
+    __syncthreads();
+    return (red[slot * 128 + l31] + red[slot * 128 + 32 + l31]) + (red[slot * 128 + 64 + l31] + red[slot * 128 + 96 + l31]);
+  };
+  int sb = 0; float rscale = 1.f;
+  if (P.row_sample) { sb = P.row_sample[rowc]; rscale = P.inv_nr[sb]; }
+  else if (P.uniform_n > 0) { sb = rowc / P.uniform_n; rscale = 1.0f / (float)P.uniform_n; }
+  if (P.ln_mode == 1) {
+    const float* rrow = P.res ? P.res + (size_t)rowc * P.ldr : nullptr;
+    float4 u[2][4];
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = w * 64 + j * 32 + 8 * g + 4 * h;
+        float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+        if (P.bias) { const float4 bv = *reinterpret_cast<const float4*>(P.bias + c0); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+        if (rrow) { const float4 rv = *reinterpret_cast<const float4*>(rrow + c0); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+        u[j][g] = v;
+        part += (v.x + v.y) + (v.z + v.w);
+        if (rok && P.C) *reinterpret_cast<float4*>(P.C + (size_t)row * P.ldc + c0) = v;
+      }
+    const float mean = row_total(part, 0) * invN;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4& v = u[j][g];
+        v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+        sq = fmaf(v.x, v.x, sq); sq = fmaf(v.y, v.y, sq); sq = fmaf(v.z, v.z, sq); sq = fmaf(v.w, v.w, sq);
+      }
+    const float rstd = 1.0f / sqrtf(row_total(sq, 1) * invN + 1e-5f);
+    if (rok && w == 0 && h == 0 && P.ln_stats) { P.ln_stats[2 * row] = mean; P.ln_stats[2 * row + 1] = rstd; }
+    __syncthreads();                                   // `red` is read; the tile below overlaps nothing of it
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = w * 64 + j * 32 + 8 * g + 4 * h;
+        const float4 gm = *reinterpret_cast<const float4*>(P.ln_gamma + c0), bt = *reinterpret_cast<const float4*>(P.ln_beta + c0);
+        float4 y;
+        y.x = u[j][g].x * rstd * gm.x + bt.x; y.y = u[j][g].y * rstd * gm.y + bt.y;
+        y.z = u[j][g].z * rstd * gm.z + bt.z; y.w = u[j][g].w * rstd * gm.w + bt.w;
+        if (rok && P.C16) *reinterpret_cast<uint2*>(P.C16 + (size_t)row * P.ldc16 + c0) = make_uint2(pack2(y.x, y.y), pack2(y.z, y.w));
+        if (P.colmean) *reinterpret_cast<float4*>(tile0 + l31 * TPR + c0) = y;
+      }
+    if (P.colmean) {                                   // per-sample mean pool of y: thread t owns column t
+      int* srow = reinterpret_cast<int*>(tile1);
+      if (tid < RM) { const int rr = m0 + tid; srow[tid] = rr < M ? (P.row_sample ? P.row_sample[rr] : rr / P.uniform_n) : -1; }
+      __syncthreads();
+      float sum = 0.f; int cur = -1;
+      for (int r = 0; r < RM; ++r) {
+        const int sm = srow[r];
+        if (sm < 0) break;
+        if (sm != cur) {
+          if (cur >= 0) atomicAdd(P.colmean + (size_t)cur * P.ldm + tid, sum * (P.row_sample ? P.inv_nr[cur] : 1.0f / (float)P.uniform_n));
+          sum = 0.f; cur = sm;
+        }
+        sum += tile0[r * TPR + tid];
+      }
+      if (cur >= 0) atomicAdd(P.colmean + (size_t)cur * P.ldm + tid, sum * (P.row_sample ? P.inv_nr[cur] : 1.0f / (float)P.uniform_n));
+    }
+  } else {
+    // LayerNorm backward: g = dy * gamma, du = (g - mean(g) - xhat * mean(g * xhat)) * rstd
+    const bool bc = P.flags & GF_RES_BCAST;                                    // per-sample broadcast residual, or per-row
+    const float* rrow = P.res ? P.res + (size_t)(bc ? sb : rowc) * P.ldr : nullptr;
+    if (!bc) rscale = 1.f;
+    const float* xrow = P.ln_x + (size_t)rowc * N;
+    const float mean = P.ln_stats[2 * rowc], rstd = P.ln_stats[2 * rowc + 1];
+    float4 gq[2][4], xq[2][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = w * 64 + j * 32 + 8 * g + 4 * h;
+        float4 dy = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+        if (rrow) { const float4 rv = *reinterpret_cast<const float4*>(rrow + c0); dy.x = fmaf(rv.x, rscale, dy.x); dy.y = fmaf(rv.y, rscale, dy.y); dy.z = fmaf(rv.z, rscale, dy.z); dy.w = fmaf(rv.w, rscale, dy.w); }
+        const float4 xv = *reinterpret_cast<const float4*>(xrow + c0);
+        const float4 gm = *reinterpret_cast<const float4*>(P.ln_gamma + c0);
+        float4 xh, gg;
+        xh.x = (xv.x - mean) * rstd; xh.y = (xv.y - mean) * rstd; xh.z = (xv.z - mean) * rstd; xh.w = (xv.w - mean) * rstd;
+        gg.x = dy.x * gm.x; gg.y = dy.y * gm.y; gg.z = dy.z * gm.z; gg.w = dy.w * gm.w;
+        s1 += (gg.x + gg.y) + (gg.z + gg.w);
+        s2 = fmaf(gg.x, xh.x, s2); s2 = fmaf(gg.y, xh.y, s2); s2 = fmaf(gg.z, xh.z, s2); s2 = fmaf(gg.w, xh.w, s2);
+        gq[j][g] = gg; xq[j][g] = xh;
+        // column-sum operands of dgamma / dbeta (rows past M are excluded by the column pass)
+        *reinterpret_cast<float4*>(tile0 + l31 * TPR + c0) = make_float4(dy.x * xh.x, dy.y * xh.y, dy.z * xh.z, dy.w * xh.w);
+        *reinterpret_cast<float4*>(tile1 + l31 * TPR + c0) = dy;
+      }
+    const float m1 = row_total(s1, 0) * invN;
+    const float m2 = row_total(s2, 1) * invN;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = w * 64 + j * 32 + 8 * g + 4 * h;
+        float4 du;
+        du.x = (gq[j][g].x - m1 - xq[j][g].x * m2) * rstd; du.y = (gq[j][g].y - m1 - xq[j][g].y * m2) * rstd;
+        du.z = (gq[j][g].z - m1 - xq[j][g].z * m2) * rstd; du.w = (gq[j][g].w - m1 - xq[j][g].w * m2) * rstd;
+        if (rok) {
+          if (P.C) *reinterpret_cast<float4*>(P.C + (size_t)row * P.ldc + c0) = du;
+          if (P.C16) *reinterpret_cast<uint2*>(P.C16 + (size_t)row * P.ldc16 + c0) = make_uint2(pack2(du.x, du.y), pack2(du.z, du.w));
+        }
+      }
+    // (row_total's barriers also ordered the tile stores above before the column pass)
+    const int nrow = min(RM, M - m0);
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < nrow; ++r) { a += tile0[r * TPR + tid]; b += tile1[r * TPR + tid]; }
+    atomicAdd(P.ln_dgamma + tid, a);
+    atomicAdd(P.ln_dbeta + tid, b);
+  }
+}
+
+// ROWS: the launch contains whole-row (fused LayerNorm) problems -> 72 KB of LDS, two blocks per CU; otherwise
+// three blocks per CU (forward launches) or two (launches with weight-gradient problems, 64 KB).
+template <int PIPE, bool ROWS>
+__global__ __launch_bounds__(256, ROWS ? 2 : 3) void gemm16_kernel(const Gemm16Batch gb, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // XCD-aware block remap (bijective): blocks that share an XCD (bid % 8) take a contiguous run of tiles
   int bid = blockIdx.x;
@@ -329,6 +529,9 @@ __global__ __launch_bounds__(256, 3) void gemm16_kernel(const Gemm16Batch gb, in
     if (i < gb.n && bid >= gb.p[i].tile_begin) pi = i;
   const Gemm16Prob& P = gb.p[pi];
   int t = bid - P.tile_begin;
+  if constexpr (ROWS) {
+    if (P.ln_mode) { body_nt_row<PIPE>(gb, P, t * RM, smem_raw); return; }
+  }
   const int ks = t % P.ksplit; t /= P.ksplit;
   const int tn = t % P.tiles_n, tm = t / P.tiles_n;
   if (P.flags & GF_A_KMAJOR) {
@@ -363,7 +566,15 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
       if ((double)(akm ? p.K + 128 : p.M) * p.lda * 2.0 >= 4.0e9 || (double)(akm ? p.K + 128 : p.N) * p.ldb * 2.0 >= 4.0e9)
         return (int)hipErrorInvalidValue;                                    // 32-bit lane offsets
       p.tiles_n = (p.N + BN - 1) / BN;
-      const int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
+      int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
+      if (p.ln_mode) {
+        if (akm || p.N != RN || !p.ln_gamma || !al16(p.ln_gamma) || (p.ln_mode == 1 && (!p.ln_beta || !al16(p.ln_beta))) ||
+            (p.ln_mode == 2 && (!p.ln_x || !al16(p.ln_x) || !p.ln_stats || !p.ln_dgamma || !p.ln_dbeta)) ||
+            (p.flags & (GF_RELU | GF_DROPOUT | GF_RELU_BWD)))
+          return (int)hipErrorInvalidValue;
+        p.tiles_n = 1;
+        tiles = (p.M + RM - 1) / RM;
+      }
       if (akm) {
         if ((p.M & 7) || (p.N & 7) || p.M < 8 || p.N < 8 || !p.C || p.C16 || p.bias || p.res ||
             (p.flags & ~(GF_A_KMAJOR | GF_B_KMAJOR | GF_ATOMIC)))
@@ -384,11 +595,12 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
     }
     if (kcap_env || total >= 384 || kcap <= dev_kmin()) break;
   }
-  bool has_tn = false;
-  for (int i = 0; i < gb.n; ++i) has_tn = has_tn || (gb.p[i].flags & GF_A_KMAJOR);
-  const size_t lds = has_tn ? 2 * BUF_BYTES : 2 * NT_BUF_BYTES;     // 64 KB / 48 KB
+  bool has_tn = false, has_rows = false;
+  for (int i = 0; i < gb.n; ++i) { has_tn = has_tn || (gb.p[i].flags & GF_A_KMAJOR); has_rows = has_rows || gb.p[i].ln_mode; }
+  const size_t lds = has_rows ? 2 * ROW_BUF_BYTES : (has_tn ? 2 * BUF_BYTES : 2 * NT_BUF_BYTES);     // 72 / 64 / 48 KB
   static const bool attr_ok = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ROW_BUF_BYTES);
     return true;
   }();
   (void)attr_ok;
@@ -396,7 +608,8 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
   for (int i = 0; i < gb.n; ++i) fl += 2.0 * gb.p[i].M * (double)gb.p[i].N * gb.p[i].K;
   const int prof = gemm_prof_open(stream, fl);
   // two register stages (four measured slower on every launch of the step)
-  hipLaunchKernelGGL(gemm16_kernel<2>, dim3(total), dim3(256), lds, stream, gb, total);
+  if (has_rows) hipLaunchKernelGGL((gemm16_kernel<2, true>), dim3(total), dim3(256), lds, stream, gb, total);
+  else          hipLaunchKernelGGL((gemm16_kernel<2, false>), dim3(total), dim3(256), lds, stream, gb, total);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }

@@ -369,8 +369,8 @@ def test_bf16_resident_schedule_matches_fp32_operand_schedule(training, kg_real,
     batch = eng.make_batch(torch.from_numpy(np.concatenate(rg)).cuda(), nrs, torch.from_numpy(kg).cuda())
     T, B = sum(nrs), len(nrs)
     names = [("R", (T, 256)), ("Q", (T, 256)), ("KV2", (T, 512)), ("KV", (B * 13, 512)), ("P", (T, 8, 13)), ("P2", (T, 8, 13)),
-             ("U", (T, 256)), ("U2", (B * 13, 256)), ("Y", (T, 256)),
-             ("comb", (B, 512)), ("fused", (B, 256))]     # (the bf16 schedule keeps H1/H2 only as bf16 masks)
+             ("U", (T, 256)), ("U2", (B * 13, 256)),
+             ("comb", (B, 512)), ("fused", (B, 256))]     # (the bf16 schedule keeps Y, H1, H2 only as bf16)
     d_outs = torch.from_numpy(np.random.RandomState(5).standard_normal((B, 6)).astype(np.float32)).cuda()
     res = {}
     for mode in ("sched16", "general"):
