@@ -486,14 +486,16 @@ int backward_nodes16(const camo_dims_t& d, const float* const* P, float* const* 
   // and the four weight gradients
   set_res(g.nt(h.dQKV, 3 * H, h.WcRgT, 3 * H, nullptr, nullptr, 0, h.dR, H, T, H, 3 * H), w.dU, H);
   set_res(g.nt(h.dQKVkg, 3 * H, h.WcKgT, 3 * H, nullptr, nullptr, 0, h.dG, H, TK, H, 3 * H), w.dU2, H);
+  CK(g.run(), "in-projection bwd (input gradients)");
+  // every remaining weight gradient in one launch: the in-projection ones do not wait for dR / dG, but beside the
+  // K = 3H products above they set that launch's length, while the lone dW_rg / dW_kg launch left most CUs idle
   g.tn(h.dQKV, 3 * H, h.R, H, Gr[CAMO_P_A1_IN_W], H, Gr[CAMO_P_A1_IN_B], H, H, T);
   g.tn(h.dQKV + H, 3 * H, h.R, H, Gr[CAMO_P_A2_IN_W] + HH, H, Gr[CAMO_P_A2_IN_B] + H, 2 * H, H, T);
   g.tn(h.dQKVkg, 3 * H, h.G, H, Gr[CAMO_P_A2_IN_W], H, Gr[CAMO_P_A2_IN_B], H, H, TK);
   g.tn(h.dQKVkg + H, 3 * H, h.G, H, Gr[CAMO_P_A1_IN_W] + HH, H, Gr[CAMO_P_A1_IN_B] + H, 2 * H, H, TK);
-  CK(g.run(), "in-projection bwd");
   g.tn(h.dR, H, h.X, D, Gr[CAMO_P_RG_PROJ_W], D, Gr[CAMO_P_RG_PROJ_B], H, D, T);
   g.tn(h.dG, H, h.KG, Dk, Gr[CAMO_P_KG_PROJ_W], Dk, Gr[CAMO_P_KG_PROJ_B], H, Dk, TK);
-  CK(g.run(), "input projection bwd");
+  CK(g.run(), "in-projection and input-projection weight gradients");
   return 0;
 }
 

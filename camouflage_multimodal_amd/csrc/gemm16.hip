@@ -593,7 +593,7 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
       p.tile_begin = total;
       total += tiles * p.ksplit;
     }
-    if (kcap_env || total >= 384 || kcap <= dev_kmin()) break;
+    if (kcap_env || total >= 200 || kcap <= dev_kmin()) break;
   }
   bool has_tn = false, has_rows = false;
   for (int i = 0; i < gb.n; ++i) { has_tn = has_tn || (gb.p[i].flags & GF_A_KMAJOR); has_rows = has_rows || gb.p[i].ln_mode; }
