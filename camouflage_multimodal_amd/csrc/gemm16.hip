@@ -532,7 +532,11 @@ __global__ __launch_bounds__(256, ROWS ? 2 : 3) void gemm16_kernel(const Gemm16B
   if constexpr (ROWS) {
     if (P.ln_mode) { body_nt_row<PIPE>(gb, P, t * RM, smem_raw); return; }
   }
-  const int ks = t % P.ksplit; t /= P.ksplit;
+  // Split-K problems number their blocks K-slice-major: the XCD remap above hands an XCD a contiguous run of block
+  // ids, i.e. (with ~8 slices) all output tiles of ONE K slice -- the tiles that re-read the same rows of dy and x
+  // then share them through that XCD's L2 instead of fetching them 2-8 times from HBM / Infinity Cache.
+  const int tiles = ((P.M + BM - 1) / BM) * P.tiles_n;
+  const int ks = t / tiles; t -= ks * tiles;
   const int tn = t % P.tiles_n, tm = t / P.tiles_n;
   if (P.flags & GF_A_KMAJOR) {
     const int ktiles = (P.K + 127) / 128 * 2;                 // K rounded up to 128 rows, in 64-row tiles
