@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event roofline leg")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus N > 1 (nccl = RCCL; gloo lets a "
+                    "one-GPU box rehearse the multi-rank path with every rank on the same device)")
     args = ap.parse_args()
 
     import torch
@@ -124,11 +126,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     torch.manual_seed(0)
     model = build_multimodal_model({}).to(dev).set_precision(args.precision).train()   # reference defaults, dropout 0.3
@@ -162,15 +168,18 @@ def main():
         elapsed = float(t.item())
 
     # ---- roofline leg: same K steps again with HIP events around every launch of the dominant kernel
+    # (every rank runs these steps -- they contain the gradient all-reduce -- only rank 0 records events)
     roof = None
-    if rank == 0 and not args.no_kernel_timing:
+    if not args.no_kernel_timing:
         L = _lib.lib()
         k = min(args.steps, 50)
-        _lib.check(L.camo_prof_begin(64 * k), "camo_prof_begin")
+        if rank == 0:
+            _lib.check(L.camo_prof_begin(64 * k), "camo_prof_begin")
         t1 = time.perf_counter()
         run(k, args.warmup)
         torch.cuda.synchronize()
         t_prof = time.perf_counter() - t1
+    if rank == 0 and not args.no_kernel_timing:
         ms, n, fl = C.c_double(), C.c_int32(), C.c_double()
         _lib.check(L.camo_prof_end(C.byref(ms), C.byref(n), C.byref(fl)), "camo_prof_end")
         alg = sum(algorithmic_flops(batches[i % len(batches)][1]) for i in range(args.warmup, args.warmup + k))
