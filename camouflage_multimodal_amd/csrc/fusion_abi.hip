@@ -365,7 +365,9 @@ int forward_nodes16(const camo_dims_t& d, const float* const* P, const float* rg
     auto pad = [&](us* buf, size_t rows, size_t rows_p, size_t width) {
       job(PREP_ZERO, nullptr, buf + rows * width, (rows_p - rows) * width * sizeof(us), 0, 0, 0, 0);
     };
-    job(PREP_ZERO, nullptr, w.zero_base, w.zero_bytes, 0, 0, 0, 0);
+    // the atomics block: pooled means, dfused and the barrier words (this schedule accumulates nothing into dKV)
+    job(PREP_ZERO, nullptr, w.zero_base, (size_t)(reinterpret_cast<char*>(w.dKV) - reinterpret_cast<char*>(w.zero_base)), 0, 0, 0, 0);
+    job(PREP_ZERO, nullptr, w.sync, 16 * sizeof(unsigned int), 0, 0, 0, 0);
     cast(rg, h.X, (size_t)T * D); cast(kg, h.KG, (size_t)TK * Dk);
     cast(P[CAMO_P_RG_PROJ_W], h.Wrg, (size_t)H * D); cast(P[CAMO_P_KG_PROJ_W], h.Wkg, (size_t)H * Dk);
     cast(P[CAMO_P_A1_IN_W], h.Win1, 3 * HH); cast(P[CAMO_P_A2_IN_W], h.Win2, 3 * HH);

@@ -414,8 +414,13 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict
   __shared__ float so[HEADS_MAXW], sd[HEADS_MAXW];
   const int b = blockIdx.x, x = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int W = 2 * C + 2, nout = x < 2 ? C : 1, coff = x == 0 ? 0 : (x == 1 ? C : (x == 2 ? 2 * C : 2 * C + 1));
-  const float* Wx = hp.W[x];
+  // (static indices + selects: indexing the by-value argument struct with the runtime wave id would move it to scratch)
+  const float* Wx = x == 0 ? hp.W[0] : (x == 1 ? hp.W[1] : (x == 2 ? hp.W[2] : hp.W[3]));
+  const float* bx = x == 0 ? hp.b[0] : (x == 1 ? hp.b[1] : (x == 2 ? hp.b[2] : hp.b[3]));
+  float* gWx = x == 0 ? hp.gW[0] : (x == 1 ? hp.gW[1] : (x == 2 ? hp.gW[2] : hp.gW[3]));
+  float* gbx = x == 0 ? hp.gb[0] : (x == 1 ? hp.gb[1] : (x == 2 ? hp.gb[2] : hp.gb[3]));
   const float* h = hid + (size_t)b * 4 * Fh + x * Fh;
+  const float bias0 = bx[0];                                  // (in flight with the hidden row)
   // labels first: their load latency hides under the dot products instead of following the barrier
   const int yb = (int)y[b]; const float eb = e[b], sb = s[b];
   constexpr int HC = 4;                                       // hidden values cached per lane (Fh <= 256), else re-read
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict
     for (int c = lane + 64 * HC; c < Fh; c += 64) acc = fmaf(h[c], Wx[(size_t)o * Fh + c], acc);
     acc = wave_sum(acc);
     if (lane == 0) {
-      float v = acc + hp.b[x][o];
+      float v = acc + (o == 0 ? bias0 : bx[o]);
       if (x == 3) v = 1.0f / (1.0f + __expf(-v));
       so[coff + o] = v;
       outs[(size_t)b * W + coff + o] = v;
@@ -438,17 +443,19 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict
   __syncthreads();
   if (threadIdx.x == 0) loss_sample(so, yb, eb, sb, C, terms + 4 * b, nullptr, sd, pred ? pred + b : nullptr);
   __syncthreads();
-  for (int c = lane, i = 0; c < Fh; c += 64, ++i) {
-    const float hval = i < HC ? hv[i < HC ? i : 0] : h[c];
+  auto back = [&](int c, float hval) {
     float dh = 0.f;
     for (int o = 0; o < nout; ++o) {
       const float d = sd[coff + o];
       dh = fmaf(d, Wx[(size_t)o * Fh + c], dh);
-      atomicAdd(hp.gW[x] + (size_t)o * Fh + c, d * hval);
+      atomicAdd(gWx + (size_t)o * Fh + c, d * hval);
     }
     dhid[(size_t)b * 4 * Fh + x * Fh + c] = hval > 0.f ? dh * scale : 0.f;
-  }
-  if (lane < nout) atomicAdd(hp.gb[x] + lane, sd[coff + lane]);
+  };
+#pragma unroll
+  for (int i = 0; i < HC; ++i) { const int c = lane + 64 * i; if (c < Fh) back(c, hv[i]); }     // (static register indices)
+  for (int c = lane + 64 * HC; c < Fh; c += 64) back(c, h[c]);
+  if (lane < nout) atomicAdd(gbx + lane, sd[coff + lane]);
 }
 
 // ---------------------------------------------------------------- optimizer
