@@ -17,7 +17,9 @@ from .test_multimodal import (build_ordered_kg_tensor, load_multimodal_model, pr
 from .train_multimodal import (NativeTrainer, calculate_f1_score, collate_fn, fit, pack_samples,  # noqa: F401
                                train_epoch_fixed, validate_fixed)
 
-__all__ = ["build_multimodal_model", "MultimodalCamouflageDetector", "CrossAttentionFusion", "LateFusion",
+from .region_graph import RegionGraphGNN, build_target_csr  # noqa: F401,E402
+
+__all__ = ["RegionGraphGNN", "build_target_csr", "build_multimodal_model", "MultimodalCamouflageDetector", "CrossAttentionFusion", "LateFusion",
            "AggressiveFocalLoss", "multitask_loss", "FusedClipAdamW", "cosine_warm_restarts_lr", "NativeTrainer",
            "calculate_f1_score", "collate_fn", "fit", "pack_samples", "train_epoch_fixed", "validate_fixed",
            "EmbeddingMatcher", "DeviceResidentDataset", "load_multimodal_model", "build_ordered_kg_tensor",

@@ -24,6 +24,15 @@ SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_
            "camo_prof_begin", "camo_prof_end")
 
 
+# every symbol include/camo_rg_gnn.h declares
+RG_SYMBOLS = ("camo_rg_workspace_bytes", "camo_rg_node_embeddings")
+RG_NPARAMS = 28
+
+
+class CamoRgDims(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32)]
+
+
 class CamoDims(C.Structure):
     _fields_ = [("rg_dim", C.c_int32), ("kg_dim", C.c_int32), ("hidden_dim", C.c_int32), ("num_heads", C.c_int32),
                 ("num_classes", C.c_int32), ("fusion_type", C.c_int32), ("dropout", C.c_float)]
@@ -67,6 +76,10 @@ def lib():
     L.camo_forward_loss_backward.restype = C.c_int
     L.camo_forward_loss_backward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz,
                                              vp, vp, vp, vp, vp, vp, i32, C.c_uint64, i32, vp]
+    L.camo_rg_workspace_bytes.restype = sz
+    L.camo_rg_workspace_bytes.argtypes = [C.POINTER(CamoRgDims), i32]
+    L.camo_rg_node_embeddings.restype = C.c_int
+    L.camo_rg_node_embeddings.argtypes = [C.POINTER(CamoRgDims), vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, vp]
     L.camo_debug_gemm.restype = C.c_int
     L.camo_debug_gemm.argtypes = [vp, i32, vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]
     L.camo_debug_gemm16.restype = C.c_int

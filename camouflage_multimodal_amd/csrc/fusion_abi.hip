@@ -25,6 +25,8 @@
 #include "gemm.h"
 #include "gemm16.h"
 #include "misc.h"
+#include "rg_gnn.h"
+#include "../../include/camo_rg_gnn.h"
 
 namespace {
 
@@ -867,4 +869,64 @@ int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int3
   return -1;
 }
 
+
+// ---- Region-Graph GNN embedding path (include/camo_rg_gnn.h) ----------------------------------------------
+namespace {
+struct RgWs { float *Hh, *a_src, *a_dst, *dinv, *xw, *ha, *hb; size_t bytes; };
+RgWs rg_carve(const camo_rg_dims_t& d, int N, void* base) {
+  RgWs w{};
+  Carver c(base);
+  const size_t n = N, C = d.hidden, K = d.heads;
+  w.Hh = c.take<float>(n * K * C); w.a_src = c.take<float>(n * K); w.a_dst = c.take<float>(n * K); w.dinv = c.take<float>(n);
+  w.xw = c.take<float>(n * C); w.ha = c.take<float>(n * C); w.hb = c.take<float>(n * C);
+  c.off = (c.off + 255) & ~size_t(255);
+  w.bytes = c.off;
+  return w;
+}
+int rg_check(const camo_rg_dims_t* d, int N) {
+  if (!d) return fail(CAMO_E_ARG, "dims is null");
+  if (N < 1 || d->in_channels < 1 || d->hidden < 1 || d->hidden > 512 || d->heads < 1 || d->heads > 8)
+    return fail(CAMO_E_UNSUPPORTED, "need N >= 1, hidden <= 512, 1 <= heads <= 8");
+  return 0;
+}
+}  // namespace
+
+size_t camo_rg_workspace_bytes(const camo_rg_dims_t* dims, int32_t N) {
+  if (rg_check(dims, N)) return 0;
+  return rg_carve(*dims, N, nullptr).bytes;
+}
+
+int camo_rg_node_embeddings(const camo_rg_dims_t* dims, const float* const* params, const float* x, const int32_t* rowptr,
+                            const int32_t* col, const float* w, int32_t N, int32_t E, void* workspace, size_t workspace_bytes,
+                            float* out, void* stream) {
+  if (int e = rg_check(dims, N)) return e;
+  if (!params || !x || !rowptr || !col || !w || !workspace || !out || E < N) return fail(CAMO_E_ARG, "null pointer argument or E < N (one self-loop per node)");
+  const camo_rg_dims_t& d = *dims;
+  const RgWs ws = rg_carve(d, N, workspace);
+  if (workspace_bytes < ws.bytes) return fail(CAMO_E_WORKSPACE, "workspace smaller than camo_rg_workspace_bytes()");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int C = d.hidden, K = d.heads, In = d.in_channels;
+  const float* const* P = params;
+  auto bn = [&](int slot) { return BnEval{P[slot], P[slot + 1], P[slot + 2], P[slot + 3]}; };
+  GB g(make_drop(0, 0.f, 0), CAMO_PREC_F32, st);
+  // conv1: GATConv (extract_rg_embeddings.py:104) + bn1 + relu
+  g.nt(x, In, P[CAMO_RG_C1_W], In, nullptr, ws.Hh, K * C, N, K * C, In);
+  CK(g.run(), "gat projection");
+  CK(launch_gat_alpha(ws.Hh, P[CAMO_RG_C1_ATT_SRC], P[CAMO_RG_C1_ATT_DST], ws.a_src, ws.a_dst, N, K, C, st), "gat attention logits");
+  CK(launch_gat_aggregate(ws.Hh, ws.a_src, ws.a_dst, rowptr, col, P[CAMO_RG_C1_BIAS], bn(CAMO_RG_BN1), ws.ha, N, K, C, st), "gat aggregate");
+  // conv2..4: GCNConv with edge weights (:108-118) + bn + relu
+  CK(launch_gcn_dinv(rowptr, w, ws.dinv, N, st), "gcn degrees");
+  float* cur = ws.ha; float* nxt = ws.hb;
+  for (int k = 0; k < 3; ++k) {
+    const int base = CAMO_RG_C2_BIAS + 6 * k;
+    g.nt(cur, C, P[base + 1], C, nullptr, ws.xw, C, N, C, C);
+    CK(g.run(), "gcn projection");
+    CK(launch_gcn_aggregate(ws.xw, rowptr, col, w, ws.dinv, P[base], bn(base + 2), nxt, N, C, st), "gcn aggregate");
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  // fc_shared + relu (:121)
+  g.nt(cur, C, P[CAMO_RG_FC_W], C, P[CAMO_RG_FC_B], out, C, N, C, C, GF_RELU);
+  CK(g.run(), "fc_shared");
+  return 0;
+}
 }  // extern "C"

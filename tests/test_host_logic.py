@@ -26,6 +26,12 @@ def test_shared_library_exports_every_declared_symbol():
     assert L.camo_abi_version() == _lib.ABI_VERSION
     assert f"#define CAMO_ABI_VERSION {_lib.ABI_VERSION}" in hdr
     assert f"#define CAMO_SUMSQ_FLOATS {_lib.SUMSQ_FLOATS}" in hdr
+    hdr2 = open(os.path.join(ROOT, "include", "camo_rg_gnn.h")).read()
+    declared2 = set(re.findall(r"\b(camo_[a-z_0-9]+)\s*\(", hdr2)) - {"camo_last_error"}
+    assert declared2 == set(_lib.RG_SYMBOLS), declared2 ^ set(_lib.RG_SYMBOLS)
+    for s in declared2:
+        assert hasattr(L, s), s
+    assert f"CAMO_RG_NPARAMS" in hdr2 and _lib.RG_NPARAMS == 28
 
 
 def test_argument_validation_without_a_gpu():
