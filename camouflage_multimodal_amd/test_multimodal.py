@@ -1,6 +1,6 @@
 """Inference side of the fusion path (the reference's models/multimodal/test_multimodal.py minus
-the Region-Graph GNN extraction and the matplotlib figures, which are outside the hot path --
-SURVEY 8f).  The model call is the HIP forward with ``return_attention=True``.
+the SLIC / feature extraction and the matplotlib figures, which are outside the hot path --
+SURVEY 8f; the Region-Graph GNN forward that sits between them is region_graph.py).  The model call is the HIP forward with ``return_attention=True``.
 
 Kept from the reference (file:line):
   * ``load_multimodal_model`` reads the training checkpoint dict, rebuilds the model from
@@ -62,6 +62,21 @@ def predict_from_embeddings(multimodal_model, rg_node_emb, kg_embeddings_dict, d
         "score": float(score_out.item()),
     }
     return predictions, attn, kg_ordered
+
+
+def predict_from_region_graph(multimodal_model, rg_model, graph_data, kg_embeddings_dict, device):
+    """The reference's ``predict_single_image`` [:83-152] from the region graph on: the Region-Graph GNN turns the
+    image's graph (``graph_data.x`` [Nr, 15], ``edge_index``, ``edge_attr`` as ``create_region_graph`` builds them,
+    extract_rg_embeddings.py:213-246) into node embeddings on the device [:93 -> extract_rg_embeddings.py:276-279] and
+    the fusion model consumes them without a host round trip.  ``rg_model``: a ``RegionGraphGNN`` of this package."""
+    class _OnDevice:
+        pass
+    d = _OnDevice()
+    d.x = graph_data.x.to(device); d.edge_index = graph_data.edge_index.to(device)
+    ea = getattr(graph_data, "edge_attr", None)
+    d.edge_attr = None if ea is None else ea.to(device)
+    node_emb = rg_model.extract_node_embeddings(d)
+    return predict_from_embeddings(multimodal_model, node_emb, kg_embeddings_dict, device)
 
 
 def batch_result_entry(image_name, predictions):

@@ -110,3 +110,25 @@ def test_hip_batched_graphs_equal_separate_graphs_and_unweighted_edges():
     a = m.extract_node_embeddings(x=torch.from_numpy(x).cuda(), edge_index=torch.from_numpy(ei).cuda(), edge_attr=torch.zeros(0, 1).cuda())
     b = m.extract_node_embeddings(x=torch.from_numpy(x).cuda(), edge_index=torch.from_numpy(ei).cuda(), edge_attr=torch.ones(ei.shape[1]).cuda())
     assert float((a - b).abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_graph_to_logits_on_device_equals_two_stage_inference(kg_real):
+    """predict_from_region_graph (region graph -> RG GNN -> fusion model, nothing leaves the device) against running the
+    two stages by hand through the host, the way the reference script does (test_multimodal.py:93-106)."""
+    from camouflage_multimodal_amd import RegionGraphGNN, build_multimodal_model, predict_from_embeddings, predict_from_region_graph
+    torch.manual_seed(1)
+    rgm = RegionGraphGNN().cuda().eval()
+    fm = build_multimodal_model({}).cuda().eval().set_precision("f32")
+    x, ei, ew = RO.make_graph(481, seed=3)
+
+    class Data:
+        pass
+    d = Data(); d.x = torch.from_numpy(x); d.edge_index = torch.from_numpy(ei); d.edge_attr = torch.from_numpy(ew).unsqueeze(1)
+    kg = {f"cat{i:02d}": torch.from_numpy(kg_real[i:i + 1]) for i in range(13)}
+    pred, attn, _ = predict_from_region_graph(fm, rgm, d, kg, "cuda")
+    emb = rgm.extract_node_embeddings(x=d.x.cuda(), edge_index=d.edge_index.cuda(), edge_attr=d.edge_attr.cuda()).cpu()
+    pred2, _, _ = predict_from_embeddings(fm, emb, kg, "cuda")
+    # (equal up to the summation order of the fusion model's atomically accumulated mean pools)
+    assert torch.allclose(pred["mask_logits"], pred2["mask_logits"], rtol=0, atol=1e-6) and pred["mask_pred"] == pred2["mask_pred"]
+    assert abs(pred["score"] - pred2["score"]) < 1e-6 and attn is not None
