@@ -25,7 +25,7 @@ SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_
 
 
 # every symbol include/camo_rg_gnn.h declares
-RG_SYMBOLS = ("camo_rg_workspace_bytes", "camo_rg_node_embeddings")
+RG_SYMBOLS = ("camo_rg_workspace_bytes", "camo_rg_node_embeddings", "camo_rg_build_csr")
 RG_NPARAMS = 28
 
 
@@ -78,6 +78,8 @@ def lib():
                                              vp, vp, vp, vp, vp, vp, i32, C.c_uint64, i32, vp]
     L.camo_rg_workspace_bytes.restype = sz
     L.camo_rg_workspace_bytes.argtypes = [C.POINTER(CamoRgDims), i32]
+    L.camo_rg_build_csr.restype = C.c_int
+    L.camo_rg_build_csr.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.camo_rg_node_embeddings.restype = C.c_int
     L.camo_rg_node_embeddings.argtypes = [C.POINTER(CamoRgDims), vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, vp]
     L.camo_debug_gemm.restype = C.c_int

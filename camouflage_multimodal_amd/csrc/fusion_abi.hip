@@ -891,6 +891,16 @@ int rg_check(const camo_rg_dims_t* d, int N) {
 }
 }  // namespace
 
+int camo_rg_build_csr(const int64_t* edge_index, const float* edge_weight, int32_t N, int32_t E, int32_t* scratch, int32_t* rowptr,
+                      int32_t* col, float* w, void* stream) {
+  if (N < 1 || E < 0 || (E > 0 && !edge_index) || !scratch || !rowptr || !col || !w) return fail(CAMO_E_ARG, "bad build_csr arguments");
+  // scratch: 3 N words = counts | cursor | self-loop weights
+  CK(launch_build_csr(reinterpret_cast<const long long*>(edge_index), reinterpret_cast<const long long*>(edge_index) + E, edge_weight, N, E,
+                      scratch, reinterpret_cast<float*>(scratch + 2 * (size_t)N), scratch + N, rowptr, col, w, static_cast<hipStream_t>(stream)),
+     "build csr");
+  return 0;
+}
+
 size_t camo_rg_workspace_bytes(const camo_rg_dims_t* dims, int32_t N) {
   if (rg_check(dims, N)) return 0;
   return rg_carve(*dims, N, nullptr).bytes;

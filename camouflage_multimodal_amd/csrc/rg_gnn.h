@@ -4,6 +4,12 @@
 #pragma once
 #include "common.h"
 
+// COO (src, dst int64 [E], w fp32 [E] or null) -> CSR by target with one self-loop per node (an explicit self-loop keeps
+// its weight, the others get 1).  counts, cursor: int [N] scratch; loopw: float [N] scratch; col / wout sized E + N.
+// The order of a row's edges after its leading self-loop is not deterministic (atomic slot allocation).
+int launch_build_csr(const long long* src, const long long* dst, const float* w, int N, int E, int* counts, float* loopw, int* cursor,
+                     int* rowptr, int* col, float* wout, hipStream_t stream);
+
 struct BnEval { const float* weight; const float* bias; const float* mean; const float* var; };   // BatchNorm1d, eval mode
 
 // dinv[i] = (sum of row i's weights)^-1/2, 0 for an empty / zero-weight row (gcn_norm)

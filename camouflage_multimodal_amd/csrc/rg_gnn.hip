@@ -88,7 +88,65 @@ __global__ void gcn_aggregate_kernel(const float* __restrict__ XW, const int* __
   for (int q = 0; q < CPL; ++q) { const int c = lane + 64 * q; if (c < C) out[(size_t)i * C + c] = bn_relu(acc[q] + bias[c], bn, c); }
 }
 
+// ---- CSR-by-target construction from a COO edge list (counting sort by target; one self-loop per node) ----
+// counts[i] = number of non-loop edges into i; loopw[i] = weight of an explicit self-loop of i (else stays 1)
+__global__ void csr_count_kernel(const long long* __restrict__ src, const long long* __restrict__ dst, const float* __restrict__ w,
+                                 int E, int* __restrict__ counts, float* __restrict__ loopw) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int s = (int)src[e], d = (int)dst[e];
+  if (s == d) loopw[s] = w ? w[e] : 1.0f;
+  else atomicAdd(counts + d, 1);
+}
+// one block: rowptr = exclusive scan of (counts + 1); cursor = rowptr (the first slot of a row takes the self-loop)
+__global__ __launch_bounds__(1024) void csr_scan_kernel(const int* __restrict__ counts, const float* __restrict__ loopw, int N,
+                                                        int* __restrict__ rowptr, int* __restrict__ cursor, int* __restrict__ col,
+                                                        float* __restrict__ wout) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x, per = (N + 1023) / 1024, b0 = t * per, b1 = min(N, b0 + per);
+  int s = 0;
+  for (int i = b0; i < b1; ++i) s += counts[i] + 1;
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = t ? part[t - 1] : 0;
+  for (int i = b0; i < b1; ++i) {
+    rowptr[i] = run;
+    col[run] = i; wout[run] = loopw[i];                     // the self-loop
+    cursor[i] = run + 1;
+    run += counts[i] + 1;
+  }
+  if (t == 1023) rowptr[N] = part[1023];
+}
+__global__ void csr_fill_kernel(const long long* __restrict__ src, const long long* __restrict__ dst, const float* __restrict__ w,
+                                int E, int* __restrict__ cursor, int* __restrict__ col, float* __restrict__ wout) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int s = (int)src[e], d = (int)dst[e];
+  if (s == d) return;
+  const int pos = atomicAdd(cursor + d, 1);
+  col[pos] = s; wout[pos] = w ? w[e] : 1.0f;
+}
+__global__ void csr_init_kernel(int* __restrict__ counts, float* __restrict__ loopw, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { counts[i] = 0; loopw[i] = 1.0f; }
+}
+
 }  // namespace
+
+int launch_build_csr(const long long* src, const long long* dst, const float* w, int N, int E, int* counts, float* loopw, int* cursor,
+                     int* rowptr, int* col, float* wout, hipStream_t stream) {
+  hipLaunchKernelGGL(csr_init_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, counts, loopw, N);
+  if (E > 0) hipLaunchKernelGGL(csr_count_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, src, dst, w, E, counts, loopw);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, loopw, N, rowptr, cursor, col, wout);
+  if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, src, dst, w, E, cursor, col, wout);
+  return (int)hipGetLastError();
+}
 
 int launch_gcn_dinv(const int* rowptr, const float* w, float* dinv, int N, hipStream_t stream) {
   hipLaunchKernelGGL(gcn_dinv_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, rowptr, w, dinv, N);

@@ -19,6 +19,24 @@ from . import _lib
 from .engine import _ptr, _stream_ptr
 
 
+def build_target_csr_device(num_nodes, edge_index, edge_weight=None):
+    """The same CSR as ``build_target_csr`` built by the library (``camo_rg_build_csr``: counting sort by target, four
+    small launches instead of a chain of torch index kernels); a row's edges after its leading self-loop come in no
+    particular order.  Returns (rowptr int32 [N+1], col int32 [E+N], w fp32 [E+N])."""
+    _lib.require_device(edge_index, "edge_index")
+    dev = edge_index.device
+    ei = edge_index.to(torch.int64).contiguous()
+    E = ei.shape[1]
+    ew = None if edge_weight is None else edge_weight.reshape(-1).to(torch.float32).contiguous()
+    scratch = torch.empty(3 * num_nodes, dtype=torch.int32, device=dev)
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(E + num_nodes, dtype=torch.int32, device=dev)
+    w = torch.empty(E + num_nodes, dtype=torch.float32, device=dev)
+    rc = _lib.lib().camo_rg_build_csr(_ptr(ei), _ptr(ew), num_nodes, E, _ptr(scratch), _ptr(rowptr), _ptr(col), _ptr(w), _stream_ptr())
+    _lib.check(rc, "camo_rg_build_csr")
+    return rowptr, col, w
+
+
 def build_target_csr(num_nodes, edge_index, edge_weight=None):
     """edge_index [2, E] (row 0 = source j, row 1 = target i, PyG convention), edge_weight [E] or None ->
     (rowptr int32 [N+1], col int32 [E'], w fp32 [E']) sorted by target with exactly one self-loop per node: existing
@@ -111,7 +129,7 @@ class RegionGraphGNN(nn.Module):
             raise RuntimeError(f"x of shape {tuple(x.shape)} does not match in_channels {self._dims.in_channels}")
         n = x.shape[0]
         ew = None if edge_attr is None or edge_attr.numel() == 0 else edge_attr.reshape(-1)     # :98
-        rowptr, col, w = build_target_csr(n, edge_index, ew)
+        rowptr, col, w = build_target_csr_device(n, edge_index, ew)
         x = x.detach().to(torch.float32).contiguous()
         L = _lib.lib()
         need = L.camo_rg_workspace_bytes(C.byref(self._dims), n)

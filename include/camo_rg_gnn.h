@@ -40,6 +40,14 @@ enum {
 
 size_t camo_rg_workspace_bytes(const camo_rg_dims_t* dims, int32_t N);
 
+/* The graph as the reference builds it (extract_rg_embeddings.py:215-246: edge_index [2, E] int64 with row 0 = source,
+ * row 1 = target, contiguous; edge_weight [E] fp32 or NULL) -> the CSR-by-target the kernels walk: one self-loop per
+ * node first in its row (an explicit self-loop keeps its weight, the others get weight 1 -- PyG's
+ * add_remaining_self_loops; GATConv's remove-then-add has the same structure), then the incoming edges in no
+ * particular order.  scratch: 3 N int32; rowptr [N+1]; col, w: [E + N]. */
+int camo_rg_build_csr(const int64_t* edge_index, const float* edge_weight, int32_t N, int32_t E, int32_t* scratch,
+                      int32_t* rowptr, int32_t* col, float* w, void* stream);
+
 /* Graph: CSR by TARGET node with exactly one self-loop per node already inserted (existing self-loops keep their
  * weight, added ones have weight 1 -- PyG's add_remaining_self_loops; GATConv ignores the weights):
  * rowptr [N+1], col [E] = source of each incoming edge, w [E].  Several graphs batch as one block-diagonal graph.

@@ -132,3 +132,23 @@ def test_graph_to_logits_on_device_equals_two_stage_inference(kg_real):
     # (equal up to the summation order of the fusion model's atomically accumulated mean pools)
     assert torch.allclose(pred["mask_logits"], pred2["mask_logits"], rtol=0, atol=1e-6) and pred["mask_pred"] == pred2["mask_pred"]
     assert abs(pred["score"] - pred2["score"]) < 1e-6 and attn is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 23, 500, 5000])
+def test_device_csr_builder_matches_host_builder_row_by_row(n):
+    from camouflage_multimodal_amd import build_target_csr
+    from camouflage_multimodal_amd.region_graph import build_target_csr_device
+    x, ei, ew = RO.make_graph(n, seed=n)
+    if n > 3:                                                                 # an explicit self-loop keeps its weight
+        ei = np.concatenate([ei, np.array([[3], [3]])], axis=1); ew = np.concatenate([ew, [0.25]]).astype(np.float32)
+    for weights in (ew, None):
+        eit = torch.from_numpy(ei).cuda(); ewt = None if weights is None else torch.from_numpy(weights).cuda()
+        r0, c0, w0 = [t.cpu().numpy() for t in build_target_csr(n, eit, ewt)]
+        r1, c1, w1 = [t.cpu().numpy() for t in build_target_csr_device(n, eit, ewt)]
+        assert np.array_equal(r0, r1)
+        for i in range(n):
+            a = sorted(zip(c0[r0[i]:r0[i + 1]].tolist(), w0[r0[i]:r0[i + 1]].tolist()))
+            b = sorted(zip(c1[r1[i]:r1[i + 1]].tolist(), w1[r1[i]:r1[i + 1]].tolist()))
+            assert a == b, i
+            assert c1[r1[i]] == i                                             # the self-loop leads its row
