@@ -183,6 +183,13 @@ def main():
         ms, n, fl = C.c_double(), C.c_int32(), C.c_double()
         _lib.check(L.camo_prof_end(C.byref(ms), C.byref(n), C.byref(fl)), "camo_prof_end")
         alg = sum(algorithmic_flops(batches[i % len(batches)][1]) for i in range(args.warmup, args.warmup + k))
+        # An event pair also times its own marker packets: an EMPTY pair on the same stream is reported next to the
+        # figure (not subtracted: it over-corrects -- rocprofv3's kernel-only average, profiles/, sits in between).
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+        for a, b in pairs:
+            a.record(); b.record()
+        torch.cuda.synchronize()
+        ev_us = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)[len(pairs) // 2]
         gemm_s = ms.value * 1e-3
         achieved = alg / gemm_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
@@ -203,6 +210,7 @@ def main():
                 "kernel": kname + ("<bf16-resident operands>" if args.precision == "bf16" else "<f32>"),
                 "launches_per_step": round(n.value / k, 1),
                 "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
+                "empty_event_pair_us": round(ev_us, 2),
                 "kernel_ms_per_step": round(ms.value / k, 4),
                 "algorithmic_gflop_per_step": round(alg / k / 1e9, 3),
                 "executed_gflop_per_step": round(fl.value / k / 1e9, 3),
