@@ -133,7 +133,7 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
       h.Wo1 = c.take<us>(H * H); h.Wo2 = c.take<us>(H * H); h.W1 = c.take<us>(2 * H * H); h.W2 = c.take<us>(2 * H * H);
       h.W1T = c.take<us>(2 * H * H); h.W2T = c.take<us>(2 * H * H); h.Wo1T = c.take<us>(H * H); h.Wo2T = c.take<us>(H * H);
       h.WcRgT = c.take<us>(3 * H * H); h.WcKgT = c.take<us>(3 * H * H);
-      h.H1 = c.take<us>((size_t)T * 2 * H); h.H2 = c.take<us>(TK * 2 * H);
+      h.H1 = c.take<us>(Tp * 2 * H); h.H2 = c.take<us>(TKp * 2 * H);      // (padded: they double as weight-gradient operands)
     }
   } else {
     const size_t F = H / 2, Fh = F / 2, Dc = (size_t)d.rg_dim + d.kg_dim;
@@ -381,9 +381,9 @@ int forward_nodes16(const camo_dims_t& d, const float* const* P, const float* rg
     castT(P[CAMO_P_A2_IN_W], h.WcKgT, H, H, 3 * H, 0); castT(P[CAMO_P_A1_IN_W] + HH, h.WcKgT, 2 * H, H, 3 * H, H);
     const size_t t = T, tk = TK;
     pad(h.X, t, w.Tp, D); pad(h.R, t, w.Tp, H); pad(h.O, t, w.Tp, H); pad(h.Y, t, w.Tp, H); pad(h.dH1, t, w.Tp, 2 * H);
-    pad(h.dU, t, w.Tp, H); pad(h.dQKV, t, w.Tp, 3 * H); pad(h.dR, t, w.Tp, H);
+    pad(h.dU, t, w.Tp, H); pad(h.dQKV, t, w.Tp, 3 * H); pad(h.dR, t, w.Tp, H); pad(h.H1, t, w.Tp, 2 * H);
     pad(h.KG, tk, w.TKp, Dk); pad(h.G, tk, w.TKp, H); pad(h.O2, tk, w.TKp, H); pad(h.Y2, tk, w.TKp, H); pad(h.dH2, tk, w.TKp, 2 * H);
-    pad(h.dU2, tk, w.TKp, H); pad(h.dQKVkg, tk, w.TKp, 3 * H); pad(h.dG, tk, w.TKp, H);
+    pad(h.dU2, tk, w.TKp, H); pad(h.dQKVkg, tk, w.TKp, 3 * H); pad(h.dG, tk, w.TKp, H); pad(h.H2, tk, w.TKp, 2 * H);
     CK(launch_prep(pb, st), "prep (clear + bf16 casts)");
   }
   GB16 g(drop, st);
@@ -445,29 +445,44 @@ int backward_nodes16(const camo_dims_t& d, const float* const* P, float* const* 
   const int H = d.hidden_dim, D = d.rg_dim, Dk = d.kg_dim, TK = B * Nk, nh = d.num_heads;
   const size_t HH = (size_t)H * H;
   const Ws::H16& h = w.h;
-  {
+  // dH1 = mask(H1) * bcast(dHm1) / n is needed only as a GEMM operand.  At hidden_dim 256 and B <= 32 the whole-row
+  // kernel builds it while staging (GF_A_VIRT) from the bf16 activation mask and the per-sample gradient rows, for both
+  // products that read it; otherwise relu_bcast_bwd writes it out.
+  const bool virt = H == 256 && B <= 32;
+  if (!virt) {
     BcastSeg s0{nullptr, w.dHm1, 2 * H, row_sample, inv_nr, 0, nullptr, T, h.dH1, h.H1};
     BcastSeg s1{nullptr, w.dHm2, 2 * H, nullptr, nullptr, Nk, nullptr, TK, h.dH2, h.H2};
     CK(launch_relu_bcast_bwd(s0, s1, 2 * H, drop.scale, st), "relu bcast bwd");
   }
+  auto make_virt = [&](Gemm16Prob& p, const float* g_rows, bool rg_side) {
+    p.flags |= GF_A_VIRT; p.virt_g = g_rows; p.ldg = 2 * H; p.aux_scale = drop.scale;
+    if (rg_side) { p.row_sample = row_sample; p.inv_nr = inv_nr; p.uniform_n = 0; } else { p.row_sample = nullptr; p.inv_nr = nullptr; p.uniform_n = Nk; }
+    if (p.flags & GF_A_KMAJOR) p.ldc16 = B;               // (sample count of a weight-gradient problem)
+  };
   GB16 g(drop, st);
   // first FFN layer: dY = bcast(dpool)/n + dH1.W1 ; dW1 += dH1^T.Y -- and, at hidden_dim 256, the LayerNorm backward
   // dY -> dU (+ dgamma, dbeta) as the epilogue of the dY product (whole-row tiles)
   if (H == 256) {
-    Gemm16Prob& p1 = g.nt(h.dH1, 2 * H, h.W1T, 2 * H, nullptr, w.dU, H, h.dU, H, T, H, 2 * H);
+    Gemm16Prob& p1 = g.nt(virt ? h.H1 : h.dH1, 2 * H, h.W1T, 2 * H, nullptr, w.dU, H, h.dU, H, T, H, 2 * H);
     set_bcast(p1, w.dcomb, 2 * H, row_sample, inv_nr, 0);
     p1.ln_mode = 2; p1.ln_gamma = P[CAMO_P_LN1_W]; p1.ln_stats = w.st1; p1.ln_x = w.U;
     p1.ln_dgamma = Gr[CAMO_P_LN1_W]; p1.ln_dbeta = Gr[CAMO_P_LN1_B];
-    Gemm16Prob& p2 = g.nt(h.dH2, 2 * H, h.W2T, 2 * H, nullptr, w.dU2, H, h.dU2, H, TK, H, 2 * H);
+    if (virt) make_virt(p1, w.dHm1, true);
+    Gemm16Prob& p2 = g.nt(virt ? h.H2 : h.dH2, 2 * H, h.W2T, 2 * H, nullptr, w.dU2, H, h.dU2, H, TK, H, 2 * H);
     set_bcast(p2, w.dcomb + H, 2 * H, nullptr, nullptr, Nk);
     p2.ln_mode = 2; p2.ln_gamma = P[CAMO_P_LN2_W]; p2.ln_stats = w.st2; p2.ln_x = w.U2;
     p2.ln_dgamma = Gr[CAMO_P_LN2_W]; p2.ln_dbeta = Gr[CAMO_P_LN2_B];
+    if (virt) make_virt(p2, w.dHm2, false);
   } else {
     set_bcast(g.nt(h.dH1, 2 * H, h.W1T, 2 * H, nullptr, w.dY, H, nullptr, 0, T, H, 2 * H), w.dcomb, 2 * H, row_sample, inv_nr, 0);
     set_bcast(g.nt(h.dH2, 2 * H, h.W2T, 2 * H, nullptr, w.dY2, H, nullptr, 0, TK, H, 2 * H), w.dcomb + H, 2 * H, nullptr, nullptr, Nk);
   }
-  g.tn(h.dH1, 2 * H, h.Y, H, Gr[CAMO_P_F1_W0], H, Gr[CAMO_P_F1_B0], 2 * H, H, T);
-  g.tn(h.dH2, 2 * H, h.Y2, H, Gr[CAMO_P_F2_W0], H, Gr[CAMO_P_F2_B0], 2 * H, H, TK);
+  {
+    Gemm16Prob& t1 = g.tn(virt ? h.H1 : h.dH1, 2 * H, h.Y, H, Gr[CAMO_P_F1_W0], H, Gr[CAMO_P_F1_B0], 2 * H, H, T);
+    if (virt) make_virt(t1, w.dHm1, true);
+    Gemm16Prob& t2 = g.tn(virt ? h.H2 : h.dH2, 2 * H, h.Y2, H, Gr[CAMO_P_F2_W0], H, Gr[CAMO_P_F2_B0], 2 * H, H, TK);
+    if (virt) make_virt(t2, w.dHm2, false);
+  }
   CK(g.run(), "ffn layer 0 bwd");
   if (H != 256) {
     LnBwdSeg s0{w.U, w.dY, w.st1, P[CAMO_P_LN1_W], w.dU, Gr[CAMO_P_LN1_W], Gr[CAMO_P_LN1_B], T, h.dU};

@@ -13,7 +13,8 @@ enum : int {
   GF_RES_BCAST = 16,  // residual row = res[sample(row), col] * inv_n(sample(row)); sample(): see GemmProb
   GF_SIGMOID = 32,    // v = 1/(1+exp(-v))                   (last)
   GF_A_KMAJOR = 64,   // A element (m,k) at A[k*lda + m] instead of A[m*lda + k]
-  GF_B_KMAJOR = 128   // B element (k,n) at B[k*ldb + n] instead of B[n*ldb + k]
+  GF_B_KMAJOR = 128,  // B element (k,n) at B[k*ldb + n] instead of B[n*ldb + k]
+  GF_A_VIRT = 256     // gemm16 only: A is the ReLU/dropout mask-broadcast gradient built on the fly (Gemm16Prob::virt_g)
 };
 
 // C[m,n] (+)= epi( sum_k A(m,k) * B(k,n) + bias[n] ) (+ res[m,n])

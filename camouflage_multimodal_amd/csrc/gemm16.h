@@ -41,6 +41,11 @@ struct Gemm16Prob {
   //                         du = LN_backward(dy) -> C (fp32) and C16 (bf16); ln_dgamma += sum dy*xhat, ln_dbeta += sum dy
   int ln_mode;
   const float* ln_gamma; const float* ln_beta; float* ln_stats; const float* ln_x; float* ln_dgamma; float* ln_dbeta;
+  // GF_A_VIRT (whole-row NT and TN problems of a launch that contains whole-row problems): the A operand is not read
+  // but built while staging:  A[t][c] = act[t][c] > 0 ? virt_g[sample(t)][c] * inv_n(sample(t)) * aux_scale : 0,
+  // act = the bf16 tensor passed as A (the forward's post-ReLU/dropout activation, rows padded and cleared like any
+  // TN operand), rounded to bf16 exactly as relu_bcast_bwd would have written it.  sample(): as for GF_RES_BCAST.
+  const float* virt_g; int ldg;
   // filled by the launcher
   int tiles_n, ksplit, kchunk, tile_begin;
 };

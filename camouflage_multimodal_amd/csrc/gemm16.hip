@@ -39,6 +39,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct Stage { u32x4 a[2], b[4]; };
 
+// act chunk (8 bf16) + 8 gradient values -> 8 bf16 of (act > 0 ? g * scale : 0)
+__device__ __forceinline__ u32x4 virt_chunk(u32x4 act, float4 g0, float4 g1, float scale) {
+  auto sel = [&](uint32_t bits, float g) { return __uint_as_float(bits) > 0.f ? g * scale : 0.f; };
+  u32x4 o;
+  o.x = pack2(sel(act.x << 16, g0.x), sel(act.x & 0xFFFF0000u, g0.y));
+  o.y = pack2(sel(act.y << 16, g0.z), sel(act.y & 0xFFFF0000u, g0.w));
+  o.z = pack2(sel(act.z << 16, g1.x), sel(act.z & 0xFFFF0000u, g1.y));
+  o.w = pack2(sel(act.w << 16, g1.z), sel(act.w & 0xFFFF0000u, g1.w));
+  return o;
+}
+
 __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
@@ -47,14 +58,14 @@ __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
 // gload is unconditional (tile index clamped into the block's range), tiles past `nt` are reloads of the
 // last tile that get written to LDS and never multiplied.
 #define G16_PIPELINE_LOOP                                                                      \
-  _Pragma("unroll") for (int j = 0; j < PIPE; ++j) gload(st[j], j);                            \
-  sstore(st[0], 0);                                                                            \
-  gload(st[0], PIPE);                                                                          \
+  _Pragma("unroll") for (int j = 0; j < PIPE; ++j) gloadi(j, j);                               \
+  sstorei(0, 0);                                                                               \
+  gloadi(0, PIPE);                                                                             \
   __syncthreads();                                                                             \
   for (int t = 0; t < nt; t += PIPE) {                                                         \
     _Pragma("unroll") for (int j = 0; j < PIPE; ++j) {                                         \
-      sstore(st[(j + 1) % PIPE], (j + 1) & 1);                                                 \
-      gload(st[(j + 1) % PIPE], t + j + 1 + PIPE);                                             \
+      sstorei((j + 1) % PIPE, (j + 1) & 1);                                                    \
+      gloadi((j + 1) % PIPE, t + j + 1 + PIPE);                                                \
       if (t + j < nt) compute(j & 1);                                                          \
       __syncthreads();                                                                         \
     }                                                                                          \
@@ -130,6 +141,8 @@ __device__ __forceinline__ void body_nt(const Gemm16Batch& gb, const Gemm16Prob&
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[1], 0, 0, 0);
     }
   };
+  auto gloadi = [&](int j, int kt) { gload(st[j], kt); };
+  auto sstorei = [&](int j, int buf) { sstore(st[j], buf); };
   G16_PIPELINE_LOOP
 
   // ---- epilogue.  C^T orientation: lane&31 = output row, registers 4g..4g+3 = columns c0..c0+3,
@@ -219,7 +232,7 @@ __device__ __forceinline__ void body_nt(const Gemm16Batch& gb, const Gemm16Prob&
 }
 
 // ------------------------------------------------------------------------------------------ TN
-template <int PIPE>
+template <int PIPE, bool VIRT>
 __device__ __forceinline__ void body_tn(const Gemm16Prob& P, int m0, int n0, int kt0, int nt, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
@@ -251,8 +264,20 @@ __device__ __forceinline__ void body_tn(const Gemm16Prob& P, int m0, int n0, int
   const short one = (short)0x3F80;
   const bf16x8 ones = {one, one, one, one, one, one, one, one};
   Stage st[PIPE];
+  int sa[PIPE][2];                        // VIRT: sample of each staged A row
+  // VIRT: the tile's 64 columns of the scaled per-sample gradient rows live in LDS behind the two stage buffers
+  float* gs = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);
+  if constexpr (VIRT) {
+    const int ns = P.uniform_n > 0 && !P.row_sample ? (P.K + P.uniform_n - 1) / P.uniform_n : P.ldc16;   // ldc16 carries the sample count
+    for (int i = tid; i < ns * 64; i += 256) {
+      const int sm = i >> 6, f = i & 63, c = min(m0 + f, M - 1);
+      const float inv = P.row_sample ? P.inv_nr[sm] : 1.0f / (float)P.uniform_n;
+      gs[i] = P.virt_g[(size_t)sm * P.ldg + c] * inv * P.aux_scale;
+    }
+    __syncthreads();
+  }
 
-  auto gload = [&](Stage& r, int kt) {
+  auto gload = [&](Stage& r, int (&srow)[2], int kt) {
     const int k = kt0 + min(kt, nt - 1);                             // wave-uniform
     const char* a = Ab + (size_t)k * astep;
     const char* b = Bb + (size_t)k * bstep;
@@ -260,11 +285,25 @@ __device__ __forceinline__ void body_tn(const Gemm16Prob& P, int m0, int n0, int
     for (int i = 0; i < 2; ++i) r.a[i] = *reinterpret_cast<const u32x4*>(a + goa[i]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) r.b[i] = *reinterpret_cast<const u32x4*>(b + gob[i]);
+    if constexpr (VIRT) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int node = min(k * BK + ((tid + 256 * i) >> 3), P.K - 1);
+        srow[i] = P.row_sample ? P.row_sample[node] : node / P.uniform_n;
+      }
+    }
   };
-  auto sstore = [&](const Stage& r, int buf) {
+  auto sstore = [&](const Stage& r, const int (&srow)[2], int buf) {
     char* base = smem + buf * BUF_BYTES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(base + la[i]) = r.a[i];
+    for (int i = 0; i < 2; ++i) {
+      u32x4 a = r.a[i];
+      if constexpr (VIRT) {
+        const float* g = gs + srow[i] * 64 + 8 * ((tid + 256 * i) & 7);
+        a = virt_chunk(a, *reinterpret_cast<const float4*>(g), *reinterpret_cast<const float4*>(g + 4), 1.0f);
+      }
+      *reinterpret_cast<u32x4*>(base + la[i]) = a;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(base + lb[i]) = r.b[i];
   };
@@ -290,6 +329,8 @@ __device__ __forceinline__ void body_tn(const Gemm16Prob& P, int m0, int n0, int
       if (do_bsum) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, accb, 0, 0, 0);   // row sums of dy^T
     }
   };
+  auto gloadi = [&](int j, int kt) { gload(st[j], sa[j], kt); };
+  auto sstorei = [&](int j, int buf) { sstore(st[j], sa[j], buf); };
   G16_PIPELINE_LOOP
 
   // C orientation: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -323,9 +364,9 @@ constexpr int RM = 32, RN = 256;
 constexpr int A_ROW_BYTES = RM * PM;                 // 4096
 constexpr int ROW_BUF_BYTES = (RM + RN) * PM;        // 36864 per stage
 constexpr int TPR = RN + 4;                          // fp32 tile pitch of the column passes
-struct StageR { u32x4 a; u32x4 b[8]; };
+struct StageR { u32x4 a; u32x4 b[8]; float4 g0, g1; };     // g0, g1: VIRT only (the 8 gradient values of the A chunk)
 
-template <int PIPE>
+template <int PIPE, bool VIRT>
 __device__ __forceinline__ void body_nt_row(const Gemm16Batch& gb, const Gemm16Prob& P, int m0, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int M = P.M, N = RN;
@@ -351,17 +392,27 @@ __device__ __forceinline__ void body_nt_row(const Gemm16Batch& gb, const Gemm16P
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   StageR st[PIPE];
+  // VIRT: this thread's A row is node min(m0 + tid/8, M-1): its sample's gradient row and scale are loop-invariant
+  const float* vg = nullptr; float vscale = 0.f;
+  if constexpr (VIRT) {
+    const int node = min(m0 + (tid >> 3), M - 1);
+    const int sm = P.row_sample ? P.row_sample[node] : node / P.uniform_n;
+    vg = P.virt_g + (size_t)sm * P.ldg + 8 * (tid & 7);
+    vscale = (P.row_sample ? P.inv_nr[sm] : 1.0f / (float)P.uniform_n) * P.aux_scale;
+  }
   auto gload = [&](StageR& r, int kt) {
     const int k = min(kt, nt - 1);
     const char* a = Ab + (size_t)k * (BK * 2);
     const char* b = Bb + (size_t)k * (BK * 2);
     r.a = *reinterpret_cast<const u32x4*>(a + goa);
+    if constexpr (VIRT) { r.g0 = *reinterpret_cast<const float4*>(vg + k * BK); r.g1 = *reinterpret_cast<const float4*>(vg + k * BK + 4); }
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.b[i] = *reinterpret_cast<const u32x4*>(b + gob[i]);
   };
   auto sstore = [&](const StageR& r, int buf) {
     char* base = smem + buf * ROW_BUF_BYTES;
-    *reinterpret_cast<u32x4*>(base + la) = r.a;
+    if constexpr (VIRT) *reinterpret_cast<u32x4*>(base + la) = virt_chunk(r.a, r.g0, r.g1, vscale);
+    else *reinterpret_cast<u32x4*>(base + la) = r.a;
 #pragma unroll
     for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(base + lb[i]) = r.b[i];
   };
@@ -383,6 +434,8 @@ __device__ __forceinline__ void body_nt_row(const Gemm16Batch& gb, const Gemm16P
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[1], 0, 0, 0);
     }
   };
+  auto gloadi = [&](int j, int kt) { gload(st[j], kt); };
+  auto sstorei = [&](int j, int buf) { sstore(st[j], buf); };
   G16_PIPELINE_LOOP
 
   // ---- epilogue: lane (l31, h) holds row m0 + l31, columns 64 w + 32 j + 8 g + 4 h + i (register 4 g + i of acc[j])
@@ -530,7 +583,11 @@ __global__ __launch_bounds__(256, ROWS ? 2 : 3) void gemm16_kernel(const Gemm16B
   const Gemm16Prob& P = gb.p[pi];
   int t = bid - P.tile_begin;
   if constexpr (ROWS) {
-    if (P.ln_mode) { body_nt_row<PIPE>(gb, P, t * RM, smem_raw); return; }
+    if (P.ln_mode) {
+      if (P.flags & GF_A_VIRT) body_nt_row<PIPE, true>(gb, P, t * RM, smem_raw);
+      else                     body_nt_row<PIPE, false>(gb, P, t * RM, smem_raw);
+      return;
+    }
   }
   // Split-K problems number their blocks K-slice-major: the XCD remap above hands an XCD a contiguous run of block
   // ids, i.e. (with ~8 slices) all output tiles of ONE K slice -- the tiles that re-read the same rows of dy and x
@@ -541,7 +598,10 @@ __global__ __launch_bounds__(256, ROWS ? 2 : 3) void gemm16_kernel(const Gemm16B
   if (P.flags & GF_A_KMAJOR) {
     const int ktiles = (P.K + 127) / 128 * 2;                 // K rounded up to 128 rows, in 64-row tiles
     const int per = P.kchunk / BK, kt0 = ks * per;
-    body_tn<PIPE>(P, tm * BM, tn * BN, kt0, min(per, ktiles - kt0), smem_raw);
+    if constexpr (ROWS) {
+      if (P.flags & GF_A_VIRT) { body_tn<PIPE, true>(P, tm * BM, tn * BN, kt0, min(per, ktiles - kt0), smem_raw); return; }
+    }
+    body_tn<PIPE, false>(P, tm * BM, tn * BN, kt0, min(per, ktiles - kt0), smem_raw);
   } else {
     body_nt<PIPE>(gb, P, tm * BM, tn * BN, smem_raw);
   }
@@ -581,8 +641,13 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
       }
       if (akm) {
         if ((p.M & 7) || (p.N & 7) || p.M < 8 || p.N < 8 || !p.C || p.C16 || p.bias || p.res ||
-            (p.flags & ~(GF_A_KMAJOR | GF_B_KMAJOR | GF_ATOMIC)))
+            (p.flags & ~(GF_A_KMAJOR | GF_B_KMAJOR | GF_ATOMIC | GF_A_VIRT)))
           return (int)hipErrorInvalidValue;
+        if (p.flags & GF_A_VIRT) {     // sample count rides in ldc16 (unused by TN); its gradient slice must fit the LDS spare
+          const int ns = p.row_sample ? p.ldc16 : (p.uniform_n > 0 ? (p.K + p.uniform_n - 1) / p.uniform_n : 0);
+          if (!p.virt_g || ns < 1 || ns * 256 > 2 * ROW_BUF_BYTES - 2 * BUF_BYTES || (!p.row_sample && p.uniform_n < 1))
+            return (int)hipErrorInvalidValue;
+        }
         const int ktiles = (p.K + 127) / 128 * 2;
         const int per = ktiles < kcap ? ktiles : kcap;                       // even
         p.kchunk = per * BK;
@@ -599,8 +664,14 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
     }
     if (kcap_env || total >= 200 || kcap <= dev_kmin()) break;
   }
-  bool has_tn = false, has_rows = false;
-  for (int i = 0; i < gb.n; ++i) { has_tn = has_tn || (gb.p[i].flags & GF_A_KMAJOR); has_rows = has_rows || gb.p[i].ln_mode; }
+  bool has_tn = false, has_rows = false, has_virt = false;
+  for (int i = 0; i < gb.n; ++i) {
+    has_tn = has_tn || (gb.p[i].flags & GF_A_KMAJOR); has_rows = has_rows || gb.p[i].ln_mode;
+    has_virt = has_virt || (gb.p[i].flags & GF_A_VIRT);
+    if ((gb.p[i].flags & GF_A_VIRT) && !(gb.p[i].flags & GF_A_KMAJOR) && (!gb.p[i].ln_mode || !gb.p[i].virt_g || (gb.p[i].ldg & 3)))
+      return (int)hipErrorInvalidValue;
+  }
+  if (has_virt && !has_rows) return (int)hipErrorInvalidValue;      // the virtual operand lives in the whole-row kernel only
   const size_t lds = has_rows ? 2 * ROW_BUF_BYTES : (has_tn ? 2 * BUF_BYTES : 2 * NT_BUF_BYTES);     // 72 / 64 / 48 KB
   static const bool attr_ok = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);

@@ -104,12 +104,14 @@ def test_hip_batched_graphs_equal_separate_graphs_and_unweighted_edges():
     off = np.cumsum([0] + [g[0].shape[0] for g in gs])
     xb = np.concatenate([g[0] for g in gs]); eib = np.concatenate([g[1] + off[i] for i, g in enumerate(gs)], axis=1); ewb = np.concatenate([g[2] for g in gs])
     ob = m.extract_node_embeddings(x=torch.from_numpy(xb).cuda(), edge_index=torch.from_numpy(eib).cuda(), edge_attr=torch.from_numpy(ewb).cuda())
-    assert float((ob - torch.cat(outs)).abs().max()) < 1e-6                  # block-diagonal batch (PyG Batch) == per graph
+    # block-diagonal batch (PyG Batch) == per graph, up to the summation order of a row's edges (the device CSR builder
+    # allocates their slots with atomics)
+    assert float((ob - torch.cat(outs)).abs().max()) < 1e-5 * max(float(ob.abs().max()), 1.0)
     # edge_attr with no elements -> unweighted GCN (extract_rg_embeddings.py:98)
     x, ei, _ = gs[0]
     a = m.extract_node_embeddings(x=torch.from_numpy(x).cuda(), edge_index=torch.from_numpy(ei).cuda(), edge_attr=torch.zeros(0, 1).cuda())
     b = m.extract_node_embeddings(x=torch.from_numpy(x).cuda(), edge_index=torch.from_numpy(ei).cuda(), edge_attr=torch.ones(ei.shape[1]).cuda())
-    assert float((a - b).abs().max()) == 0.0
+    assert float((a - b).abs().max()) < 1e-5 * max(float(a.abs().max()), 1.0)
 
 
 @pytest.mark.gpu
