@@ -453,3 +453,36 @@ def test_bf16_schedules_agree_on_boundary_batches(nrs, kg_real, monkeypatch):
     for k in ga:
         scale = max(float(np.abs(gb[k]).max()), 1e-8)
         assert float(np.abs(ga[k] - gb[k]).max()) <= 6e-3 * scale, (k, float(np.abs(ga[k] - gb[k]).max()), scale)
+
+
+def test_bf16_dropin_autograd_loop_equals_native_packed_step():
+    """Drop-in mode in bf16 precision (per-sample B = 1 forward through autograd, torch losses, loss.backward()): the
+    bf16-resident schedule at T = Nr of a single sample, its fused LayerNorm launches and virtual operand included.
+    The summed per-sample gradients must equal the gradients of one native packed step on the same samples (dropout
+    off: the mask index of an element depends on its position in the packed batch)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from camouflage_multimodal_amd import AggressiveFocalLoss, NativeTrainer
+    cfg = OP.full_cfg(dict(dropout=0.0))
+    nrs = [303, 64, 500, 1]
+    rg = [OP.make_rg(n, 128, seed=800 + i) for i, n in enumerate(nrs)]
+    kg = np.stack([OP.make_kg(13, 128, seed=60 + i) for i in range(len(nrs))])
+    y, e, s = OP.make_labels(len(nrs), seed=12)
+    m = make_model(cfg, 5, "bf16").train()
+    focal, bce, mse = AggressiveFocalLoss(0.75, 3.0), nn.BCEWithLogitsLoss(), nn.MSELoss()
+    m.zero_grad()
+    for b in range(len(nrs)):
+        yl = torch.tensor([int(y[b])]).cuda(); el = torch.tensor([float(e[b])]).cuda(); sl = torch.tensor([float(s[b])]).cuda()
+        mo, io, eo, so = m(torch.from_numpy(rg[b])[None].cuda(), torch.from_numpy(kg[b])[None, :, None, :].cuda())
+        loss = focal(mo, yl) * 3.0 + F.cross_entropy(io, yl) + bce(eo.squeeze(1), el) * 0.5 + mse(so.squeeze(1), sl) * 0.3
+        loss.backward()
+    drop_in = {k: t2n(p.grad).copy() for k, p in m.named_parameters()}
+    m2 = make_model(cfg, 5, "bf16").train()
+    tr = NativeTrainer(m2, keep_grads=True, max_norm=1e9)          # (no clipping: compare raw gradients)
+    tr.step(torch.from_numpy(np.concatenate(rg)).cuda(), nrs, torch.from_numpy(kg).cuda(), torch.from_numpy(y), torch.from_numpy(e),
+            torch.from_numpy(s))
+    tr.engine.ensure_flat_grads(attach=True)
+    for k, p in m2.named_parameters():
+        want = t2n(p.grad)
+        scale = max(float(np.abs(want).max()), 1e-8)
+        assert float(np.abs(drop_in[k] - want).max()) <= 6e-3 * scale, (k, float(np.abs(drop_in[k] - want).max()), scale)
