@@ -14,13 +14,14 @@ from .losses import AggressiveFocalLoss, multitask_loss  # noqa: F401
 from .optim import FusedClipAdamW, cosine_warm_restarts_lr  # noqa: F401
 from .test_multimodal import (build_ordered_kg_tensor, load_multimodal_model, predict_embedding_directory,  # noqa: F401
                               predict_from_embeddings, predict_from_region_graph)
-from .train_multimodal import (NativeTrainer, calculate_f1_score, collate_fn, fit, pack_samples,  # noqa: F401
-                               train_epoch_fixed, validate_fixed)
+from .train_multimodal import (NativeTrainer, SmartMultimodalDataset, calculate_f1_score, collate_fn,  # noqa: F401
+                               extract_label_from_mask, fit, pack_samples, train_epoch_fixed, train_multimodal_fixed,
+                               validate_fixed)
 
 from .region_graph import RegionGraphGNN, build_target_csr  # noqa: F401,E402
 
 __all__ = ["RegionGraphGNN", "build_target_csr", "build_multimodal_model", "MultimodalCamouflageDetector", "CrossAttentionFusion", "LateFusion",
            "AggressiveFocalLoss", "multitask_loss", "FusedClipAdamW", "cosine_warm_restarts_lr", "NativeTrainer",
            "calculate_f1_score", "collate_fn", "fit", "pack_samples", "train_epoch_fixed", "validate_fixed",
-           "EmbeddingMatcher", "DeviceResidentDataset", "load_multimodal_model", "build_ordered_kg_tensor",
+           "EmbeddingMatcher", "DeviceResidentDataset", "SmartMultimodalDataset", "extract_label_from_mask", "train_multimodal_fixed", "load_multimodal_model", "build_ordered_kg_tensor",
            "predict_from_embeddings", "predict_from_region_graph", "predict_embedding_directory"]

@@ -19,7 +19,6 @@
 // counter hash.  Conditions: head_dim == 32, Nk <= 16; kg2rg additionally Nr <= 16*4*MAXT.
 #include "attn.h"
 
-#include <cstdlib>
 
 namespace {
 

@@ -18,10 +18,8 @@
 #include <string>
 
 #include "../../include/camo_fusion.h"
-#include <cstdlib>
 
 #include "attn.h"
-#include "fused.h"
 #include "gemm.h"
 #include "gemm16.h"
 #include "misc.h"
@@ -31,6 +29,9 @@
 namespace {
 
 thread_local std::string g_err;
+// testing hook (camo_debug_set_option): -1 = choose the schedule from the configuration, 0 = never take the bf16-resident
+// schedule.  Set by tests that A/B the schedules in one process; never read from the environment.
+int g_opt_sched16 = -1;
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 int fail_hip(int e, const char* where) {
@@ -57,13 +58,10 @@ struct Carver {
 struct Ws {
   // zeroed once per forward: [ means | dfused | dKV ] (accumulated into by atomics)
   float* zero_base; size_t zero_bytes;
-  unsigned int* sync;   // 16 words inside the zero block: [0..2] forward tail barrier, [4..6] backward tail barrier
   // forward (saved for backward)
   float *R, *G, *Q, *KV2, *KV, *Q2, *P, *P2, *O, *O2, *U, *U2, *st1, *st2, *Y, *Y2, *H1, *H2;
   float *means, *Ymean, *H1mean, *Y2mean, *H2mean; size_t means_n;
   float *comb, *F1, *fused, *hid, *a2;
-  // bf16 shadow copies of the node-level weights for the fused forward: Wrg | Wq | Wkv2 | Wo | W1
-  unsigned short *sWrg, *sWq, *sWkv2, *sWo, *sW1;
   // backward scratch
   float *dlog, *dhid, *dfused, *dF1, *dcomb, *dHm1, *dHm2, *da2;
   float *dH1, *dH2, *dY, *dY2, *dU, *dU2, *dO, *dO2, *dQ, *dKV, *dQ2, *dKV2, *dS2, *dR, *dG;
@@ -98,11 +96,10 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
     w.H1 = c.take<float>(T * 2 * H); w.H2 = c.take<float>(TK * 2 * H);
     w.means_n = (size_t)B * 6 * H;
     {   // one contiguous block so a single memset clears every atomically-accumulated buffer
-      const size_t nz = w.means_n + (size_t)B * H + TK * 2 * H + 16;
+      const size_t nz = w.means_n + (size_t)B * H + TK * 2 * H;
       float* z = c.take<float>(nz);
       w.zero_base = z; w.zero_bytes = nz * sizeof(float);
       w.means = z; w.dfused = z ? z + w.means_n : nullptr; w.dKV = z ? w.dfused + (size_t)B * H : nullptr;
-      w.sync = z ? reinterpret_cast<unsigned int*>(w.dKV + TK * 2 * H) : nullptr;
     }
     if (w.means) { w.Ymean = w.means; w.H1mean = w.Ymean + B * H; w.Y2mean = w.H1mean + B * 2 * H; w.H2mean = w.Y2mean + B * H; }
     w.comb = c.take<float>(B * 2 * H); w.F1 = c.take<float>(B * H); w.fused = c.take<float>(B * H);
@@ -118,8 +115,6 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
     w.dQ2 = c.take<float>(TK * H); w.dKV2 = c.take<float>(T * 2 * H);
     w.dS2 = c.take<float>(T * nh * Nk);
     w.dR = c.take<float>(T * H); w.dG = c.take<float>(TK * H);
-    w.sWrg = c.take<unsigned short>(H * (size_t)d.rg_dim); w.sWq = c.take<unsigned short>(H * H);
-    w.sWkv2 = c.take<unsigned short>(2 * H * H); w.sWo = c.take<unsigned short>(H * H); w.sW1 = c.take<unsigned short>(2 * H * H);
     {
       typedef unsigned short us;
       const size_t Tp = ((size_t)T + 127) / 128 * 128, TKp = (TK + 127) / 128 * 128, D = d.rg_dim, Dk = d.kg_dim;
@@ -183,7 +178,6 @@ int check_dims(const camo_dims_t* d, int B, int T, int Nk) {
 struct GB {
   GemmBatch b;
   int prec; hipStream_t st;
-  TailPlan* plan = nullptr;   // when set, run() appends the batch to the plan as one phase instead of launching it
   GB(const DropCfg& d, int prec_, hipStream_t st_) : prec(prec_), st(st_) { std::memset(&b, 0, sizeof(b)); b.drop = d; }
   GemmProb& add(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K, int flags) {
     GemmProb& p = b.p[b.n++];
@@ -210,33 +204,11 @@ struct GB {
   }
   int run() {
     if (b.n == 0) return 0;
-    if (plan) {
-      if (plan->nphase >= TAIL_MAXPH || plan->n + b.n > TAIL_MAXP) return (int)hipErrorInvalidValue;
-      plan->phase_begin[plan->nphase] = plan->n;
-      for (int i = 0; i < b.n; ++i) plan->p[plan->n++] = b.p[i];
-      plan->phase_begin[++plan->nphase] = plan->n;
-      b.n = 0;
-      return 0;
-    }
     int e = launch_gemm_batch(b, prec, st);
     b.n = 0;
     return e;
   }
 };
-// The per-sample tail as ONE persistent launch with device-wide barriers between its layers: opt-in
-// (CAMO_TAIL_PERSIST=1).  Measured on MI355X it LOSES to the separate launches -- forward 58 us against 49 us,
-// backward 113 us against 30 us at B = 16: the release/acquire fences of a barrier write back and invalidate the
-// XCD's whole L2, which costs more than the ~5 us launch floor it replaces.
-bool tail_persistent_ok(int B) {
-  const char* env = std::getenv("CAMO_TAIL_PERSIST");
-  return B <= 64 && env && env[0] == '1';
-}
-void tail_begin(TailPlan& tp, GB& g, const DropCfg& drop, unsigned int* sync) {
-  std::memset(&tp, 0, sizeof(tp));
-  tp.drop = drop; tp.sync = sync;
-  g.plan = &tp;
-}
-
 void set_res(GemmProb& p, const float* res, int ldr) { p.res = res; p.ldr = ldr; }
 void set_drop(GemmProb& p, uint32_t site) { p.flags |= GF_DROPOUT; p.drop_site = site; }
 void set_relu_bwd(GemmProb& p, const float* act, int ldr, float scale) {
@@ -284,8 +256,7 @@ void set_bcast(Gemm16Prob& p, const float* v, int ldv, const int* row_sample, co
 // cross-attention fusion with both input projections, every width a multiple of 64, head_dim 32 attention
 // on the MFMA kernels.  Anything else (and CAMO_SCHED16=0) takes the general fp32-operand schedule.
 bool sched16_ok(const camo_dims_t& d, const float* const* P, int precision, int T, int Nk, int max_nr) {
-  const char* env = std::getenv("CAMO_SCHED16");          // read per call: tests A/B the two schedules in one process
-  if ((env && env[0] == '0') || precision != CAMO_PREC_BF16 || d.fusion_type != CAMO_FUSION_CROSS_ATTENTION) return false;
+  if (g_opt_sched16 == 0 || precision != CAMO_PREC_BF16 || d.fusion_type != CAMO_FUSION_CROSS_ATTENTION) return false;
   if (!P[CAMO_P_RG_PROJ_W] || !P[CAMO_P_KG_PROJ_W]) return false;
   if ((d.hidden_dim % 64) || (d.rg_dim % 64) || (d.kg_dim % 64)) return false;
   if (!attn_mfma_ok(d.hidden_dim, d.num_heads, Nk, max_nr, false) || !attn_mfma_ok(d.hidden_dim, d.num_heads, Nk, max_nr, true))
@@ -367,9 +338,8 @@ int forward_nodes16(const camo_dims_t& d, const float* const* P, const float* rg
     auto pad = [&](us* buf, size_t rows, size_t rows_p, size_t width) {
       job(PREP_ZERO, nullptr, buf + rows * width, (rows_p - rows) * width * sizeof(us), 0, 0, 0, 0);
     };
-    // the atomics block: pooled means, dfused and the barrier words (this schedule accumulates nothing into dKV)
+    // the atomics block: pooled means and dfused (this schedule accumulates nothing into dKV)
     job(PREP_ZERO, nullptr, w.zero_base, (size_t)(reinterpret_cast<char*>(w.dKV) - reinterpret_cast<char*>(w.zero_base)), 0, 0, 0, 0);
-    job(PREP_ZERO, nullptr, w.sync, 16 * sizeof(unsigned int), 0, 0, 0, 0);
     cast(rg, h.X, (size_t)T * D); cast(kg, h.KG, (size_t)TK * Dk);
     cast(P[CAMO_P_RG_PROJ_W], h.Wrg, (size_t)H * D); cast(P[CAMO_P_KG_PROJ_W], h.Wkg, (size_t)H * Dk);
     cast(P[CAMO_P_A1_IN_W], h.Win1, 3 * HH); cast(P[CAMO_P_A2_IN_W], h.Win2, 3 * HH);
@@ -578,77 +548,44 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   const float* R = rg; const float* G = kg;
   if (!P[CAMO_P_RG_PROJ_W] && D != H) return fail(CAMO_E_ARG, "rg_proj weight missing but rg_dim != hidden_dim");
   if (!P[CAMO_P_KG_PROJ_W] && Dk != H) return fail(CAMO_E_ARG, "kg_proj weight missing but kg_dim != hidden_dim");
-  // Fused node-level forward (fused_fwd.hip): opt-in (CAMO_FUSED=1) -- measured at parity with the unfused
-  // schedule on MI355X (each stage inside the workgroup is as latency-bound as the separate launches were), so
-  // the general schedule below (any dims, exact-f32 mode) stays the default and the reference it is tested against.
-  const char* fenv = std::getenv("CAMO_FUSED");
-  const bool fused = !use16 && fenv && fenv[0] == '1' && precision == CAMO_PREC_BF16 && P[CAMO_P_RG_PROJ_W] &&
-                     rg_fused_supported(D, H, nh, Nk);
   const size_t HH2 = (size_t)H * H;
   if (use16) {
     if (int e = forward_nodes16(d, P, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, w, attn_rg2kg, attn_kg2rg, drop, st)) return e;
   } else {
   if (P[CAMO_P_KG_PROJ_W]) { g.nt(kg, Dk, P[CAMO_P_KG_PROJ_W], Dk, P[CAMO_P_KG_PROJ_B], w.G, H, TK, H, Dk); G = w.G; }
-  if (!fused && P[CAMO_P_RG_PROJ_W]) { g.nt(rg, D, P[CAMO_P_RG_PROJ_W], D, P[CAMO_P_RG_PROJ_B], w.R, H, T, H, D); R = w.R; }
+  if (P[CAMO_P_RG_PROJ_W]) { g.nt(rg, D, P[CAMO_P_RG_PROJ_W], D, P[CAMO_P_RG_PROJ_B], w.R, H, T, H, D); R = w.R; }
   CK(g.run(), "input projections");
   // in-projections of both attention blocks (packed in_proj_weight: rows 0..H-1 = Wq, H..3H-1 = Wk|Wv)
-  if (!fused) {
-    g.nt(R, H, P[CAMO_P_A1_IN_W], H, P[CAMO_P_A1_IN_B], w.Q, H, T, H, H);
-    g.nt(R, H, P[CAMO_P_A2_IN_W] + HH2, H, P[CAMO_P_A2_IN_B] + H, w.KV2, 2 * H, T, 2 * H, H);
-  }
+  g.nt(R, H, P[CAMO_P_A1_IN_W], H, P[CAMO_P_A1_IN_B], w.Q, H, T, H, H);
+  g.nt(R, H, P[CAMO_P_A2_IN_W] + HH2, H, P[CAMO_P_A2_IN_B] + H, w.KV2, 2 * H, T, 2 * H, H);
   g.nt(G, H, P[CAMO_P_A1_IN_W] + HH2, H, P[CAMO_P_A1_IN_B] + H, w.KV, 2 * H, TK, 2 * H, H);
   g.nt(G, H, P[CAMO_P_A2_IN_W], H, P[CAMO_P_A2_IN_B], w.Q2, H, TK, H, H);
   CK(g.run(), "attention in-projections");
-  if (fused) {
-    const float* src[5] = {P[CAMO_P_RG_PROJ_W], P[CAMO_P_A1_IN_W], P[CAMO_P_A2_IN_W] + HH2, P[CAMO_P_A1_OUT_W], P[CAMO_P_F1_W0]};
-    unsigned short* dst[5] = {w.sWrg, w.sWq, w.sWkv2, w.sWo, w.sW1};
-    const int Ns[5] = {H, H, 2 * H, H, 2 * H}, Ks[5] = {D, H, H, H, H};
-    CK(launch_cast_tiled_bf16(src, dst, Ns, Ks, 5, st), "cast weights to tiled bf16");
-    RgFwdArgs fa{};
-    fa.X = rg; fa.D = D; fa.offs = rg_offsets;
-    fa.Wrg = w.sWrg; fa.Wq = w.sWq; fa.Wkv2 = w.sWkv2; fa.Wo = w.sWo; fa.W1 = w.sW1;
-    fa.brg = P[CAMO_P_RG_PROJ_B]; fa.bq = P[CAMO_P_A1_IN_B]; fa.bkv2 = P[CAMO_P_A2_IN_B] + H; fa.bo = P[CAMO_P_A1_OUT_B];
-    fa.b1 = P[CAMO_P_F1_B0]; fa.ln_g = P[CAMO_P_LN1_W]; fa.ln_b = P[CAMO_P_LN1_B];
-    fa.KV = w.KV;
-    fa.R = w.R; fa.Q = w.Q; fa.KV2 = w.KV2; fa.P = w.P; fa.O = w.O; fa.U = w.U; fa.stats = w.st1; fa.Y = w.Y; fa.H1 = w.H1;
-    fa.Ymean = w.Ymean; fa.H1mean = w.H1mean;
-    fa.Nk = Nk; fa.nh = nh; fa.scale = 1.0f / sqrtf((float)(H / nh)); fa.drop = drop;
-    { const char* ds = std::getenv("CAMO_FUSED_STOP"); fa.debug_stop = ds ? std::atoi(ds) : 0; }
-    CK(launch_rg_forward_fused(fa, B, max_nr, st), "fused node-level forward");
-    R = w.R;
-    if (attn_rg2kg) CK(launch_attn_avg_site(w.P, attn_rg2kg, T, nh, Nk, SITE_ATTN_RG2KG, drop, st), "attn avg rg2kg");
-  } else {
-    CK(launch_attn_rg2kg_fwd(w.Q, w.KV, rg_offsets, w.P, w.O, attn_rg2kg, B, T, max_nr, H, nh, Nk, drop, st), "attn rg2kg fwd");
-  }
+      CK(launch_attn_rg2kg_fwd(w.Q, w.KV, rg_offsets, w.P, w.O, attn_rg2kg, B, T, max_nr, H, nh, Nk, drop, st), "attn rg2kg fwd");
   CK(launch_attn_kg2rg_fwd(w.Q2, w.KV2, rg_offsets, w.P2, w.O2, B, max_nr, H, nh, Nk, drop, st), "attn kg2rg fwd");
   if (attn_kg2rg) CK(launch_attn_avg(w.P2, attn_kg2rg, T, nh, Nk, drop, st), "attn avg");
   // out-projection + residual (fusion_model.py:119,130), then LayerNorm
-  if (!fused) set_res(g.nt(w.O, H, P[CAMO_P_A1_OUT_W], H, P[CAMO_P_A1_OUT_B], w.U, H, T, H, H), R, H);
+  set_res(g.nt(w.O, H, P[CAMO_P_A1_OUT_W], H, P[CAMO_P_A1_OUT_B], w.U, H, T, H, H), R, H);
   set_res(g.nt(w.O2, H, P[CAMO_P_A2_OUT_W], H, P[CAMO_P_A2_OUT_B], w.U2, H, TK, H, H), G, H);
   CK(g.run(), "attention out-projections");
   {
-    LnSeg s0{w.U, w.Y, w.st1, P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], fused ? 0 : T};
+    LnSeg s0{w.U, w.Y, w.st1, P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], T};
     LnSeg s1{w.U2, w.Y2, w.st2, P[CAMO_P_LN2_W], P[CAMO_P_LN2_B], TK};
     CK(launch_ln_fwd(s0, s1, H, st), "layernorm fwd");
   }
   // FFN first layers (ReLU + dropout fused), fusion_model.py:53-65
-  if (!fused) set_drop(g.nt(w.Y, H, P[CAMO_P_F1_W0], H, P[CAMO_P_F1_B0], w.H1, 2 * H, T, 2 * H, H, GF_RELU), SITE_FFN_RG);
+  set_drop(g.nt(w.Y, H, P[CAMO_P_F1_W0], H, P[CAMO_P_F1_B0], w.H1, 2 * H, T, 2 * H, H, GF_RELU), SITE_FFN_RG);
   set_drop(g.nt(w.Y2, H, P[CAMO_P_F2_W0], H, P[CAMO_P_F2_B0], w.H2, 2 * H, TK, 2 * H, H, GF_RELU), SITE_FFN_KG);
   CK(g.run(), "ffn layer 0");
   }
   // per-sample means of Y and H1d, then the second FFN layer on the means (mean-pool linearity)
   if (use16) {
     // accumulated by layernorm fwd and the FFN GEMM epilogue
-  } else if (fused) {   // the node-level sums were accumulated by the fused kernel
-    SegMean sm[2] = {{w.Y2, H, H, nullptr, Nk, w.Y2mean, H}, {w.H2, 2 * H, 2 * H, nullptr, Nk, w.H2mean, 2 * H}};
-    CK(launch_seg_mean(sm, 2, B, Nk, st), "pool (kg)");
   } else {
     SegMean sm[4] = {{w.Y, H, H, rg_offsets, 0, w.Ymean, H}, {w.H1, 2 * H, 2 * H, rg_offsets, 0, w.H1mean, 2 * H},
                      {w.Y2, H, H, nullptr, Nk, w.Y2mean, H}, {w.H2, 2 * H, 2 * H, nullptr, Nk, w.H2mean, 2 * H}};
     CK(launch_seg_mean(sm, 4, B, max_nr > Nk ? max_nr : Nk, st), "pool");
   }
-  TailPlan tplan;
-  if (tail_persistent_ok(B)) tail_begin(tplan, gt, drop, w.sync);
   set_res(gt.nt(w.H1mean, 2 * H, P[CAMO_P_F1_W3], 2 * H, P[CAMO_P_F1_B3], w.comb, 2 * H, B, H, 2 * H), w.Ymean, H);
   set_res(gt.nt(w.H2mean, 2 * H, P[CAMO_P_F2_W3], 2 * H, P[CAMO_P_F2_B3], w.comb + H, 2 * H, B, H, 2 * H), w.Y2mean, H);
   CK(gt.run(), "ffn layer 3 on pooled rows");
@@ -657,12 +594,7 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   CK(gt.run(), "fusion layer 0");
   gt.nt(w.F1, H, P[CAMO_P_FU_W3], H, P[CAMO_P_FU_B3], w.fused, H, B, H, H);
   CK(gt.run(), "fusion layer 3");
-  if (int e = heads_forward(d, P + CAMO_P_HEADS, w, B, H, outs, gt, gt.plan ? nullptr : fl)) return e;
-  if (gt.plan) {
-    CK(launch_tail(tplan, st), "per-sample tail (persistent)");
-    if (fl) return fail(CAMO_E_UNSUPPORTED, "CAMO_TAIL_PERSIST=1 cannot be combined with the fused training call");
-  }
-  return 0;
+  return heads_forward(d, P + CAMO_P_HEADS, w, B, H, outs, gt, fl);
 }
 
 int camo_forward(const camo_dims_t* dims, const float* const* params, const float* rg, const int32_t* rg_offsets,
@@ -712,8 +644,6 @@ static int backward_impl(const camo_dims_t* dims, const float* const* params, fl
   const bool has_rgp = P[CAMO_P_RG_PROJ_W] != nullptr, has_kgp = P[CAMO_P_KG_PROJ_W] != nullptr;
   const float* R = has_rgp ? w.R : rg;
   const float* G = has_kgp ? w.G : kg;
-  TailPlan tplan;
-  if (tail_persistent_ok(B)) tail_begin(tplan, gt, drop, w.sync + 4);
   if (int e = heads_backward(d, P + CAMO_P_HEADS, Gr + CAMO_P_HEADS, w, B, H, outs, d_outs, d_outs_pre_activation, drop, st, gt, heads_out_done)) return e;
   // fusion layer
   set_relu_bwd(gt.nn(w.dfused, H, P[CAMO_P_FU_W3], H, w.dF1, H, B, H, H), w.F1, H, drop.scale);
@@ -728,7 +658,6 @@ static int backward_impl(const camo_dims_t* dims, const float* const* params, fl
   gt.tn(w.dcomb, 2 * H, w.H1mean, 2 * H, Gr[CAMO_P_F1_W3], 2 * H, Gr[CAMO_P_F1_B3], H, 2 * H, B);
   gt.tn(w.dcomb + H, 2 * H, w.H2mean, 2 * H, Gr[CAMO_P_F2_W3], 2 * H, Gr[CAMO_P_F2_B3], H, 2 * H, B);
   CK(gt.run(), "ffn layer 3 bwd (pooled)");
-  if (gt.plan) CK(launch_tail(tplan, st), "per-sample tail bwd (persistent)");
   if (sched16_ok(d, P, precision, T, Nk, max_nr))
     return backward_nodes16(d, P, Gr, rg_offsets, row_sample, inv_nr, B, T, Nk, max_nr, w, drop, st);
   {
@@ -789,8 +718,7 @@ int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* para
                                int32_t training, uint64_t seed, int32_t precision, void* stream) {
   if (!dims || !grads || !y || !e || !s || !outs || !loss_terms) return fail(CAMO_E_ARG, "null pointer argument");
   const int head0 = dims->fusion_type == CAMO_FUSION_LATE ? CAMO_PL_HEADS : CAMO_P_HEADS;
-  const char* env = std::getenv("CAMO_TAIL_PERSIST");
-  const bool fuse = heads_loss_ok(B, dims->num_classes) && !(env && env[0] == '1');
+  const bool fuse = heads_loss_ok(B, dims->num_classes);
   if (fuse) {
     const FusedLoss fl{y, e, s, loss_terms, pred, grads + head0};
     if (int rc = forward_impl(dims, params, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
@@ -811,7 +739,7 @@ int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* para
 int camo_loss(const float* outs, const int64_t* y, const float* e, const float* s, int32_t B, int32_t num_classes,
               float* loss_terms, float* d_outs, float* d_pre, int32_t* pred, void* stream) {
   if (!outs || !y || !e || !s || !loss_terms) return fail(CAMO_E_ARG, "null pointer argument");
-  if (B < 1 || num_classes < 2) return fail(CAMO_E_ARG, "need B >= 1 and num_classes >= 2");
+  if (B < 1 || num_classes < 1 || num_classes > 64) return fail(CAMO_E_ARG, "need B >= 1 and 1 <= num_classes <= 64");
   CK(launch_loss(outs, reinterpret_cast<const long long*>(y), e, s, B, num_classes, loss_terms, d_outs, d_pre, pred,
                  static_cast<hipStream_t>(stream)), "loss");
   return 0;
@@ -857,6 +785,12 @@ int camo_debug_gemm16(const void* A16, int32_t lda, const void* B16, int32_t ldb
   p.bias = bias; p.res = res; p.ldr = ldr; p.bias_grad = bias_grad; p.M = M; p.N = N; p.K = K; p.flags = flags; p.aux_scale = 1.f;
   CK(launch_gemm16_batch(gb, static_cast<hipStream_t>(stream)), "debug gemm16");
   return 0;
+}
+
+int camo_debug_set_option(const char* name, int32_t value) {
+  if (!name) return fail(CAMO_E_ARG, "option name is null");
+  if (std::strcmp(name, "sched16") == 0) { g_opt_sched16 = value; return 0; }
+  return fail(CAMO_E_ARG, std::string("unknown option ") + name);
 }
 
 int camo_prof_begin(int32_t max_launches) {

@@ -41,23 +41,6 @@ struct GemmBatch {
   DropCfg drop;
 };
 
-// The per-sample tail as one persistent launch (gemm.hip, tail_persistent_kernel): up to TAIL_MAXPH dependent
-// phases of skinny problems (M <= 64 rows, or a dW contraction over <= 64 rows), a device-wide barrier between
-// phases.  `sync` = 3 zero-initialised uint32 in device memory (arrivals, exits, timeout flag); the kernel
-// leaves the first two at zero again.
-#define TAIL_MAXP 24
-#define TAIL_MAXPH 8
-struct TailPlan {
-  GemmProb p[TAIL_MAXP];
-  int n, nphase;
-  int phase_begin[TAIL_MAXPH + 1];
-  int phase_tiles[TAIL_MAXPH];
-  DropCfg drop;
-  unsigned int* sync;
-};
-int tail_problem_ok(const GemmProb& p);
-int launch_tail(TailPlan& tp, hipStream_t stream);
-
 // precision: CAMO_PREC_F32 / CAMO_PREC_BF16.  Returns hipError_t as int.
 int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream);
 

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256, (PIPE <= 2 ? 2 : 1)) void gemm_grouped_kernel(
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // One 16x16 tile (or, for dW problems, NW tiles: one per wave) of skinny problem P; `local` = tile index within
-// the problem.  Every thread returns normally (the persistent tail kernel runs barriers after it).
+// the problem.  Every thread returns normally.
 // Operand layouts and the 16-byte-load switch are COMPILE-TIME (block-uniform dispatch in skinny_tile below): with
 // runtime switches the loads sat in branches, their destination registers became PHIs, and the s_waitcnt in front
 // of the PHI copies drained the prefetch every k block (1.1 us per 16-deep block, one full memory round trip).
@@ -647,54 +647,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmBatch gb
   skinny_tile<NW>(gb.p[pi], gb.drop, blockIdx.x - gb.p[pi].tile_begin, red);
 }
 
-// ---------------------------------------------------------------------------------------------
-// The whole per-sample tail in ONE launch.  Its five dependent layers (forward: pooled FFN layer, fusion MLP,
-// head layers; backward: the same in reverse with the weight gradients) are a few 16x16 tiles each, so as
-// separate launches they cost five launch floors (~5 us each on MI355X) for microseconds of work.  Here a
-// resident grid walks the phases and meets at a device-wide barrier between them: arrive = release fence +
-// atomic increment, wait = spin on the counter + acquire fence (the fences write back / invalidate the
-// non-coherent per-XCD L2 lines and the CU's L1, so plain loads and stores in between are safe).
-// Exit conditions: every block runs every phase and every barrier (no early exits); the spin gives up after
-// 2^22 polls and raises sync[2] instead of hanging; the counters reset themselves (last block out).
-__device__ __forceinline__ void tail_grid_barrier(unsigned int* sync, unsigned int target) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned int spins = 0;
-    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 22)) { __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
-__global__ __launch_bounds__(256) void tail_persistent_kernel(const TailPlan tp) {
-  __shared__ float red[3][4][64];
-  const unsigned int nb = gridDim.x;
-  for (int ph = 0; ph < tp.nphase; ++ph) {
-    const int pb = tp.phase_begin[ph], pe = tp.phase_begin[ph + 1];
-    for (int t = blockIdx.x; t < tp.phase_tiles[ph]; t += nb) {
-      int pi = pb;
-      for (int i = pb + 1; i < pe; ++i)
-        if (t >= tp.p[i].tile_begin) pi = i;
-      skinny_tile<4>(tp.p[pi], tp.drop, t - tp.p[pi].tile_begin, red);
-      __syncthreads();                     // `red` is reused by the next tile
-    }
-    if (ph + 1 < tp.nphase) tail_grid_barrier(tp.sync, (unsigned int)(ph + 1) * nb);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned int old = __hip_atomic_fetch_add(tp.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == nb - 1) {                   // last block out: every block is past its last barrier
-      __hip_atomic_store(tp.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(tp.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 }  // namespace
 
 namespace {
@@ -767,39 +719,6 @@ static int launch_skinny(GemmBatch& gb, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-int tail_problem_ok(const GemmProb& p) { return ((p.flags & GF_A_KMAJOR) ? p.K : p.M) <= 64; }
-
-int launch_tail(TailPlan& tp, hipStream_t stream) {
-  if (tp.nphase <= 0 || tp.n <= 0) return 0;
-  if (!tp.sync || tp.nphase > TAIL_MAXPH || tp.n > TAIL_MAXP) return (int)hipErrorInvalidValue;
-  int max_tiles = 1;
-  for (int ph = 0; ph < tp.nphase; ++ph) {
-    int total = 0;
-    for (int i = tp.phase_begin[ph]; i < tp.phase_begin[ph + 1]; ++i) {
-      GemmProb& p = tp.p[i];
-      if (!tail_problem_ok(p)) return (int)hipErrorInvalidValue;
-      p.tiles_n = (p.N + 15) / 16;
-      const int tiles = ((p.M + 15) / 16) * p.tiles_n;
-      p.ksplit = 1; p.kchunk = p.K;
-      p.tile_begin = total;
-      total += (p.flags & GF_A_KMAJOR) ? (tiles + 3) / 4 : tiles;
-    }
-    tp.phase_tiles[ph] = total;
-    if (total > max_tiles) max_tiles = total;
-  }
-  // every block must be resident at once (the barrier spins): one block per CU at most, and no more blocks than
-  // the widest phase has tiles
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 64;
-    return n;
-  }();
-  int grid = max_tiles < 208 ? max_tiles : 208;
-  if (grid > cus) grid = cus;
-  hipLaunchKernelGGL(tail_persistent_kernel, dim3(grid), dim3(256), 0, stream, tp);
-  return (int)hipGetLastError();
-}
-
 int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
   if (gb.n <= 0) return 0;
   if (precision == 0) {
@@ -811,8 +730,7 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
     }
     if (skinny) return launch_skinny(gb, stream);
   }
-  // (developer knob for sweeps: K tiles per split-K block of a weight-gradient problem)
-  static const int kcap = [] { const char* e = std::getenv("CAMO_DEV_TN_KCAP"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 12; }();
+  constexpr int kcap = 12;          // K tiles per split-K block of a weight-gradient problem (measured best on MI355X)
   // tiles without split-K
   for (int i = 0; i < gb.n; ++i) {
     GemmProb& p = gb.p[i];

@@ -20,7 +20,6 @@
 // (a wave-instruction covers 128 contiguous bytes of two rows).
 #include "gemm16.h"
 
-#include <cstdlib>
 
 namespace {
 
@@ -607,7 +606,7 @@ __global__ __launch_bounds__(256, ROWS ? 2 : 3) void gemm16_kernel(const Gemm16B
   }
 }
 
-int dev_kmin() { static const int v = [] { const char* e = std::getenv("CAMO_DEV_TN16_KMIN"); const int x = e ? std::atoi(e) : 0; return x >= 2 ? x : 8; }(); return v; }
+constexpr int KCAP_MIN = 8;          // shortest split-K chunk (64-row tiles) a sparse launch falls back to
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -618,9 +617,8 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
   // Split-K depth of the weight-gradient problems, in 64-row tiles per block.  Long chunks (16 tiles) keep the
   // fp32 atomics of the epilogue rare -- they, not the K loop, dominate short chunks -- but a launch that would
   // leave most CUs idle (the lone dW_rg / dW_kg launch) takes shorter chunks to spread over the chip.
-  static const int kcap_env = [] { const char* e = std::getenv("CAMO_DEV_TN16_KCAP"); const int v = e ? std::atoi(e) : 0; return v > 0 ? 2 * ((v + 1) / 2) : 0; }();
   int total = 0;
-  for (int kcap = kcap_env ? kcap_env : 16;; kcap >>= 1) {
+  for (int kcap = 16;; kcap >>= 1) {
     total = 0;
     for (int i = 0; i < gb.n; ++i) {
       Gemm16Prob& p = gb.p[i];
@@ -662,7 +660,7 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
       p.tile_begin = total;
       total += tiles * p.ksplit;
     }
-    if (kcap_env || total >= 200 || kcap <= dev_kmin()) break;
+    if (total >= 200 || kcap <= KCAP_MIN) break;
   }
   bool has_tn = false, has_rows = false, has_virt = false;
   for (int i = 0; i < gb.n; ++i) {

@@ -4,7 +4,6 @@
 // needed; everything streams coalesced fp32.
 #include "misc.h"
 
-#include <cstdlib>
 
 namespace {
 
@@ -348,21 +347,27 @@ __device__ __forceinline__ void loss_sample(const float* __restrict__ o, int yb,
     if (d_outs) d_outs[k] = val;
     if (d_pre) d_pre[k] = (k == W - 1) ? val * sc * (1.0f - sc) : val;
   };
-  // focal on mask logits
+  // focal on mask logits.  A label outside [0, C) (torch raises on one) poisons this sample's loss and gradients
+  // with NaN instead of reading out of bounds; the host wrappers validate labels before the call.
+  const bool ybad = yb < 0 || yb >= C;
+  if (ybad) yb = 0;
+  const float poison = ybad ? __builtin_nanf("") : 0.f;
   {
     float mx = -INFINITY; int am = 0;
     for (int k = 0; k < C; ++k) if (o[k] > mx) { mx = o[k]; am = k; }
     float z = 0.f;
     for (int k = 0; k < C; ++k) z += expf(o[k] - mx);
+    // ce from the log-sum-exp (finite when pt underflows, like torch's log_softmax); the gradient is written
+    // without the division by pt:  d l / d logit_k = at * (-3 om^2 ce pt - om^3) * (delta_ky - p_k)
+    const float ce = -(o[yb] - mx - logf(z));
     const float pt = expf(o[yb] - mx) / z;
-    const float ce = -logf(pt);
     const float at = yb == 1 ? 0.75f : 0.25f;
     const float om = 1.0f - pt;
-    terms4[0] = 3.0f * at * om * om * om * ce;
-    const float dl_dpt = at * (-3.0f * om * om * ce - om * om * om / pt);
+    terms4[0] = 3.0f * at * om * om * om * ce + poison;
+    const float dl = at * (-3.0f * om * om * ce * pt - om * om * om);
     for (int k = 0; k < C; ++k) {
       const float pk = expf(o[k] - mx) / z;
-      put(k, 3.0f * dl_dpt * pt * ((k == yb ? 1.0f : 0.0f) - pk));
+      put(k, 3.0f * dl * ((k == yb ? 1.0f : 0.0f) - pk) + poison);
     }
     if (pred) *pred = am;
   }
@@ -596,7 +601,7 @@ int launch_ln_fwd(const LnSeg& s0, const LnSeg& s1, int H, hipStream_t stream) {
 }
 
 int launch_ln_bwd(const LnBwdSeg& s0_, const LnBwdSeg& s1_, int H, hipStream_t stream) {
-  static const int rpb = [] { const char* e = std::getenv("CAMO_DEV_LNB_ROWS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 32; }();
+  constexpr int rpb = 32;
   const LnBwdSeg& s0 = s0_; const LnBwdSeg& s1 = s1_;
   auto nblk = [](int rows) { int b = (rows + rpb - 1) / rpb; return rows == 0 ? 0 : (b > 2048 ? 2048 : (b < 1 ? 1 : b)); };
   const int nb0 = nblk(s0.rows), nb1 = nblk(s1.rows);

@@ -23,6 +23,7 @@ class GradAllReducer:
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
     def __call__(self, flat_grads: torch.Tensor):
         if self.world > 1:

@@ -27,12 +27,40 @@ assert len(CROSS_SLOTS) == _lib.NPARAMS_CROSS and len(LATE_SLOTS) == _lib.NPARAM
 _PREC = {"f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
 
 
-def _stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)   # (~8 us of torch bookkeeping: fetch once per step)
+def _stream_ptr(device=None):
+    """The current HIP stream of ``device`` (default: the current device) as a void*."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)   # (~8 us of torch bookkeeping: fetch once per step)
+
+
+class _NullCtx:
+    def __enter__(self): return None
+    def __exit__(self, *a): return False
+
+
+_NULL = _NullCtx()
+
+
+def _on(device):
+    """Context that makes ``device`` the current HIP device for the launches of a C-ABI call (they go to the stream
+    handed over, but the library's hipFuncSetAttribute / hipGetDevice calls and torch's allocations must see the device
+    that owns the pointers).  Free when it already is current."""
+    if device.type != "cuda" or torch.cuda.current_device() == device.index:
+        return _NULL
+    return torch.cuda.device(device)
 
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def check_labels(mask_label, num_classes):
+    """torch's cross_entropy raises on a target outside [0, C); the loss kernel would index with it.  Labels that are
+    still on the host (the usual case: they come out of the data loader) are checked here for free; labels already
+    on the device are checked by the kernel, which poisons that sample's loss and gradients with NaN."""
+    if not mask_label.is_cuda and mask_label.numel():
+        lo, hi = int(mask_label.min()), int(mask_label.max())
+        if lo < 0 or hi >= num_classes:
+            raise IndexError(f"Target {lo if lo < 0 else hi} is out of bounds for {num_classes} classes")
 
 
 class Batch:
@@ -133,11 +161,29 @@ class FusionEngine:
         if self._ptab is None:
             self.reflatten()
 
+    @property
+    def device(self):
+        return self.flat_params.device
+
+    def _same_device(self, t, name):
+        """Raw device pointers cross the ABI: a tensor on another GPU than the parameters would make the kernels
+        dereference a foreign address (a memory fault, not a Python error), so refuse it here."""
+        _lib.require_device(t, name)
+        if t.device != self.flat_params.device:
+            raise _lib.CamoError(f"{name} is on {t.device} but the model parameters are on {self.flat_params.device}: "
+                                 "every tensor of a call must live on the model's device")
+        return t
+
+    def fold_rank(self, rank):
+        """Data parallelism: give every rank its own dropout mask stream (the mask index of an element is its LOCAL
+        position in the rank's packed batch, so identically seeded ranks would draw identical masks)."""
+        self._seed_base = (int(torch.initial_seed()) ^ ((int(rank) + 1) * 0xD1B54A32D192ED03)) & 0xFFFFFFFFFFFFFFFF
+
     def make_batch(self, rg_packed, nrs, kg):
         """rg_packed [T, rg_dim], nrs: host ints, kg [B, Nk, kg_dim] -> Batch (device, fp32, contiguous)."""
         self._require_ready()
-        _lib.require_device(rg_packed, "rg_embeddings")
-        _lib.require_device(kg, "kg_embeddings")
+        self._same_device(rg_packed, "rg_embeddings")
+        self._same_device(kg, "kg_embeddings")
         nrs = [int(n) for n in nrs]
         B = len(nrs)
         if B < 1 or min(nrs) < 1:
@@ -159,8 +205,9 @@ class FusionEngine:
             offs = host.to(rg_packed.device, non_blocking=False)
             row_sample = torch.empty(sum(nrs), dtype=torch.int32, device=rg_packed.device)
             inv_nr = torch.empty(B, dtype=torch.float32, device=rg_packed.device)
-            _lib.check(_lib.lib().camo_prepare_batch(_ptr(offs), B, max(nrs), _ptr(row_sample), _ptr(inv_nr), _stream_ptr()),
-                       "camo_prepare_batch")
+            with _on(self.device):
+                _lib.check(_lib.lib().camo_prepare_batch(_ptr(offs), B, max(nrs), _ptr(row_sample), _ptr(inv_nr),
+                                                         _stream_ptr(self.device)), "camo_prepare_batch")
             desc = (offs, row_sample, inv_nr)
             self._offsets_cache[key] = desc
         return Batch(rg_packed, kg, desc[0], desc[1], desc[2], nrs)
@@ -188,19 +235,22 @@ class FusionEngine:
         if want_attention and self.cross:
             a1 = torch.empty(batch.T, batch.Nk, dtype=torch.float32, device=batch.rg.device)
             a2 = torch.empty(batch.T, batch.Nk, dtype=torch.float32, device=batch.rg.device)
-        rc = _lib.lib().camo_forward(C.byref(self.dims), self._ptab, _ptr(batch.rg), _ptr(batch.offsets),
-                                     _ptr(batch.row_sample), _ptr(batch.inv_nr), _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs),
-                                     _ptr(a1), _ptr(a2), int(bool(training)), seed, _PREC[mod.precision], _stream_ptr())
+        with _on(self.device):
+            rc = _lib.lib().camo_forward(C.byref(self.dims), self._ptab, _ptr(batch.rg), _ptr(batch.offsets),
+                                         _ptr(batch.row_sample), _ptr(batch.inv_nr), _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs),
+                                         _ptr(a1), _ptr(a2), int(bool(training)), seed, _PREC[mod.precision], _stream_ptr(self.device))
         _lib.check(rc, "camo_forward")
         return outs, ((a1, a2) if a1 is not None else None)
 
     def backward_raw(self, batch, ws, outs, d_outs, training, seed, gtab, pre_activation=False):
         mod = self.module()
-        rc = _lib.lib().camo_backward(C.byref(self.dims), self._ptab, gtab, _ptr(batch.rg), _ptr(batch.offsets),
-                                      _ptr(batch.row_sample), _ptr(batch.inv_nr), _ptr(batch.kg), batch.B, batch.T,
-                                      batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs), _ptr(d_outs),
-                                      int(bool(pre_activation)), int(bool(training)), seed, _PREC[mod.precision],
-                                      _stream_ptr())
+        self._same_device(d_outs, "d_outs")
+        with _on(self.device):
+            rc = _lib.lib().camo_backward(C.byref(self.dims), self._ptab, gtab, _ptr(batch.rg), _ptr(batch.offsets),
+                                          _ptr(batch.row_sample), _ptr(batch.inv_nr), _ptr(batch.kg), batch.B, batch.T,
+                                          batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs), _ptr(d_outs),
+                                          int(bool(pre_activation)), int(bool(training)), seed, _PREC[mod.precision],
+                                          _stream_ptr(self.device))
         _lib.check(rc, "camo_backward")
 
     def train_raw(self, batch, ws, mask_label, edge_label, score_label, training, seed, gtab):
@@ -208,16 +258,18 @@ class FusionEngine:
         the flat gradient buffer in one library call.  Returns (outs [B, 2C+2], loss_terms [B, 4], pred int32 [B])."""
         mod = self.module()
         dev = batch.rg.device
+        check_labels(mask_label, self.dims.num_classes)
         y = mask_label.to(device=dev, dtype=torch.int64).contiguous()
         e = edge_label.to(device=dev, dtype=torch.float32).contiguous()
         s = score_label.to(device=dev, dtype=torch.float32).contiguous()
         outs = torch.empty(batch.B, self.out_width, dtype=torch.float32, device=dev)
         terms = torch.empty(batch.B, 4, dtype=torch.float32, device=dev)
         pred = torch.empty(batch.B, dtype=torch.int32, device=dev)
-        rc = _lib.lib().camo_forward_loss_backward(
-            C.byref(self.dims), self._ptab, gtab, _ptr(batch.rg), _ptr(batch.offsets), _ptr(batch.row_sample), _ptr(batch.inv_nr),
-            _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(y), _ptr(e), _ptr(s),
-            _ptr(outs), _ptr(terms), _ptr(pred), int(bool(training)), seed, _PREC[mod.precision], _stream_ptr())
+        with _on(self.device):
+            rc = _lib.lib().camo_forward_loss_backward(
+                C.byref(self.dims), self._ptab, gtab, _ptr(batch.rg), _ptr(batch.offsets), _ptr(batch.row_sample), _ptr(batch.inv_nr),
+                _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(y), _ptr(e), _ptr(s),
+                _ptr(outs), _ptr(terms), _ptr(pred), int(bool(training)), seed, _PREC[mod.precision], _stream_ptr(self.device))
         _lib.check(rc, "camo_forward_loss_backward")
         return outs, terms, pred
 

@@ -116,9 +116,32 @@ class MultimodalCamouflageDetector(nn.Module):
         self.score_head = _mlp(final_dim, final_dim // 2, 1, dropout)   # + Sigmoid, applied by the kernel
         self.config = dict(rg_dim=rg_dim, kg_dim=kg_dim, hidden_dim=hidden_dim, num_heads=num_heads,
                            fusion_type=fusion_type, num_classes=num_classes, dropout=float(dropout))
-        #: CAMO_PREC_BF16 (bf16 MFMA operands, fp32 accumulate) or CAMO_PREC_F32 (exact fp32 MFMA)
-        self.precision = "bf16"
+        #: "f32" (default: exact fp32 MFMA -- the reference is fp32 throughout, so an import swap keeps its numerics to
+        #: ~2e-5 on the logits) or "bf16" (bf16 MFMA operands, fp32 accumulate: logits within 1e-3; what bench.py times).
+        #: Opt in with ``model.set_precision("bf16")`` or the ``precision`` key of the trainer config.
+        self.precision = "f32"
         self._engine = _engine.FusionEngine(self)
+
+    # copy.deepcopy / pickle (EMA or best-model snapshots, torch.save(model)): the engine holds a weak reference to ITS
+    # module, a ctypes pointer table and the flat buffers -- none of which may be shared with a copy.  The copy gets
+    # its parameters by value and an engine of its own.
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_engine"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._engine = _engine.FusionEngine(self)
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k == "_engine" else copy.deepcopy(v, memo)
+        new._engine = _engine.FusionEngine(new)
+        return new
 
     # nn.Module plumbing: keep the flat parameter buffer coherent across .to()/.cuda()/.float()
     def _apply(self, fn, recurse=True):

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .engine import _ptr, _stream_ptr
+from .engine import _on, _ptr, _stream_ptr, check_labels
 
 LOSS_WEIGHTS = dict(mask=3.0, instance=1.0, edge=0.5, score=0.3)   # train_multimodal.py:257,260,263,266
 
@@ -28,15 +28,17 @@ def multitask_loss(outs, mask_label, edge_label, score_label, num_classes=2, wan
     _lib.require_device(outs, "outs")
     B = outs.shape[0]
     dev = outs.device
+    check_labels(mask_label, num_classes)
     y = mask_label.to(device=dev, dtype=torch.int64).contiguous()
     e = edge_label.to(device=dev, dtype=torch.float32).contiguous()
     s = score_label.to(device=dev, dtype=torch.float32).contiguous()
     terms = torch.empty(B, 4, dtype=torch.float32, device=dev)
     d_outs = torch.empty_like(outs)
     pred = torch.empty(B, dtype=torch.int32, device=dev) if want_pred else None
-    rc = _lib.lib().camo_loss(_ptr(outs), _ptr(y), _ptr(e), _ptr(s), B, num_classes, _ptr(terms),
-                              _ptr(None if pre_activation else d_outs), _ptr(d_outs if pre_activation else None),
-                              _ptr(pred), _stream_ptr())
+    with _on(dev):
+        rc = _lib.lib().camo_loss(_ptr(outs), _ptr(y), _ptr(e), _ptr(s), B, num_classes, _ptr(terms),
+                                  _ptr(None if pre_activation else d_outs), _ptr(d_outs if pre_activation else None),
+                                  _ptr(pred), _stream_ptr(dev))
     _lib.check(rc, "camo_loss")
     return terms, d_outs, pred
 

@@ -14,7 +14,7 @@ import math
 import torch
 
 from . import _lib
-from .engine import _ptr, _stream_ptr
+from .engine import _on, _ptr, _stream_ptr
 
 
 def cosine_warm_restarts_lr(base_lr, epoch, T_0=10, T_mult=2, eta_min=0.0):
@@ -63,11 +63,12 @@ class FusedClipAdamW:
         m, v, ss = self._state()
         self.step_count += 1
         L = _lib.lib()
-        st = _stream_ptr()
-        _lib.check(L.camo_grad_sumsq(_ptr(g), g.numel(), _ptr(ss), st), "camo_grad_sumsq")
-        _lib.check(L.camo_clip_adamw(_ptr(eng.flat_params), _ptr(g), _ptr(m), _ptr(v), g.numel(), _ptr(ss),
-                                     self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
-                                     self.weight_decay, self.step_count, int(bool(zero_grads)), st), "camo_clip_adamw")
+        with _on(eng.device):
+            st = _stream_ptr(eng.device)
+            _lib.check(L.camo_grad_sumsq(_ptr(g), g.numel(), _ptr(ss), st), "camo_grad_sumsq")
+            _lib.check(L.camo_clip_adamw(_ptr(eng.flat_params), _ptr(g), _ptr(m), _ptr(v), g.numel(), _ptr(ss),
+                                         self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
+                                         self.weight_decay, self.step_count, int(bool(zero_grads)), st), "camo_clip_adamw")
 
     def grad_norm(self):
         """Pre-clip global gradient norm of the last step (device tensor)."""

@@ -16,8 +16,10 @@
  *    one [T, rg_dim] matrix (variable Nr per sample, no padding), the KG rows
  *    are [B*Nk, kg_dim];
  *  - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*); no
- *    allocation, no synchronisation, no global mutable state => graph-capturable
- *    and thread-compatible;
+ *    allocation, no synchronisation, and the environment is never read.  The only
+ *    process-global state is the two testing/measurement hooks at the end of this
+ *    file (camo_debug_set_option, camo_prof_begin/end); without them the calls are
+ *    graph-capturable and thread-compatible;
  *  - return value: 0 on success, a negative CAMO_E_* code otherwise; no C++
  *    exception crosses the boundary; camo_last_error() gives a thread-local
  *    message for the last failing call.
@@ -187,6 +189,9 @@ int camo_debug_gemm16(const void* A16, int32_t lda, const void* B16, int32_t ldb
                       void* C16, int32_t ldc16, const float* bias, const float* res, int32_t ldr, float* bias_grad,
                       int32_t M, int32_t N, int32_t K, int32_t flags, void* stream);
 int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int32_t Nk, const char* name);
+/* camo_debug_set_option: lets a test run two schedules of the same call in one process.
+ *   "sched16": -1 (default) choose from the configuration, 0 never take the bf16-resident schedule. */
+int camo_debug_set_option(const char* name, int32_t value);
 
 /* Opt-in launch timing for bench.py's roofline leg: between camo_prof_begin and camo_prof_end every
  * launch of the grouped GEMM kernel (the dominant kernel: >= 98 % of the path's FLOPs) is bracketed

@@ -5,6 +5,9 @@ model (forward, loss, backward, clip, AdamW).  It exists so that the HIP path
 can be checked against an independent implementation on a box where the
 reference itself is absent.
 
+``torch_port.py`` restates the same training step with torch CPU ops and autograd (the reference's own CPU path runs
+on those kernels); ``bench.py`` times it as the fairer CPU baseline and a test holds it to the golden step.
+
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import it.  Nothing under ``camouflage_multimodal_amd/`` does, and the
 product path raises when its HIP extension is missing instead of falling back

@@ -15,6 +15,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # tests/test_ddp_gpu.py spawns its rank processes before this process initialises HIP: run it first
+    items.sort(key=lambda it: 0 if "test_ddp_gpu" in it.nodeid else 1)
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
         return {k: z[k] for k in z.files}

@@ -1,0 +1,186 @@
+"""Round-2 parity cases ("Next round" item 1): the benchmarked mode against the oracle, the long-sequence
+configuration, the epoch loop / validation / checkpoint / history / inference post-processing end to end.  Needs an MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import assert_close
+from oracle import fusion_oracle as FO
+from oracle import params as OP
+from test_hip_parity import make_model, outs6, t2n
+
+pytestmark = pytest.mark.gpu
+
+
+def _grad_errors(model, ref, coef):
+    num = den = 0.0
+    rels = []
+    for k, p in model.named_parameters():
+        want = ref["raw_grads"][k].astype(np.float64); got = t2n(p.grad).astype(np.float64) / coef
+        num += ((got - want) ** 2).sum(); den += (want ** 2).sum()
+        rels.append((np.sqrt(((got - want) ** 2).sum()) / max(np.sqrt((want ** 2).sum()), 1e-30), np.sqrt((want ** 2).sum()), k))
+    rels.sort(reverse=True)
+    return np.sqrt(num / den), np.sqrt(den), rels
+
+
+def test_benchmarked_mode_bf16_dropout_b16_matches_oracle(kg_real):
+    """What bench.py times: default configuration, bf16 precision (bf16-resident schedule), train mode with dropout 0.3,
+    B = 16 samples drawn from the real Nr histogram -- against the oracle's train step with the same seed, i.e. the same
+    counter-hash dropout masks at all nine sites."""
+    from camouflage_multimodal_amd import NativeTrainer
+    cfg = OP.full_cfg()
+    h = load_golden("nr_histogram")
+    rs = np.random.RandomState(11)
+    nrs = [int(x) for x in rs.choice(h["values"], size=16, p=h["counts"] / h["counts"].sum())]
+    rg = [OP.make_rg(n, 128, seed=900 + i) for i, n in enumerate(nrs)]
+    kg = np.stack([kg_real] * 16)
+    y, e, s = OP.make_labels(16, seed=21)
+    dseed = 0x5EEDC0FFEE123457
+    m = make_model(cfg, 0, "bf16").train()
+    tr = NativeTrainer(m, keep_grads=True)
+    orc = FO.FusionOracle(cfg, OP.make_params(cfg, 0))
+    ref = FO.train_step(orc, FO.AdamW(orc.p), rg, kg, y, e, s, training=True, seed=dseed)
+    terms, pred = tr.step(torch.from_numpy(np.concatenate(rg)).cuda(), nrs, torch.from_numpy(kg).cuda(), torch.from_numpy(y),
+                          torch.from_numpy(e), torch.from_numpy(s), seed=dseed)
+    assert_close(t2n(terms), ref["loss_terms"], 2e-3, 2e-3, "bf16 + dropout loss terms")
+    assert (t2n(pred) == outs6(ref["outs"])[:, :2].argmax(1)).all()
+    assert_close(t2n(tr.opt.grad_norm())[0], ref["grad_norm"], 0, 2e-2, "grad norm")
+    coef = min(1.0, 1.0 / (float(ref["grad_norm"]) + 1e-6))
+    tr.engine.ensure_flat_grads(attach=True)
+    total, gn, rels = _grad_errors(m, ref, coef)
+    print("bf16+dropout B=16: global relative gradient error", total, "worst tensors", [(f"{r:.3f}", f"{n:.2e}", k) for r, n, k in rels[:5]])
+    assert total < 5e-2
+    assert all(r < 0.10 for r, n, _ in rels if n > 1e-3 * gn)
+
+
+def test_long_sequence_config_nr2048(kg_real):
+    """BASELINE configs[3] stand-in: Nr = 2048 nodes per sample, B = 4 -- the KG->RG softmax spans 2048 keys.
+    f32: eval logits and one training step against the oracle; bf16: logits within north_star's 1e-3."""
+    from camouflage_multimodal_amd import NativeTrainer
+    cfg = OP.full_cfg(dict(dropout=0.0))
+    nrs = [2048] * 4
+    rg = [OP.make_rg(n, 128, seed=1200 + i) for i, n in enumerate(nrs)]
+    kg = np.stack([kg_real] * 4)
+    y, e, s = OP.make_labels(4, seed=33)
+    orc = FO.FusionOracle(cfg, OP.make_params(cfg, 0))
+    ref_eval, _ = orc.forward_list(rg, kg)
+    rgp = torch.from_numpy(np.concatenate(rg)).cuda(); kgt = torch.from_numpy(kg).cuda()
+    m = make_model(cfg, 0, "f32").eval()
+    with torch.no_grad():
+        o = m.forward_packed(rgp, nrs, kgt, return_attention=True)
+    assert_close(np.concatenate([t2n(v) for v in o[:4]], axis=1), outs6(ref_eval), 2e-5, 1e-5, "f32 logits at Nr=2048")
+    for b in range(4):
+        assert_close(t2n(o[4]["kg2rg"][b]), ref_eval["attn_kg2rg"][b], 2e-7, 2e-4, "kg2rg map over 2048 keys")
+        assert_close(t2n(o[4]["kg2rg"][b]).sum(1), np.ones(13), 1e-5, 0, "kg2rg rows sum to 1")
+    mb = make_model(cfg, 0, "bf16").eval()
+    with torch.no_grad():
+        ob = mb.forward_packed(rgp, nrs, kgt)
+    err = np.abs(np.concatenate([t2n(v) for v in ob], axis=1) - outs6(ref_eval)).max()
+    print("bf16 max |logit err| at Nr=2048 =", err)
+    assert err < 1e-3
+    m.train()
+    tr = NativeTrainer(m, keep_grads=True)
+    ref = FO.train_step(orc, FO.AdamW(orc.p), rg, kg, y, e, s, training=True)
+    terms, _ = tr.step(rgp, nrs, kgt, torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s))
+    assert_close(t2n(terms), ref["loss_terms"], 2e-5, 1e-4, "loss terms at Nr=2048")
+    assert_close(t2n(tr.opt.grad_norm())[0], ref["grad_norm"], 0, 2e-4, "grad norm at Nr=2048")
+    coef = min(1.0, 1.0 / (float(ref["grad_norm"]) + 1e-6))
+    tr.engine.ensure_flat_grads(attach=True)
+    for k, p in m.named_parameters():
+        want = ref["raw_grads"][k]
+        rms = float(np.sqrt((want.astype(np.float64) ** 2).mean()))
+        assert_close(t2n(p.grad) / coef, want, 4e-4 * rms + 2e-7, 4e-4, f"grad {k} at Nr=2048")
+
+
+def _synthetic_samples(n, seed0):
+    out = []
+    for i in range(n):
+        y, e, s = OP.make_labels(1, seed=seed0 + i)
+        out.append(dict(rg_node_emb=torch.from_numpy(OP.make_rg(20 + 7 * (i % 5), 128, seed=seed0 + i)),
+                        kg_emb=torch.from_numpy(OP.make_kg(13, 128, seed=seed0 + 50 + i))[:, None, :],      # [13,1,128] like EmbeddingMatcher
+                        mask_label=int(i % 2), edge_label=float(e[0]), score_label=float(s[0]), image_name=f"img{i}.jpg"))
+    return out
+
+
+def test_fit_runs_epochs_validation_checkpoint_and_history(tmp_path):
+    """train_multimodal_fixed's epoch loop (train_multimodal.py:397-492) on 12 synthetic samples through
+    DeviceResidentDataset: two epochs; validate_fixed's CE / F1 / per-class accuracy against the oracle's eval forward
+    on the trained weights; the best-checkpoint file and training_history_fixed.json as the reference writes them."""
+    from camouflage_multimodal_amd import DeviceResidentDataset, fit, load_multimodal_model, validate_fixed
+    from camouflage_multimodal_amd.optim import cosine_warm_restarts_lr
+    torch.manual_seed(0)
+    train_s, val_s = _synthetic_samples(12, 100), _synthetic_samples(6, 300)
+    tds, vds = DeviceResidentDataset(train_s, "cuda"), DeviceResidentDataset(val_s, "cuda")
+    train_loader = [tds.batch(list(range(i, i + 4))) for i in range(0, 12, 4)]
+    val_loader = [[val_s[0], val_s[1], val_s[2]], vds.batch([3, 4, 5])]          # reference-style dict lists and packed tuples both work
+    cfg = {"model": dict(rg_dim=128, kg_dim=128, hidden_dim=256, num_heads=8, fusion_type="cross_attention", num_classes=2, dropout=0.3),
+           "learning_rate": 5e-4, "weight_decay": 1e-4, "epochs": 2, "batch_size": 4, "checkpoint_dir": str(tmp_path / "ckpt"),
+           "precision": "f32"}
+    logs = []
+    model, hist = fit(cfg, train_loader, val_loader, device="cuda", log=logs.append)
+    keys = {"train_loss", "val_loss", "train_f1_class_0", "train_f1_class_1", "train_f1_avg", "val_f1_class_0", "val_f1_class_1",
+            "val_f1_avg", "val_acc_0", "val_acc_1"}
+    assert set(hist) == keys and all(len(v) == 2 for v in hist.values()) and len(logs) == 2
+    assert all(np.isfinite(v).all() for v in hist.values()) and hist["train_loss"][0] > 0
+    with open(tmp_path / "ckpt" / "training_history_fixed.json") as f:
+        assert json.load(f) == hist
+    # validation numbers against the oracle on the trained parameters
+    sd = {k: t2n(v) for k, v in model.state_dict().items()}
+    orc = FO.FusionOracle(cfg["model"], sd)
+    ref, _ = orc.forward_list([s["rg_node_emb"].numpy() for s in val_s], np.stack([s["kg_emb"].numpy()[:, 0] for s in val_s]))
+    labels = np.array([s["mask_label"] for s in val_s])
+    ce = float(np.mean([FO.cross_entropy(ref["mask"][i:i + 1], labels[i:i + 1])[0] for i in range(6)]))
+    preds = ref["mask"].argmax(1)
+    f1 = FO.f1_scores(preds, labels)
+    vl, vf1, a0, a1 = validate_fixed(model, val_loader, "cuda")
+    assert abs(vl - ce) < 1e-4 and abs(vl - hist["val_loss"][-1]) < 1e-6
+    for k in ("f1_class_0", "f1_class_1", "f1_avg", "precision_1", "recall_1"):
+        assert abs(float(vf1[k]) - f1[k]) < 1e-6, k
+    assert abs(a0 - 100 * ((preds == labels) & (labels == 0)).sum() / 3) < 1e-9 and abs(a1 - 100 * ((preds == labels) & (labels == 1)).sum() / 3) < 1e-9
+    # the best checkpoint (written iff some epoch's class-1 F1 beat 0)
+    path = tmp_path / "ckpt" / "multimodal_best_fixed.pth"
+    if max(hist["val_f1_class_1"]) > 0:
+        ck = torch.load(path, weights_only=True)
+        assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "val_loss", "val_f1_class_1", "val_f1_avg", "val_acc_0",
+                           "val_acc_1", "config"}
+        best = int(np.argmax(hist["val_f1_class_1"]))            # first epoch reaching the maximum is the one saved last
+        assert ck["epoch"] == best and abs(ck["val_f1_class_1"] - hist["val_f1_class_1"][best]) < 1e-9 and ck["config"] == cfg
+        # the reference saves after scheduler.step(): the stored lr is the next epoch's
+        assert abs(ck["optimizer_state_dict"]["param_groups"][0]["lr"] - cosine_warm_restarts_lr(5e-4, best + 1)) < 1e-12
+        m2, c2 = load_multimodal_model(str(path), "cuda")
+        assert c2 == cfg and not m2.training
+    else:
+        assert not path.exists()
+
+
+def test_predict_post_processing_and_batch_results(tmp_path, kg_real):
+    """predict_single_image's post-processing (test_multimodal.py:105-150) and batch_results.json (:350-375) against the oracle."""
+    from camouflage_multimodal_amd import predict_embedding_directory, predict_from_embeddings
+    cfg = OP.full_cfg()
+    m = make_model(cfg, 0, "f32").eval()
+    orc = FO.FusionOracle(cfg, OP.make_params(cfg, 0))
+    names = [str(n) for n in load_golden("kg_embeddings")["names"]]
+    kgd = {n: torch.from_numpy(kg_real[i:i + 1].copy()) for i, n in enumerate(names)}       # insertion order = category id
+    order = sorted(range(13), key=lambda i: names[i])                                       # inference sorts the keys [:65]
+    rgs = {f"img{i}.jpg": {"node_embeddings": torch.from_numpy(OP.make_rg(303 + 50 * i, 128, seed=40 + i))} for i in range(3)}
+    sm = lambda x: np.exp(x - x.max()) / np.exp(x - x.max()).sum()
+    for name, rg in rgs.items():
+        pred, attn, kg_ordered = predict_from_embeddings(m, rg["node_embeddings"], kgd, "cuda")
+        ref, _ = orc.forward_list([rg["node_embeddings"].numpy()], kg_real[order][None])
+        assert list(kg_ordered) == sorted(names)
+        assert_close(pred["mask_logits"].numpy()[0], ref["mask"][0], 2e-5, 1e-5, "mask logits")
+        assert_close(pred["mask_prob"].numpy()[0], sm(ref["mask"][0]), 1e-5, 1e-5, "mask prob")
+        assert_close(pred["instance_prob"].numpy()[0], sm(ref["instance"][0]), 1e-5, 1e-5, "instance prob")
+        assert abs(pred["edge_prob"] - 1 / (1 + np.exp(-float(ref["edge"][0, 0])))) < 1e-5 and abs(pred["score"] - float(ref["score"][0, 0])) < 1e-5
+        assert pred["mask_pred"] == int(ref["mask"][0].argmax()) and pred["instance_pred"] == int(ref["instance"][0].argmax())
+        assert_close(t2n(attn["rg2kg"][0]), ref["attn_rg2kg"][0], 2e-6, 2e-4, "rg2kg map (columns in sorted-key order)")
+    res = predict_embedding_directory(m, rgs, kgd, str(tmp_path / "out"), "cuda", max_images=2)
+    with open(tmp_path / "out" / "batch_results.json") as f:
+        assert json.load(f) == res
+    assert len(res) == 2 and set(res[0]) == {"image", "prediction", "pred_label", "camo_prob", "not_camo_prob", "score"}
+    assert res[0]["image"] == "img0.jpg" and res[0]["prediction"] in ("Camouflaged", "Not Camouflaged")
+    assert abs(res[0]["camo_prob"] + res[0]["not_camo_prob"] - 1) < 1e-6

@@ -194,3 +194,99 @@ def test_build_ordered_kg_tensor():
     assert list(od) == ["a", "b", "c"] and t.shape == (3, 1, 4) and t[:, 0, 0].tolist() == [0.0, 1.0, 2.0]
     t2, od2 = build_ordered_kg_tensor(torch.arange(6.0).view(3, 2))
     assert list(od2) == ["cat_0", "cat_1", "cat_2"] and t2.shape == (3, 2)
+
+
+def _write_png(path, arr):
+    from PIL import Image
+    Image.fromarray(arr.astype(np.uint8), mode="L").save(path)
+
+
+def test_smart_dataset_labels_weights_and_png_labels(tmp_path):
+    """Data glue of train_multimodal.py:62-188 on synthetic ground-truth PNGs: the label rule (mean intensity > 0.1 and
+    more than 5 % of the pixels above 10), edge_label = float(edge.mean() > 10), score_label = mask.mean()/255, and
+    the aggressive sample weights (majority/count * 5 for class 1, times the confidence) feeding the sharded sampler."""
+    from camouflage_multimodal_amd import SmartMultimodalDataset, extract_label_from_mask
+    from camouflage_multimodal_amd.ddp import sharded_weighted_sampler
+    from camouflage_multimodal_amd.train_multimodal import png_labels
+    dirs = {k: tmp_path / k for k in ("gt_object", "gt_instance", "gt_edge")}
+    for d in dirs.values():
+        d.mkdir()
+    rs = np.random.RandomState(0)
+    masks = {}
+    blob = np.zeros((256, 320)); blob[40:200, 60:260] = 255                  # one big object: label 1
+    masks["a"] = blob
+    masks["b"] = np.zeros((64, 80))                                          # empty: label 0
+    tiny = np.zeros((64, 80)); tiny[0:3, 0:3] = 255                          # < 5 % of the pixels: label 0
+    masks["c"] = tiny
+    many = np.zeros((64, 80))
+    for i in range(12):                                                      # 12 separate blobs (> 10 contours)
+        many[4 * (i // 6) * 8 + 2:4 * (i // 6) * 8 + 22, 13 * (i % 6) + 1:13 * (i % 6) + 11] = 200
+    masks["d"] = many
+    edges = {"a": np.full((64, 80), 30.0), "b": np.zeros((64, 80)), "c": np.full((64, 80), 10.0), "d": np.full((64, 80), 11.0)}
+    matched = []
+    for name, m in masks.items():
+        _write_png(dirs["gt_object"] / f"{name}.png", m); _write_png(dirs["gt_instance"] / f"{name}.png", m)
+        _write_png(dirs["gt_edge"] / f"{name}.png", edges[name])
+        matched.append({"image_name": name + ".jpg", "rg_node_embeddings": torch.from_numpy(OP.make_rg(4, 128, seed=1)),
+                        "kg_embeddings": torch.zeros(13, 1, 128)})
+    matched.append({"image_name": "missing.jpg", "rg_node_embeddings": torch.zeros(2, 128), "kg_embeddings": torch.zeros(13, 1, 128)})
+    ds = SmartMultimodalDataset(matched, str(dirs["gt_object"]), str(dirs["gt_instance"]), str(dirs["gt_edge"]))
+    assert len(ds) == 4 and ds.get_labels() == [1, 0, 0, 1]
+    mean_a, mean_d = masks["a"].mean() / 255, masks["d"].mean() / 255
+    conf = [s["confidence"] for s in ds.valid_samples]
+    assert abs(conf[0] - min(2 * mean_a, 1.0)) < 1e-12            # a clean blob has few edge pixels (< 2 %): doubled confidence
+    assert abs(conf[1] - 1.0) < 1e-12 and abs(conf[2] - (1 - masks["c"].mean() / 255)) < 1e-12
+    assert abs(conf[3] - min(2 * mean_d, 1.0)) < 1e-12            # 12 external contours > 10
+    assert extract_label_from_mask(str(tmp_path / "nope.png")) == (0, 0.0)
+    small = np.zeros((64, 80)); small[10:50, 20:70] = 255                     # same shape at 64x80: its outline is 3.5 % of the
+    _write_png(tmp_path / "small.png", small)                                 # pixels (>= 2 %) and it is one contour: plain mean
+    assert extract_label_from_mask(str(tmp_path / "small.png")) == (1, small.mean() / 255)
+    item = ds[0]
+    assert set(item) == {"rg_node_emb", "kg_emb", "mask_label", "confidence", "edge_label", "score_label", "image_name"}
+    assert item["edge_label"] == 1.0 and abs(item["score_label"] - mean_a) < 1e-12
+    assert ds[2]["edge_label"] == 0.0 and ds[3]["edge_label"] == 1.0          # mean 10 is not > 10; 11 is
+    assert png_labels(str(dirs["gt_object"] / "b.png"), str(dirs["gt_edge"] / "b.png")) == (0.0, 0.0)
+    w = ds.get_aggressive_sample_weights()                                    # counts {1: 2, 0: 2}: majority 2
+    assert np.allclose(w, [5.0 * conf[0], conf[1], conf[2], 5.0 * conf[3]])
+    draw0 = sharded_weighted_sampler(w, 64, epoch=1, world=2, rank=0, seed=3)
+    draw1 = sharded_weighted_sampler(w, 64, epoch=1, world=2, rank=1, seed=3)
+    assert len(draw0) == len(draw1) == 32 and sum(ds.get_labels()[i] for i in draw0 + draw1) > 40    # class 1 oversampled
+    assert [s["mask_label"] for s in ds.training_samples()] == [1, 0, 0, 1]
+
+
+def test_deepcopy_and_pickle_give_the_copy_its_own_engine():
+    import copy
+    from camouflage_multimodal_amd import build_multimodal_model
+    m = build_multimodal_model(dict(rg_dim=16, kg_dim=16, hidden_dim=32, num_heads=4))
+    c = copy.deepcopy(m)
+    assert c._engine.module() is c and m._engine.module() is m
+    fc, fm = c._engine.flat_params, m._engine.flat_params
+    assert fc.data_ptr() != fm.data_ptr() and torch.equal(fc, fm)
+    for p in c.parameters():
+        assert fc.data_ptr() <= p.data_ptr() < fc.data_ptr() + 4 * fc.numel()
+    with torch.no_grad():
+        next(c.parameters()).add_(1.0)                       # updating the copy leaves the original alone
+    assert not torch.equal(c._engine.flat_params, m._engine.flat_params)
+    buf = io.BytesIO()
+    torch.save(m, buf); buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)                 # (a file this test wrote itself)
+    assert m2._engine.module() is m2 and torch.equal(m2._engine.flat_params, fm)
+
+
+def test_device_and_label_checks_run_before_the_abi(monkeypatch):
+    from camouflage_multimodal_amd import _lib, build_multimodal_model
+    from camouflage_multimodal_amd.engine import check_labels
+    with pytest.raises(IndexError, match="Target 2 is out of bounds"):
+        check_labels(torch.tensor([0, 2, 1]), 2)
+    with pytest.raises(IndexError, match="Target -1 is out of bounds"):
+        check_labels(torch.tensor([-1]), 2)
+    check_labels(torch.tensor([0, 1]), 2)
+    m = build_multimodal_model(dict(rg_dim=16, kg_dim=16, hidden_dim=32, num_heads=4))
+    monkeypatch.setattr(_lib, "require_device", lambda t, name: None)        # pretend 'cpu' is a HIP device
+    with pytest.raises(_lib.CamoError, match="every tensor of a call must live on the model's device"):
+        m._engine._same_device(torch.zeros(3, 16, device="meta"), "rg_embeddings")
+    assert m._engine._same_device(torch.zeros(3, 16), "rg_embeddings") is not None
+    b0 = m._engine._seed_base
+    m._engine.fold_rank(0); s0 = m._engine._seed_base
+    m._engine.fold_rank(1); s1 = m._engine._seed_base
+    assert len({b0, s0, s1}) == 3                                            # ranks draw different dropout streams

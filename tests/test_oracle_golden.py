@@ -174,3 +174,24 @@ def test_train_mode_dropout_gradcheck():
                 assert abs(fd - g[k][i]) <= 1e-5 + 1e-4 * abs(fd), (k, i, fd, g[k][i])
     finally:
         M.f32 = old
+
+
+def test_torch_port_matches_numpy_oracle_and_golden_step():
+    """oracle/torch_port.py (the torch-CPU restatement bench.py times as ``cpu_baseline``) against the golden optimizer
+    step of the default configuration and against the numpy oracle: same losses, gradient norm and updated parameters."""
+    import torch
+    from helpers import train_batch, train_case
+    from oracle.torch_port import TorchPort
+    cfg, seed, nrs, nk, kg_fixed, _ = train_case("default")
+    g = load_golden("train_default_step0")
+    rg, kg, y, e, s = train_batch(cfg, seed, nrs, nk, kg_fixed, 0)
+    tp = TorchPort(cfg, OP.make_params(cfg, seed))
+    torch.set_num_threads(4)
+    losses, norm = tp.train_step(rg, kg, y, e, s, training=True)          # dropout 0 in this case: deterministic
+    assert np.abs(np.array(losses) - g["loss_terms"].sum(1)).max() < 2e-5
+    assert abs(norm - float(g["grad_norm"])) < 2e-4 * float(g["grad_norm"])
+    orc = FO.FusionOracle(cfg, OP.make_params(cfg, seed))
+    FO.train_step(orc, FO.AdamW(orc.p), rg, kg, y, e, s, training=True)
+    for k, v in orc.p.items():
+        err = np.abs(tp.P[k].detach().numpy() - v)
+        assert err.max() <= 2.2 * 5e-4 and (err <= 3e-6 + 1e-5 * np.abs(v)).mean() > 0.99, k
