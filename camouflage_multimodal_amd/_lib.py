@@ -12,14 +12,15 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcamo_fusion.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
+FWD_INFERENCE = 1
 SUMSQ_FLOATS = 257
 FUSION_CROSS_ATTENTION, FUSION_LATE = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
 NPARAMS_CROSS, NPARAMS_LATE = 44, 22
 
 # every symbol include/camo_fusion.h declares
-SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_prepare_batch", "camo_forward", "camo_backward", "camo_forward_loss_backward",
+SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_batch_desc_bytes", "camo_prepare_batch", "camo_forward", "camo_backward", "camo_forward_loss_backward",
            "camo_loss", "camo_grad_sumsq", "camo_clip_adamw", "camo_debug_gemm", "camo_debug_gemm16", "camo_debug_ws_offset",
            "camo_debug_set_option", "camo_prof_begin", "camo_prof_end")
 
@@ -61,12 +62,14 @@ def lib():
     L.camo_last_error.argtypes = []
     L.camo_workspace_bytes.restype = sz
     L.camo_workspace_bytes.argtypes = [C.POINTER(CamoDims), i32, i32, i32]
+    L.camo_batch_desc_bytes.restype = sz
+    L.camo_batch_desc_bytes.argtypes = [i32, i32]
     L.camo_prepare_batch.restype = C.c_int
-    L.camo_prepare_batch.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.camo_prepare_batch.argtypes = [vp, i32, i32, i32, vp, sz, vp]
     L.camo_forward.restype = C.c_int
-    L.camo_forward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, vp, vp, i32, u64, i32, vp]
+    L.camo_forward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, vp, vp, i32, u64, i32, i32, vp]
     L.camo_backward.restype = C.c_int
-    L.camo_backward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, vp, i32, i32, u64, i32, vp]
+    L.camo_backward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, vp, i32, i32, u64, i32, vp]
     L.camo_loss.restype = C.c_int
     L.camo_loss.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.camo_grad_sumsq.restype = C.c_int
@@ -74,7 +77,7 @@ def lib():
     L.camo_clip_adamw.restype = C.c_int
     L.camo_clip_adamw.argtypes = [vp, vp, vp, vp, sz, vp, f32, f32, f32, f32, f32, f32, i32, i32, vp]
     L.camo_forward_loss_backward.restype = C.c_int
-    L.camo_forward_loss_backward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz,
+    L.camo_forward_loss_backward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz,
                                              vp, vp, vp, vp, vp, vp, i32, C.c_uint64, i32, vp]
     L.camo_rg_workspace_bytes.restype = sz
     L.camo_rg_workspace_bytes.argtypes = [C.POINTER(CamoRgDims), i32]

@@ -1,0 +1,57 @@
+// Fused row-tile kernels of the bf16 schedule at the reference configuration (hidden 256, 8 heads of 32, input dims 128,
+// Nk <= 16): launchers and argument blocks (fused_rows.hip).  All launchers return hipError_t as int.
+//
+// A "tile" is 32 rows of one stream's packed activations; a block of 4 waves walks a tile through a chain of linear
+// layers whose weights it streams from L2 in MFMA-fragment order (weight "shadows", bf16) while every intermediate stays
+// in LDS / registers.  Forward = 2 launches for BOTH streams:
+//   front: x -> proj -> [q | k' | v'] in-projections                       (RG rows and KG rows, 32-row tiles of the packed rows)
+//   back : attention -> out-projection + residual -> LayerNorm -> FFN layer 0 (+ReLU, dropout) -> pooled sums
+//          (RG: 32-row tiles of one sample against its 13 KG keys; KG: one block per sample against its Nr RG keys)
+#pragma once
+#include "common.h"
+
+typedef unsigned short us16;
+
+// ---- weight shadows: W [N][K] fp32 -> bf16 in the order a block's 4 waves stream it:  [wave][k step of 16][tile of 32 rows][lane][8]
+// with row n = 32 (wave * N/128 + tile) + (lane & 31), k = 16 kstep + 8 (lane >> 5) + j  (tests/test_fragment_maps.py::frag_order).
+// A logical W is up to 3 source blocks stacked along N (transposed == 0: W[n][k] = src_i[(n - n0_i) * ld_i + k]) or, for the
+// backward's dy.W products, stacked along K and read transposed (transposed == 1: W[n][k] = src_i[(k - k0_i) * ld_i + n]).
+struct ShadowJob { us16* dst; int N, K, transposed, nsrc; const float* src[3]; int rows[3]; int ld[3]; int chunk_begin; };
+#define SHADOW_MAXJ 16
+struct ShadowBatch { ShadowJob j[SHADOW_MAXJ]; int n; void* zero_ptr; size_t zero_bytes; };
+int launch_weight_shadows(ShadowBatch& sb, hipStream_t stream);
+
+// ---- forward, front half
+struct FrontStream {
+  const float* X; int M;                       // fp32 input rows [M][128]
+  const us16* W0; const float* b0;             // projection: shadow of [256 x 128], bias [256]
+  const us16* W1; const float* bq; const float* bkv;   // in-projections: shadow of [768 x 256] = [Wq; Wk'; Wv'], biases [256], [512]
+  us16* X16;                                   // [M][128]  bf16 copy of the input (weight-gradient operand; written when save != 0)
+  us16* R16; us16* Q16; us16* KV16;            // [M][256] projection, [M][256] queries (pre-scaled by 1/sqrt(32)), [M][512] keys|values
+  int tile_begin;
+};
+struct FrontArgs { FrontStream s[2]; float qscale; int save; };
+int launch_fused_front(FrontArgs& a, hipStream_t stream);
+
+// ---- forward, back half
+struct BackStream {
+  const us16* Wo; const float* bo; const us16* W1; const float* b1; const float* ln_g; const float* ln_b;
+  const us16* R16;                             // residual rows (the front half's projection)
+  us16* O16; us16* Y16; us16* XH16; float* rstd; uint32_t* mask;   // saved for backward when save != 0: attention output, LN output,
+                                                                   // normalised LN input, 1/std per row, ReLU/dropout bit mask [rows][16 words]
+  float* Ymean; float* Hmean;                  // [B][256], [B][512]: per-sample means, accumulated with atomics into zeroed buffers
+  uint32_t site_ffn;
+};
+struct BackArgs {
+  BackStream s[2];                             // 0: RG rows, 1: KG rows
+  const us16* Q16; const us16* KV16;           // RG queries [T][256]; KG keys|values [B*Nk][512]
+  const us16* Q2_16; const us16* KV2_16;       // KG queries [B*Nk][256]; RG keys|values [T][512]
+  const int* off; const int* tile_off; const float* inv_nr;
+  float* lse2;                                 // [B][8][16][2]: max and sum of the KG->RG softmax (saved for backward)
+  int B, Nk, rg_tiles_max;
+  DropCfg drop; int save;
+};
+int launch_fused_back(BackArgs& a, hipStream_t stream);
+
+size_t fused_front_lds();
+size_t fused_back_lds();

@@ -1,0 +1,555 @@
+// Fused row-tile kernels of the bf16 schedule (gfx950); contract in fused_rows.h, layouts in tests/test_fragment_maps.py.
+//
+// Why this shape.  At the reference sizes a training step is ~8 k RG rows x a chain of five 256-wide linear layers: one
+// 32-row tile per CU.  Run as one GEMM launch per layer, every activation makes an HBM round trip between launches and
+// each launch pays its own fill/drain (round 1: 8 launches x 15-24 us at 7 % of the MFMA peak).  Here a block keeps its
+// 32 rows on chip through the whole chain and only the weights move: each of the 4 waves owns a quarter of a layer's
+// output features, streams exactly its quarter of the weight matrix from L2 straight into registers (the shadow copy is
+// stored in MFMA-fragment order, so a wave-instruction is one contiguous 1-KB read and no weight touches LDS), and meets
+// the other waves only through the 32 x 256 bf16 activation tile in LDS that the next layer reads as its other operand.
+//
+// Orientation.  With the weights as the MFMA "A" operand a stage computes out^T: lane = row, registers = features.  Row
+// statistics (LayerNorm, softmax over the 13 keys) are then in-lane sums plus one exchange between the lane halves, the
+// epilogue writes 4 consecutive features per store, and an attention head's 32 features are exactly one accumulator tile
+// that feeds the next MFMA as an operand without leaving the registers (cdna_hip_programming.md, "an accumulator tile as
+// the next MFMA's operand").  Stages whose epilogue reduces over ROWS (the pooled FFN activation) swap the operands:
+// lane = feature, registers = rows.
+#include "fused_rows.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ bf16x8 join(s16x4 lo, s16x4 hi) { return bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}; }
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+__device__ __forceinline__ float bf_lo(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t v) { return __uint_as_float(v & 0xFFFF0000u); }
+// accumulator register r of lane half h holds row (r & 3) + 8 (r >> 2) + 4 h of the 32x32 tile
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- one linear layer of a tile: acc[t] (+)= sum over KS k steps.  `wp` = the wave's fragment stream + lane (16-byte
+// units: fragment i of the stream is wp[64 i]); `act` = LDS address of this lane's first activation fragment (row
+// lane & 31, byte offset 16 (lane >> 5)); k step ks is 32 bytes further.  DEPTH weight fragments are kept in flight.
+constexpr int DEPTH = 12;
+template <int NT, int KS, bool W_IS_A>
+__device__ __forceinline__ void stage_mma(const u32x4* __restrict__ wp, const char* act, f32x16 (&acc)[NT]) {
+  constexpr int TOTAL = NT * KS;
+  constexpr int D = DEPTH < TOTAL ? DEPTH : TOTAL;
+  u32x4 buf[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) buf[i] = wp[64 * i];
+  bf16x8 x;
+#pragma unroll
+  for (int i = 0; i < TOTAL; ++i) {
+    const int ks = i / NT, t = i % NT;
+    if (t == 0) x = *reinterpret_cast<const bf16x8*>(act + 32 * ks);
+    const bf16x8 wf = as_frag(buf[i % D]);
+    if (i + D < TOTAL) buf[i % D] = wp[64 * (i + D)];
+    if constexpr (W_IS_A) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, x, acc[t], 0, 0, 0);
+    else                  acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, wf, acc[t], 0, 0, 0);
+  }
+}
+
+// rows [0, nrows) of a bf16 LDS tile -> global, 16 bytes per thread, whole rows contiguous (LOG2C: log2 of 16-byte chunks per row)
+template <int LOG2C>
+__device__ __forceinline__ void copy_out(const char* lds, int pitch, int col_byte0, us16* dst, int ld, size_t row0, int nrows) {
+  for (int c = threadIdx.x; c < (32 << LOG2C); c += 256) {
+    const int r = c >> LOG2C, k = c & ((1 << LOG2C) - 1);
+    if (r < nrows)
+      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(dst + (row0 + r) * (size_t)ld) + 16 * k) =
+          *reinterpret_cast<const u32x4*>(lds + r * pitch + col_byte0 + 16 * k);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight shadows
+__global__ __launch_bounds__(256) void shadow_kernel(const ShadowBatch sb, int total_chunks) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (sb.zero_ptr) {                                       // the step's atomics block rides along (grid-stride, 16 B per thread)
+    u32x4* z = static_cast<u32x4*>(sb.zero_ptr);
+    const size_t n16 = sb.zero_bytes >> 4;
+    for (size_t i = gid; i < n16; i += (size_t)gridDim.x * 256) z[i] = u32x4{0u, 0u, 0u, 0u};
+  }
+  if (gid >= total_chunks) return;
+  int ji = 0;
+#pragma unroll
+  for (int i = 1; i < SHADOW_MAXJ; ++i)
+    if (i < sb.n && gid >= sb.j[i].chunk_begin) ji = i;
+  const ShadowJob& J = sb.j[ji];
+  const int c = gid - J.chunk_begin;
+  // chunk c = ((w * KS + ks) * NTw + t) * 64 + lane
+  const int KS = J.K >> 4, NTw = J.N >> 7;
+  const int lane = c & 63;
+  int r = c >> 6;
+  const int t = r % NTw; r /= NTw;
+  const int ks = r % KS; const int w = r / KS;
+  const int n = 32 * (w * NTw + t) + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+  float v[8];
+  if (!J.transposed) {
+    int i = 0, nn = n;
+    while (i + 1 < J.nsrc && nn >= J.rows[i]) { nn -= J.rows[i]; ++i; }
+    const float* p = J.src[i] + (size_t)nn * J.ld[i] + k0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = p[e];
+  } else {
+    int i = 0, kk = k0;
+    while (i + 1 < J.nsrc && kk >= J.rows[i]) { kk -= J.rows[i]; ++i; }      // (source blocks are multiples of 8 rows)
+    const float* p = J.src[i] + (size_t)kk * J.ld[i] + n;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = p[(size_t)e * J.ld[i]];
+  }
+  reinterpret_cast<u32x4*>(J.dst)[c] = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+}
+
+// ------------------------------------------------------------------------------------------------ forward, front half
+constexpr int PX = 272;     // row pitch (bytes) of the [32][128] bf16 input tile: 256 + 16
+constexpr int PR = 528;     // ... of a [32][256] bf16 tile: a ds_read_b128 lane group's 16 rows land on 16 distinct bank quads
+constexpr int PQ = 1552;    // ... of the [32][768] bf16 [q | k' | v'] tile
+constexpr int F_BUFR = 32 * PX, F_BUFQ = F_BUFR + 32 * PR, F_LDS = F_BUFQ + 32 * PQ;      // 8704, 25600, 75264
+
+__global__ __launch_bounds__(256, 2) void front_kernel(const FrontArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const FrontStream& S = a.s[(int)blockIdx.x >= a.s[1].tile_begin ? 1 : 0];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = ((int)blockIdx.x - S.tile_begin) * 32;
+  const int nrows = min(32, S.M - row0);
+  char* bufX = smem; char* bufR = smem + F_BUFR; char* bufQ = smem + F_BUFQ;
+  {   // input tile: fp32 -> bf16, rows past the end cleared
+    const int r = tid >> 3, c = tid & 7;
+    const float4* src = reinterpret_cast<const float4*>(S.X + (size_t)(row0 + min(r, nrows - 1)) * 128 + 16 * c);
+    float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+    if (r >= nrows) { v0 = v1 = v2 = v3 = make_float4(0.f, 0.f, 0.f, 0.f); }
+    *reinterpret_cast<u32x4*>(bufX + r * PX + 32 * c) = u32x4{pack2(v0.x, v0.y), pack2(v0.z, v0.w), pack2(v1.x, v1.y), pack2(v1.z, v1.w)};
+    *reinterpret_cast<u32x4*>(bufX + r * PX + 32 * c + 16) = u32x4{pack2(v2.x, v2.y), pack2(v2.z, v2.w), pack2(v3.x, v3.y), pack2(v3.z, v3.w)};
+  }
+  __syncthreads();
+  if (a.save) copy_out<4>(bufX, PX, 0, S.X16, 128, row0, nrows);
+  // projection 128 -> 256
+  {
+    f32x16 acc[2] = {zero16(), zero16()};
+    stage_mma<2, 8, true>(reinterpret_cast<const u32x4*>(S.W0) + (size_t)w * (8 * 2 * 64) + lane, bufX + l31 * PX + 16 * h, acc);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
+        const float4 bv = *reinterpret_cast<const float4*>(S.b0 + c0);
+        *reinterpret_cast<u32x2*>(bufR + l31 * PR + 2 * c0) =
+            u32x2{pack2(acc[t][4 * g] + bv.x, acc[t][4 * g + 1] + bv.y), pack2(acc[t][4 * g + 2] + bv.z, acc[t][4 * g + 3] + bv.w)};
+      }
+  }
+  __syncthreads();
+  copy_out<5>(bufR, PR, 0, S.R16, 256, row0, nrows);
+  // in-projections 256 -> [256 q | 512 k', v'] (24 feature tiles, 6 per wave)
+  {
+    f32x16 acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) acc[t] = zero16();
+    stage_mma<6, 16, true>(reinterpret_cast<const u32x4*>(S.W1) + (size_t)w * (16 * 6 * 64) + lane, bufR + l31 * PR + 16 * h, acc);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      const int tg = 6 * w + t;                                  // wave-uniform
+      const float* bias = tg < 8 ? S.bq + 32 * tg : S.bkv + 32 * (tg - 8);
+      const float sc = tg < 8 ? a.qscale : 1.0f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 8 * g + 4 * h;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+        *reinterpret_cast<u32x2*>(bufQ + l31 * PQ + 2 * (32 * tg + c)) =
+            u32x2{pack2((acc[t][4 * g] + bv.x) * sc, (acc[t][4 * g + 1] + bv.y) * sc),
+                  pack2((acc[t][4 * g + 2] + bv.z) * sc, (acc[t][4 * g + 3] + bv.w) * sc)};
+      }
+    }
+  }
+  __syncthreads();
+  copy_out<5>(bufQ, PQ, 0, S.Q16, 256, row0, nrows);
+  copy_out<6>(bufQ, PQ, 512, S.KV16, 512, row0, nrows);
+}
+
+// ------------------------------------------------------------------------------------------------ forward, back half
+// LDS map (bytes).  Region A is the attention scratch and, once the attention and the out-projection are done with it, the
+// fp32 tile of the LayerNorm output whose columns are summed for the mean pool.
+constexpr int PK = 528;      // RG tile: the sample's 16 key rows [16][256] (ds_read_b128 fragments: rows 4 banks apart)
+constexpr int PV = 576;      // RG tile: the sample's 16 value rows [16][256] (transposing reads: rows 16 banks apart)
+constexpr int PVC = 192;     // KG block: a wave's 32-row x 64-feature value chunk (transposing reads)
+constexpr int PT = 260;      // fp32 tile pitch (floats)
+constexpr int B_VS = 16 * PK;                       // 8448
+constexpr int B_REGION_A = 32 * PT * 4;             // 33280 >= 8448 + 9216 (RG) and >= 4 * 32 * 192 (KG)
+constexpr int B_BUFO = B_REGION_A, B_BUFY = B_BUFO + 32 * PR, B_RED = B_BUFY + 32 * PR, B_LDS = B_RED + 1024;   // 33280, 50176, 67072, 68096
+
+// RG tile: rows [row0, row0 + nrows) of sample b against its Nk keys; wave w owns heads 2w, 2w+1.  Leaves the attention
+// output (bf16) in bufO.
+__device__ __forceinline__ void attn_rg_tile(const BackArgs& a, char* smem, int b, size_t row0, int nrows, int w, int lane) {
+  const int tid = threadIdx.x, l31 = lane & 31, h = lane >> 5, Nk = a.Nk;
+  char* Ks = smem; char* Vs = smem + B_VS; char* bufO = smem + B_BUFO;
+  // the sample's key | value rows: [Nk][512] bf16 -> two images, rows Nk..15 cleared
+  for (int c = tid; c < 16 * 64; c += 256) {
+    const int j = c >> 6, ch = c & 63;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (j < Nk) v = *reinterpret_cast<const u32x4*>(a.KV16 + ((size_t)b * Nk + j) * 512 + 8 * ch);
+    if (ch < 32) *reinterpret_cast<u32x4*>(Ks + j * PK + 16 * ch) = v;
+    else         *reinterpret_cast<u32x4*>(Vs + j * PV + 16 * (ch - 32)) = v;
+  }
+  // this lane's query fragments (B operand: lane = row, 8 consecutive features)
+  const us16* qrow = a.Q16 + (row0 + min(l31, nrows - 1)) * 256 + 64 * w + 8 * h;
+  bf16x8 qf[2][2];
+#pragma unroll
+  for (int hd = 0; hd < 2; ++hd)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[hd][s] = as_frag(*reinterpret_cast<const u32x4*>(qrow + 32 * hd + 16 * s));
+  __syncthreads();
+  const bool dodrop = a.drop.p > 0.f;
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+  for (int hd = 0; hd < 2; ++hd) {
+    const int head = 2 * w + hd;
+    // S^T[j][row] = K_h . Q_h^T  (queries are pre-scaled): lane = row, registers 0..7 = keys acc_row(i, h) < 16
+    f32x16 S = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (l31 & 15) * PK + 2 * (32 * head + 16 * s + 8 * h));
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[hd][s], S, 0, 0, 0);
+    }
+    float e[8], m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { e[i] = acc_row(i, h) < Nk ? S[i] : -INFINITY; m = fmaxf(m, e[i]); }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { e[i] = __expf(e[i] - m); sum += e[i]; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    const uint32_t ibase = ((uint32_t)(row0 + l31) * 8u + (uint32_t)head) * (uint32_t)Nk;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      e[i] *= inv;
+      if (dodrop) e[i] *= drop_mult(a.drop, SITE_ATTN_RG2KG, ibase + (uint32_t)acc_row(i, h));
+    }
+    const bf16x8 pf = as_frag(u32x4{pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])});
+    // O^T = V_h^T . P^T: one k step over the 16 keys; A fragment (lane = feature) element jj = key 8 (jj >> 2) + 4 h + (jj & 3)
+    const char* vp = Vs + (4 * h + q4) * PV + 2 * (32 * head + 16 * g1 + 4 * p4);
+    const bf16x8 vf = join(lds_tr16(vp), lds_tr16(vp + 8 * PV));
+    const f32x16 O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, zero16(), 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<u32x2*>(bufO + l31 * PR + 2 * (32 * head + 8 * g + 4 * h)) =
+          u32x2{pack2(O[4 * g], O[4 * g + 1]), pack2(O[4 * g + 2], O[4 * g + 3])};
+  }
+}
+
+// KG block: the Nk query rows of sample b against its nr RG keys (rows rb ..).  Two passes over the keys in 32-row chunks
+// (row max, then exp / sum / P.V), the key ROWS in the accumulator registers (lane = query), so nothing crosses lanes but
+// the final exchange between the lane halves.  Wave w owns heads 2w, 2w+1 and stages its value chunks privately.
+__device__ __forceinline__ void attn_kg_block(const BackArgs& a, char* smem, int b, int w, int lane) {
+  const int l31 = lane & 31, h = lane >> 5, Nk = a.Nk;
+  const int rb = a.off[b], nr = a.off[b + 1] - rb, nch = (nr + 31) >> 5;
+  char* Vt = smem + w * (32 * PVC);
+  char* bufO = smem + B_BUFO;
+  const us16* qrow = a.Q2_16 + ((size_t)b * Nk + min(l31, Nk - 1)) * 256 + 64 * w + 8 * h;
+  bf16x8 qf[2][2];
+#pragma unroll
+  for (int hd = 0; hd < 2; ++hd)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[hd][s] = as_frag(*reinterpret_cast<const u32x4*>(qrow + 32 * hd + 16 * s));
+  const us16* kbase = a.KV2_16 + (size_t)rb * 512 + 64 * w + 8 * h;
+  auto load_k = [&](u32x4 (&k)[2][2], int c) {
+    const us16* p = kbase + (size_t)min(32 * c + l31, nr - 1) * 512;
+#pragma unroll
+    for (int hd = 0; hd < 2; ++hd)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) k[hd][s] = *reinterpret_cast<const u32x4*>(p + 32 * hd + 16 * s);
+  };
+  auto scores = [&](const u32x4 (&k)[2][2], int hd) {
+    f32x16 S = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(k[hd][s]), qf[hd][s], S, 0, 0, 0);
+    return S;                                            // S[row acc_row(i, h) of the chunk][query l31]
+  };
+  // pass 1: per query the maximum over all keys
+  float mx[2] = {-INFINITY, -INFINITY};
+  {
+    u32x4 kc[2][2], kn[2][2];
+    load_k(kc, 0);
+    for (int c = 0; c < nch; ++c) {
+      load_k(kn, min(c + 1, nch - 1));
+#pragma unroll
+      for (int hd = 0; hd < 2; ++hd) {
+        const f32x16 S = scores(kc, hd);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx[hd] = (32 * c + acc_row(i, h) < nr) ? fmaxf(mx[hd], S[i]) : mx[hd];
+      }
+#pragma unroll
+      for (int hd = 0; hd < 2; ++hd)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) kc[hd][s] = kn[hd][s];
+    }
+    mx[0] = fmaxf(mx[0], __shfl_xor(mx[0], 32, 64));
+    mx[1] = fmaxf(mx[1], __shfl_xor(mx[1], 32, 64));
+  }
+  // pass 2
+  f32x16 Z[2] = {zero16(), zero16()};
+  float L[2] = {0.f, 0.f};
+  {
+    const bool dodrop = a.drop.p > 0.f;
+    const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    // value chunk: 32 rows x 128 bytes (this wave's two heads): lane-slot i covers row (lane + 64 i) >> 3, 16-byte chunk (lane + 64 i) & 7
+    const us16* vbase = a.KV2_16 + (size_t)rb * 512 + 256 + 64 * w;
+    auto load_v = [&](u32x4 (&v)[4], int c) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int id = lane + 64 * i;
+        v[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)min(32 * c + (id >> 3), nr - 1) * 512 + 8 * (id & 7));
+      }
+    };
+    u32x4 kc[2][2], kn[2][2], vc[4], vn[4];
+    load_k(kc, 0); load_v(vc, 0);
+    for (int c = 0; c < nch; ++c) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int id = lane + 64 * i; *reinterpret_cast<u32x4*>(Vt + (id >> 3) * PVC + 16 * (id & 7)) = vc[i]; }
+      const int cn = min(c + 1, nch - 1);
+      load_k(kn, cn); load_v(vn, cn);
+#pragma unroll
+      for (int hd = 0; hd < 2; ++hd) {
+        const f32x16 S = scores(kc, hd);
+        float e[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = 32 * c + acc_row(i, h);
+          e[i] = row < nr ? __expf(S[i] - mx[hd]) : 0.f;
+          L[hd] += e[i];
+          if (dodrop) e[i] *= drop_mult(a.drop, SITE_ATTN_KG2RG, ((uint32_t)(rb + row) * 8u + (uint32_t)(2 * w + hd)) * (uint32_t)Nk + (uint32_t)l31);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8 ef = as_frag(u32x4{pack2(e[8 * s], e[8 * s + 1]), pack2(e[8 * s + 2], e[8 * s + 3]),
+                                          pack2(e[8 * s + 4], e[8 * s + 5]), pack2(e[8 * s + 6], e[8 * s + 7])});
+          const char* vp = Vt + (16 * s + 4 * h + q4) * PVC + 2 * (32 * hd + 16 * g1 + 4 * p4);
+          const bf16x8 vf = join(lds_tr16(vp), lds_tr16(vp + 8 * PVC));
+          Z[hd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ef, vf, Z[hd], 0, 0, 0);      // Z[query][feature] += E^T . V
+        }
+      }
+#pragma unroll
+      for (int hd = 0; hd < 2; ++hd)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) kc[hd][s] = kn[hd][s];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vc[i] = vn[i];
+    }
+    L[0] += __shfl_xor(L[0], 32, 64);
+    L[1] += __shfl_xor(L[1], 32, 64);
+  }
+  // O2[j][feature] = Z / L[j]: Z has the query on its registers (0..7 -> j = acc_row(i, h) < 16), L lives on lane j
+#pragma unroll
+  for (int hd = 0; hd < 2; ++hd) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = acc_row(i, h);
+      const float Lj = __shfl(L[hd], j, 64);
+      if (j < Nk) *reinterpret_cast<us16*>(bufO + j * PR + 2 * (64 * w + 32 * hd + l31)) = f2bf(Z[hd][i] / Lj);
+    }
+    if (a.save && a.lse2 && lane < Nk) {
+      float* o = a.lse2 + (((size_t)b * 8 + 2 * w + hd) * 16 + lane) * 2;
+      o[0] = mx[hd]; o[1] = L[hd];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool kg = (int)blockIdx.x < a.B;                                   // the B long-running KG blocks are dispatched first
+  int b; size_t rowg0; int nrows; float inv_n;
+  if (kg) {
+    b = blockIdx.x; rowg0 = (size_t)b * a.Nk; nrows = a.Nk; inv_n = 1.0f / (float)a.Nk;
+  } else {
+    const int tile = (int)blockIdx.x - a.B;
+    if (tile >= a.tile_off[a.B]) return;
+    int lo = 0, hi = a.B - 1;                                              // sample of this tile: tile_off[b] <= tile < tile_off[b+1]
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_off[mid] <= tile) lo = mid; else hi = mid - 1; }
+    b = lo;
+    const int r0 = a.off[b] + 32 * (tile - a.tile_off[b]);
+    rowg0 = r0; nrows = min(32, a.off[b + 1] - r0); inv_n = a.inv_nr[b];
+  }
+  const BackStream& S = a.s[kg ? 1 : 0];
+  char* bufO = smem + B_BUFO; char* bufY = smem + B_BUFY;
+  float* red = reinterpret_cast<float*>(smem + B_RED);
+  float* tile32 = reinterpret_cast<float*>(smem);
+
+  if (kg) {
+    for (int c = tid; c < 32 * PR / 16; c += 256) reinterpret_cast<u32x4*>(bufO)[c] = u32x4{0u, 0u, 0u, 0u};   // rows >= Nk stay zero
+    __syncthreads();
+    attn_kg_block(a, smem, b, w, lane);
+  } else {
+    attn_rg_tile(a, smem, b, rowg0, nrows, w, lane);
+  }
+  __syncthreads();
+  if (a.save) copy_out<5>(bufO, PR, 0, S.O16, 256, rowg0, nrows);
+
+  // ---- out-projection + residual, LayerNorm (lane = row; wave w: features 64 w .. 64 w + 63)
+  const size_t rrow = rowg0 + min(l31, nrows - 1);
+  float u[32];
+  {
+    f32x16 acc[2] = {zero16(), zero16()};
+    stage_mma<2, 16, true>(reinterpret_cast<const u32x4*>(S.Wo) + (size_t)w * (16 * 2 * 64) + lane, bufO + l31 * PR + 16 * h, acc);
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
+        const float4 bv = *reinterpret_cast<const float4*>(S.bo + c0);
+        const u32x2 rv = *reinterpret_cast<const u32x2*>(S.R16 + rrow * 256 + c0);
+        float* o = u + 16 * t + 4 * g;
+        o[0] = acc[t][4 * g] + bv.x + bf_lo(rv.x); o[1] = acc[t][4 * g + 1] + bv.y + bf_hi(rv.x);
+        o[2] = acc[t][4 * g + 2] + bv.z + bf_lo(rv.y); o[3] = acc[t][4 * g + 3] + bv.w + bf_hi(rv.y);
+        part += (o[0] + o[1]) + (o[2] + o[3]);
+      }
+    // row totals: the lane's 32 values + the other lane half = this wave's 64 features; then the 4 waves through LDS
+    auto row_total = [&](float p, int slot) {
+      p += __shfl_xor(p, 32, 64);
+      if (h == 0) red[slot * 128 + w * 32 + l31] = p;
+      __syncthreads();
+      return (red[slot * 128 + l31] + red[slot * 128 + 32 + l31]) + (red[slot * 128 + 64 + l31] + red[slot * 128 + 96 + l31]);
+    };
+    const float mean = row_total(part, 0) * (1.0f / 256.0f);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { u[i] -= mean; sq = fmaf(u[i], u[i], sq); }
+    const float rstd = 1.0f / sqrtf(row_total(sq, 1) * (1.0f / 256.0f) + 1e-5f);
+    if (a.save && w == 0 && h == 0 && l31 < nrows) S.rstd[rowg0 + l31] = rstd;
+    // (both barriers of row_total are behind every wave's out-projection MFMAs: region A is free for the fp32 tile)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
+        const float4 gm = *reinterpret_cast<const float4*>(S.ln_g + c0), bt = *reinterpret_cast<const float4*>(S.ln_b + c0);
+        float* o = u + 16 * t + 4 * g;
+        const float x0 = o[0] * rstd, x1 = o[1] * rstd, x2 = o[2] * rstd, x3 = o[3] * rstd;
+        const float4 y = make_float4(x0 * gm.x + bt.x, x1 * gm.y + bt.y, x2 * gm.z + bt.z, x3 * gm.w + bt.w);
+        *reinterpret_cast<u32x2*>(bufY + l31 * PR + 2 * c0) = u32x2{pack2(y.x, y.y), pack2(y.z, y.w)};
+        *reinterpret_cast<float4*>(tile32 + l31 * PT + c0) = y;
+        if (a.save && l31 < nrows)
+          *reinterpret_cast<u32x2*>(S.XH16 + (rowg0 + l31) * 256 + c0) = u32x2{pack2(x0, x1), pack2(x2, x3)};
+      }
+  }
+  __syncthreads();
+  {   // mean pool of the LayerNorm output: thread t owns feature t
+    float sum = 0.f;
+    for (int r = 0; r < nrows; ++r) sum += tile32[r * PT + tid];
+    atomicAdd(S.Ymean + (size_t)b * 256 + tid, sum * inv_n);
+  }
+  if (a.save) copy_out<5>(bufY, PR, 0, S.Y16, 256, rowg0, nrows);
+
+  // ---- FFN layer 0 + ReLU + dropout, pooled over the rows (lane = feature; wave w: features 128 w .. 128 w + 127)
+  {
+    f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
+    stage_mma<4, 16, false>(reinterpret_cast<const u32x4*>(S.W1) + (size_t)w * (16 * 4 * 64) + lane, bufY + l31 * PR + 16 * h, acc);
+    const bool dodrop = a.drop.p > 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int f = 128 * w + 32 * t + l31;
+      const float bias = S.b1[f];
+      float colsum = 0.f;
+      uint32_t wlo = 0u, whi = 0u;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = acc_row(i, h);
+        float v = fmaxf(acc[t][i] + bias, 0.f);
+        if (dodrop) v *= drop_mult(a.drop, S.site_ffn, (uint32_t)(rowg0 + row) * 512u + (uint32_t)f);
+        if (row >= nrows) v = 0.f;
+        colsum += v;
+        if (a.save) {
+          const unsigned long long bal = __ballot(v > 0.f);
+          if (lane == i) { wlo = (uint32_t)bal; whi = (uint32_t)(bal >> 32); }
+        }
+      }
+      colsum += __shfl_xor(colsum, 32, 64);
+      if (h == 0) atomicAdd(S.Hmean + (size_t)b * 512 + f, colsum * inv_n);
+      if (a.save && lane < 16) {                       // lane i holds the words of rows acc_row(i, 0) and acc_row(i, 1), features 32 (4 w + t) ..
+        const int ra = acc_row(lane, 0);
+        if (ra < nrows) S.mask[(rowg0 + ra) * 16 + 4 * w + t] = wlo;
+        if (ra + 4 < nrows) S.mask[(rowg0 + ra + 4) * 16 + 4 * w + t] = whi;
+      }
+    }
+  }
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+size_t fused_front_lds() { return F_LDS; }
+size_t fused_back_lds() { return B_LDS; }
+
+int launch_weight_shadows(ShadowBatch& sb, hipStream_t stream) {
+  if (sb.n < 0 || sb.n > SHADOW_MAXJ) return (int)hipErrorInvalidValue;
+  int total = 0;
+  for (int i = 0; i < sb.n; ++i) {
+    ShadowJob& J = sb.j[i];
+    if ((J.N & 127) || (J.K & 15) || J.nsrc < 1 || J.nsrc > 3 || !J.dst || !al16(J.dst)) return (int)hipErrorInvalidValue;
+    int sum = 0;
+    for (int s = 0; s < J.nsrc; ++s) { if (!J.src[s] || (J.rows[s] & 7)) return (int)hipErrorInvalidValue; sum += J.rows[s]; }
+    if (sum != (J.transposed ? J.K : J.N)) return (int)hipErrorInvalidValue;
+    J.chunk_begin = total;
+    total += J.N * J.K / 8;
+  }
+  if (sb.zero_ptr && (!al16(sb.zero_ptr) || (sb.zero_bytes & 15))) return (int)hipErrorInvalidValue;
+  int blocks = (total + 255) / 256;
+  if (sb.zero_ptr && blocks < 64) blocks = 64;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(shadow_kernel, dim3(blocks), dim3(256), 0, stream, sb, total);
+  return (int)hipGetLastError();
+}
+
+int launch_fused_front(FrontArgs& a, hipStream_t stream) {
+  int total = 0;
+  for (int i = 0; i < 2; ++i) {
+    FrontStream& S = a.s[i];
+    if (S.M < 1 || !S.X || !S.W0 || !S.W1 || !S.b0 || !S.bq || !S.bkv || !S.R16 || !S.Q16 || !S.KV16 || (a.save && !S.X16))
+      return (int)hipErrorInvalidValue;
+    if (!al16(S.X) || !al16(S.b0) || !al16(S.bq) || !al16(S.bkv) || !al16(S.R16) || !al16(S.Q16) || !al16(S.KV16) || !al16(S.W0) || !al16(S.W1))
+      return (int)hipErrorInvalidValue;
+    S.tile_begin = total;
+    total += (S.M + 31) / 32;
+  }
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+    return true;
+  }();
+  (void)attr;
+  hipLaunchKernelGGL(front_kernel, dim3(total), dim3(256), F_LDS, stream, a);
+  return (int)hipGetLastError();
+}
+
+int launch_fused_back(BackArgs& a, hipStream_t stream) {
+  if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q16 || !a.KV16 || !a.Q2_16 || !a.KV2_16 || !a.off || !a.tile_off || !a.inv_nr)
+    return (int)hipErrorInvalidValue;
+  for (int i = 0; i < 2; ++i) {
+    const BackStream& S = a.s[i];
+    if (!S.Wo || !S.bo || !S.W1 || !S.b1 || !S.ln_g || !S.ln_b || !S.R16 || !S.Ymean || !S.Hmean) return (int)hipErrorInvalidValue;
+    if (a.save && (!S.O16 || !S.Y16 || !S.XH16 || !S.rstd || !S.mask)) return (int)hipErrorInvalidValue;
+    if (!al16(S.bo) || !al16(S.ln_g) || !al16(S.ln_b) || !al16(S.Wo) || !al16(S.W1) || !al16(S.R16)) return (int)hipErrorInvalidValue;
+  }
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&back_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS);
+    return true;
+  }();
+  (void)attr;
+  hipLaunchKernelGGL(back_kernel, dim3(a.B + a.rg_tiles_max), dim3(256), B_LDS, stream, a);
+  return (int)hipGetLastError();
+}

@@ -21,6 +21,7 @@
 
 #include "attn.h"
 #include "gemm.h"
+#include "fused_rows.h"
 #include "gemm16.h"
 #include "misc.h"
 #include "rg_gnn.h"
@@ -32,6 +33,8 @@ thread_local std::string g_err;
 // testing hook (camo_debug_set_option): -1 = choose the schedule from the configuration, 0 = never take the bf16-resident
 // schedule.  Set by tests that A/B the schedules in one process; never read from the environment.
 int g_opt_sched16 = -1;
+int g_opt_fused = -1;      // likewise for the fused row-tile schedule (fused_rows.h): 0 = never take it
+int g_opt_fused_save = 0;  // 1 = inference calls of the fused schedule also write what a backward would need (tests read it back)
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 int fail_hip(int e, const char* where) {
@@ -44,6 +47,7 @@ int fail_hip(int e, const char* where) {
     if (e_ != 0) return fail_hip(e_, where); \
   } while (0)
 
+typedef unsigned short us;
 struct Carver {
   char* base; size_t off;
   explicit Carver(void* b) : base(static_cast<char*>(b)), off(0) {}
@@ -54,6 +58,17 @@ struct Carver {
     return p;
   }
 };
+
+// The batch descriptor (camo_prepare_batch): [ row -> sample map | 1 / Nr | first 32-row tile of every sample ]
+struct Desc { int* row_sample; float* inv_nr; int* tile_off; size_t bytes; };
+Desc desc_carve(int B, int T, void* base) {
+  Desc d{};
+  Carver c(base);
+  d.row_sample = c.take<int>((size_t)T); d.inv_nr = c.take<float>((size_t)B); d.tile_off = c.take<int>((size_t)B + 1);
+  c.off = (c.off + 255) & ~size_t(255);
+  d.bytes = c.off;
+  return d;
+}
 
 struct Ws {
   // zeroed once per forward: [ means | dfused | dKV ] (accumulated into by atomics)
@@ -76,8 +91,20 @@ struct Ws {
     unsigned short *Wrg, *Wkg, *Win1, *Win2, *Wo1, *Wo2, *W1, *W2, *W1T, *W2T, *Wo1T, *Wo2T, *WcRgT, *WcKgT;
   } h;
   size_t Tp, TKp;
+  // fused row-tile schedule (fused_rows.h): weight shadows in MFMA-fragment order and the bf16 activations that cross
+  // its launches / are saved for backward.  Only carved at the reference configuration (fused17_dims).
+  struct F17 {
+    us16 *Wrg, *Wkg, *Wqkv_rg, *Wqkv_kg, *Wo1, *Wo2, *W1, *W2;
+    us16 *X16, *KG16, *R16, *G16, *Q16, *Q2_16, *KV16, *KV2_16, *O16, *O2_16, *Y16, *Y2_16, *XH16, *XH2_16;
+    float *rstd1, *rstd2, *lse2; uint32_t *mask1, *mask2;
+  } f;
   size_t bytes;
 };
+
+// the fused row-tile kernels are written for the reference configuration
+bool fused17_dims(const camo_dims_t& d) {
+  return d.fusion_type == CAMO_FUSION_CROSS_ATTENTION && d.hidden_dim == 256 && d.num_heads == 8 && d.rg_dim == 128 && d.kg_dim == 128;
+}
 
 Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
   Ws w{};
@@ -116,7 +143,6 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
     w.dS2 = c.take<float>(T * nh * Nk);
     w.dR = c.take<float>(T * H); w.dG = c.take<float>(TK * H);
     {
-      typedef unsigned short us;
       const size_t Tp = ((size_t)T + 127) / 128 * 128, TKp = (TK + 127) / 128 * 128, D = d.rg_dim, Dk = d.kg_dim;
       w.Tp = Tp; w.TKp = TKp;
       Ws::H16& h = w.h;
@@ -129,6 +155,17 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
       h.W1T = c.take<us>(2 * H * H); h.W2T = c.take<us>(2 * H * H); h.Wo1T = c.take<us>(H * H); h.Wo2T = c.take<us>(H * H);
       h.WcRgT = c.take<us>(3 * H * H); h.WcKgT = c.take<us>(3 * H * H);
       h.H1 = c.take<us>(Tp * 2 * H); h.H2 = c.take<us>(TKp * 2 * H);      // (padded: they double as weight-gradient operands)
+      if (fused17_dims(d)) {
+        Ws::F17& f = w.f;
+        f.Wrg = c.take<us>(H * D); f.Wkg = c.take<us>(H * Dk); f.Wqkv_rg = c.take<us>(3 * H * H); f.Wqkv_kg = c.take<us>(3 * H * H);
+        f.Wo1 = c.take<us>(H * H); f.Wo2 = c.take<us>(H * H); f.W1 = c.take<us>(2 * H * H); f.W2 = c.take<us>(2 * H * H);
+        f.X16 = c.take<us>(Tp * D); f.KG16 = c.take<us>(TKp * Dk); f.R16 = c.take<us>(Tp * H); f.G16 = c.take<us>(TKp * H);
+        f.Q16 = c.take<us>(Tp * H); f.Q2_16 = c.take<us>(TKp * H); f.KV16 = c.take<us>(TKp * 2 * H); f.KV2_16 = c.take<us>(Tp * 2 * H);
+        f.O16 = c.take<us>(Tp * H); f.O2_16 = c.take<us>(TKp * H); f.Y16 = c.take<us>(Tp * H); f.Y2_16 = c.take<us>(TKp * H);
+        f.XH16 = c.take<us>(Tp * H); f.XH2_16 = c.take<us>(TKp * H);
+        f.rstd1 = c.take<float>(Tp); f.rstd2 = c.take<float>(TKp); f.lse2 = c.take<float>((size_t)B * 8 * 16 * 2);
+        f.mask1 = c.take<uint32_t>(Tp * 16); f.mask2 = c.take<uint32_t>(TKp * 16);
+      }
     }
   } else {
     const size_t F = H / 2, Fh = F / 2, Dc = (size_t)d.rg_dim + d.kg_dim;
@@ -219,7 +256,6 @@ void set_bcast(GemmProb& p, const float* v, int ldv, const int* row_sample, cons
 }
 
 // ---- the bf16 schedule's GEMM batch (gemm16.h) ------------------------------------------------
-typedef unsigned short us;
 struct GB16 {
   Gemm16Batch b; hipStream_t st;
   GB16(const DropCfg& d, hipStream_t st_) : st(st_) { std::memset(&b, 0, sizeof(b)); b.drop = d; }
@@ -408,6 +444,50 @@ int forward_nodes16(const camo_dims_t& d, const float* const* P, const float* rg
   return 0;
 }
 
+// ---- node-level forward of the fused row-tile schedule: the same function in 3 launches (fused_rows.h) ----
+bool fused17_ok(const camo_dims_t& d, const float* const* P, int precision, int Nk) {
+  return g_opt_fused != 0 && precision == CAMO_PREC_BF16 && fused17_dims(d) && Nk <= 16 && P[CAMO_P_RG_PROJ_W] && P[CAMO_P_KG_PROJ_W];
+}
+
+int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg, const int32_t* rg_offsets, const Desc& bd,
+                    const float* kg, int B, int T, int Nk, const Ws& w, const DropCfg& drop, bool save, hipStream_t st) {
+  const int H = 256, D = 128, TK = B * Nk;
+  const size_t HH = (size_t)H * H;
+  const Ws::F17& f = w.f;
+  {   // weight shadows (bf16, fragment order) + the clear of the step's atomics block
+    ShadowBatch sb; std::memset(&sb, 0, sizeof(sb));
+    auto job = [&](us* dst, int N, int K, const float* s0, int r0, const float* s1 = nullptr, int r1 = 0) {
+      ShadowJob& J = sb.j[sb.n++];
+      J.dst = dst; J.N = N; J.K = K; J.transposed = 0; J.nsrc = s1 ? 2 : 1;
+      J.src[0] = s0; J.rows[0] = r0; J.ld[0] = K; J.src[1] = s1; J.rows[1] = r1; J.ld[1] = K;
+    };
+    job(f.Wrg, H, D, P[CAMO_P_RG_PROJ_W], H); job(f.Wkg, H, D, P[CAMO_P_KG_PROJ_W], H);
+    job(f.Wqkv_rg, 3 * H, H, P[CAMO_P_A1_IN_W], H, P[CAMO_P_A2_IN_W] + HH, 2 * H);       // [Wq1; Wk2; Wv2]: what RG rows are projected with
+    job(f.Wqkv_kg, 3 * H, H, P[CAMO_P_A2_IN_W], H, P[CAMO_P_A1_IN_W] + HH, 2 * H);       // [Wq2; Wk1; Wv1]
+    job(f.Wo1, H, H, P[CAMO_P_A1_OUT_W], H); job(f.Wo2, H, H, P[CAMO_P_A2_OUT_W], H);
+    job(f.W1, 2 * H, H, P[CAMO_P_F1_W0], 2 * H); job(f.W2, 2 * H, H, P[CAMO_P_F2_W0], 2 * H);
+    sb.zero_ptr = w.zero_base;
+    sb.zero_bytes = ((size_t)(reinterpret_cast<char*>(w.dKV) - reinterpret_cast<char*>(w.zero_base)) + 15) & ~size_t(15);
+    CK(launch_weight_shadows(sb, st), "weight shadows");
+  }
+  FrontArgs fa; std::memset(&fa, 0, sizeof(fa));
+  fa.qscale = 1.0f / sqrtf(32.0f); fa.save = save ? 1 : 0;
+  fa.s[0] = FrontStream{rg, T, f.Wrg, P[CAMO_P_RG_PROJ_B], f.Wqkv_rg, P[CAMO_P_A1_IN_B], P[CAMO_P_A2_IN_B] + H, f.X16, f.R16, f.Q16, f.KV2_16, 0};
+  fa.s[1] = FrontStream{kg, TK, f.Wkg, P[CAMO_P_KG_PROJ_B], f.Wqkv_kg, P[CAMO_P_A2_IN_B], P[CAMO_P_A1_IN_B] + H, f.KG16, f.G16, f.Q2_16, f.KV16, 0};
+  CK(launch_fused_front(fa, st), "fused forward, front half");
+  BackArgs ba; std::memset(&ba, 0, sizeof(ba));
+  ba.s[0] = BackStream{f.Wo1, P[CAMO_P_A1_OUT_B], f.W1, P[CAMO_P_F1_B0], P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], f.R16,
+                       f.O16, f.Y16, f.XH16, f.rstd1, f.mask1, w.Ymean, w.H1mean, SITE_FFN_RG};
+  ba.s[1] = BackStream{f.Wo2, P[CAMO_P_A2_OUT_B], f.W2, P[CAMO_P_F2_B0], P[CAMO_P_LN2_W], P[CAMO_P_LN2_B], f.G16,
+                       f.O2_16, f.Y2_16, f.XH2_16, f.rstd2, f.mask2, w.Y2mean, w.H2mean, SITE_FFN_KG};
+  ba.Q16 = f.Q16; ba.KV16 = f.KV16; ba.Q2_16 = f.Q2_16; ba.KV2_16 = f.KV2_16;
+  ba.off = rg_offsets; ba.tile_off = bd.tile_off; ba.inv_nr = bd.inv_nr; ba.lse2 = f.lse2;
+  ba.B = B; ba.Nk = Nk; ba.rg_tiles_max = T / 32 + B;          // >= sum of ceil(Nr / 32); surplus blocks exit at once
+  ba.drop = drop; ba.save = save ? 1 : 0;
+  CK(launch_fused_back(ba, st), "fused forward, back half");
+  return 0;
+}
+
 // ---- node-level backward of the bf16 schedule (w.dcomb, w.dHm1, w.dHm2 hold the pooled gradients) ----
 int backward_nodes16(const camo_dims_t& d, const float* const* P, float* const* Gr, const int32_t* rg_offsets,
                      const int32_t* row_sample, const float* inv_nr, int B, int T, int Nk, int max_nr, const Ws& w,
@@ -500,20 +580,29 @@ size_t camo_workspace_bytes(const camo_dims_t* dims, int32_t B, int32_t T, int32
   return carve(*dims, B, T, Nk, nullptr).bytes;
 }
 
-int camo_prepare_batch(const int32_t* rg_offsets, int32_t B, int32_t max_nr, int32_t* row_sample, float* inv_nr, void* stream) {
-  if (!rg_offsets || !row_sample || !inv_nr || B < 1 || max_nr < 1) return fail(CAMO_E_ARG, "bad prepare_batch arguments");
-  CK(launch_rowmap(rg_offsets, row_sample, inv_nr, B, max_nr, static_cast<hipStream_t>(stream)), "rowmap");
+size_t camo_batch_desc_bytes(int32_t B, int32_t T) {
+  if (B < 1 || T < B) { fail(CAMO_E_ARG, "need B >= 1 and T >= B"); return 0; }
+  return desc_carve(B, T, nullptr).bytes;
+}
+
+int camo_prepare_batch(const int32_t* rg_offsets, int32_t B, int32_t T, int32_t max_nr, void* desc, size_t desc_bytes, void* stream) {
+  if (!rg_offsets || !desc || B < 1 || T < B || max_nr < 1 || max_nr > T) return fail(CAMO_E_ARG, "bad prepare_batch arguments");
+  const Desc d = desc_carve(B, T, desc);
+  if (desc_bytes < d.bytes) return fail(CAMO_E_WORKSPACE, "descriptor buffer smaller than camo_batch_desc_bytes()");
+  CK(launch_rowmap(rg_offsets, d.row_sample, d.inv_nr, d.tile_off, B, max_nr, static_cast<hipStream_t>(stream)), "rowmap");
   return 0;
 }
 
 static int forward_impl(const camo_dims_t* dims, const float* const* params, const float* rg, const int32_t* rg_offsets,
-                        const int32_t* row_sample, const float* inv_nr,
+                        const void* desc,
                         const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace,
                         size_t workspace_bytes, float* outs, float* attn_rg2kg, float* attn_kg2rg, int32_t training,
-                        uint64_t seed, int32_t precision, void* stream, const FusedLoss* fl) {
+                        uint64_t seed, int32_t precision, int32_t flags, void* stream, const FusedLoss* fl) {
   if (int e = check_dims(dims, B, T, Nk)) return e;
-  if (!params || !rg || !rg_offsets || !row_sample || !inv_nr || !kg || !workspace || !outs)
+  if (!params || !rg || !rg_offsets || !desc || !kg || !workspace || !outs)
     return fail(CAMO_E_ARG, "null pointer argument");
+  const Desc bd = desc_carve(B, T, const_cast<void*>(desc));
+  const int32_t* row_sample = bd.row_sample; const float* inv_nr = bd.inv_nr;
   if (max_nr < 1 || max_nr > T) return fail(CAMO_E_ARG, "max_nr out of range");
   if (precision != CAMO_PREC_F32 && precision != CAMO_PREC_BF16) return fail(CAMO_E_ARG, "unknown precision");
   const camo_dims_t& d = *dims;
@@ -527,8 +616,11 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   GB gt(drop, CAMO_PREC_F32, st);   // per-sample (B-row) GEMMs
   // one clear of everything this step accumulates into with atomics (means now, dfused/dKV in backward);
   // the bf16 schedule's prep launch does it along with its casts
-  const bool use16 = sched16_ok(d, P, precision, T, Nk, max_nr);
-  if (!use16) CK((int)hipMemsetAsync(w.zero_base, 0, w.zero_bytes, st), "memset zero block");
+  // inference calls (nothing saved for a backward, no attention maps asked for) at the reference configuration take the
+  // fused row-tile schedule
+  const bool use17 = (flags & CAMO_FWD_INFERENCE) && !attn_rg2kg && !attn_kg2rg && fused17_ok(d, P, precision, Nk);
+  const bool use16 = !use17 && sched16_ok(d, P, precision, T, Nk, max_nr);
+  if (!use16 && !use17) CK((int)hipMemsetAsync(w.zero_base, 0, w.zero_bytes, st), "memset zero block");
 
   if (d.fusion_type == CAMO_FUSION_LATE) {
     // LateFusion.forward, fusion_model.py:164-171
@@ -549,7 +641,9 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   if (!P[CAMO_P_RG_PROJ_W] && D != H) return fail(CAMO_E_ARG, "rg_proj weight missing but rg_dim != hidden_dim");
   if (!P[CAMO_P_KG_PROJ_W] && Dk != H) return fail(CAMO_E_ARG, "kg_proj weight missing but kg_dim != hidden_dim");
   const size_t HH2 = (size_t)H * H;
-  if (use16) {
+  if (use17) {
+    if (int e = forward_nodes17(d, P, rg, rg_offsets, bd, kg, B, T, Nk, w, drop, g_opt_fused_save != 0, st)) return e;
+  } else if (use16) {
     if (int e = forward_nodes16(d, P, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, w, attn_rg2kg, attn_kg2rg, drop, st)) return e;
   } else {
   if (P[CAMO_P_KG_PROJ_W]) { g.nt(kg, Dk, P[CAMO_P_KG_PROJ_W], Dk, P[CAMO_P_KG_PROJ_B], w.G, H, TK, H, Dk); G = w.G; }
@@ -579,8 +673,8 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   CK(g.run(), "ffn layer 0");
   }
   // per-sample means of Y and H1d, then the second FFN layer on the means (mean-pool linearity)
-  if (use16) {
-    // accumulated by layernorm fwd and the FFN GEMM epilogue
+  if (use16 || use17) {
+    // accumulated by the kernels that produce the pooled tensors
   } else {
     SegMean sm[4] = {{w.Y, H, H, rg_offsets, 0, w.Ymean, H}, {w.H1, 2 * H, 2 * H, rg_offsets, 0, w.H1mean, 2 * H},
                      {w.Y2, H, H, nullptr, Nk, w.Y2mean, H}, {w.H2, 2 * H, 2 * H, nullptr, Nk, w.H2mean, 2 * H}};
@@ -598,22 +692,24 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
 }
 
 int camo_forward(const camo_dims_t* dims, const float* const* params, const float* rg, const int32_t* rg_offsets,
-                 const int32_t* row_sample, const float* inv_nr,
+                 const void* batch_desc,
                  const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace,
                  size_t workspace_bytes, float* outs, float* attn_rg2kg, float* attn_kg2rg, int32_t training,
-                 uint64_t seed, int32_t precision, void* stream) {
-  return forward_impl(dims, params, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
-                      attn_rg2kg, attn_kg2rg, training, seed, precision, stream, nullptr);
+                 uint64_t seed, int32_t precision, int32_t flags, void* stream) {
+  return forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
+                      attn_rg2kg, attn_kg2rg, training, seed, precision, flags, stream, nullptr);
 }
 
 static int backward_impl(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
-                         const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr, const float* kg, int32_t B,
+                         const int32_t* rg_offsets, const void* desc, const float* kg, int32_t B,
                          int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes, const float* outs,
                          const float* d_outs, int32_t d_outs_pre_activation, int32_t training, uint64_t seed, int32_t precision,
                          void* stream, bool heads_out_done) {
   if (int e = check_dims(dims, B, T, Nk)) return e;
-  if (!params || !grads || !rg || !rg_offsets || !row_sample || !inv_nr || !kg || !workspace || !outs || (!d_outs && !heads_out_done))
+  if (!params || !grads || !rg || !rg_offsets || !desc || !kg || !workspace || !outs || (!d_outs && !heads_out_done))
     return fail(CAMO_E_ARG, "null pointer argument");
+  const Desc bd = desc_carve(B, T, const_cast<void*>(desc));
+  const int32_t* row_sample = bd.row_sample; const float* inv_nr = bd.inv_nr;
   if (max_nr < 1 || max_nr > T) return fail(CAMO_E_ARG, "max_nr out of range");
   if (precision != CAMO_PREC_F32 && precision != CAMO_PREC_BF16) return fail(CAMO_E_ARG, "unknown precision");
   const camo_dims_t& d = *dims;
@@ -703,16 +799,16 @@ static int backward_impl(const camo_dims_t* dims, const float* const* params, fl
 }
 
 int camo_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
-                  const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr, const float* kg, int32_t B,
+                  const int32_t* rg_offsets, const void* batch_desc, const float* kg, int32_t B,
                   int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes, const float* outs,
                   const float* d_outs, int32_t d_outs_pre_activation, int32_t training, uint64_t seed, int32_t precision,
                   void* stream) {
-  return backward_impl(dims, params, grads, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
+  return backward_impl(dims, params, grads, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
                        d_outs, d_outs_pre_activation, training, seed, precision, stream, false);
 }
 
 int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
-                               const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr, const float* kg,
+                               const int32_t* rg_offsets, const void* batch_desc, const float* kg,
                                int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes,
                                const int64_t* y, const float* e, const float* s, float* outs, float* loss_terms, int32_t* pred,
                                int32_t training, uint64_t seed, int32_t precision, void* stream) {
@@ -721,18 +817,18 @@ int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* para
   const bool fuse = heads_loss_ok(B, dims->num_classes);
   if (fuse) {
     const FusedLoss fl{y, e, s, loss_terms, pred, grads + head0};
-    if (int rc = forward_impl(dims, params, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
-                              nullptr, nullptr, training, seed, precision, stream, &fl)) return rc;
-    return backward_impl(dims, params, grads, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes,
+    if (int rc = forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
+                              nullptr, nullptr, training, seed, precision, 0, stream, &fl)) return rc;
+    return backward_impl(dims, params, grads, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes,
                          outs, nullptr, 1, training, seed, precision, stream, true);
   }
   // large batches / many classes: the three steps as separate launches, d(loss)/d(pre-activation) staged in the workspace
-  if (int rc = forward_impl(dims, params, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
-                            nullptr, nullptr, training, seed, precision, stream, nullptr)) return rc;
+  if (int rc = forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
+                            nullptr, nullptr, training, seed, precision, 0, stream, nullptr)) return rc;
   const Ws w = carve(*dims, B, T, Nk, workspace);
   CK(launch_loss(outs, reinterpret_cast<const long long*>(y), e, s, B, dims->num_classes, loss_terms, nullptr, w.dlog, pred,
                  static_cast<hipStream_t>(stream)), "loss");
-  return backward_impl(dims, params, grads, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, workspace, workspace_bytes,
+  return backward_impl(dims, params, grads, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes,
                        outs, w.dlog, 1, training, seed, precision, stream, false);
 }
 
@@ -790,6 +886,8 @@ int camo_debug_gemm16(const void* A16, int32_t lda, const void* B16, int32_t ldb
 int camo_debug_set_option(const char* name, int32_t value) {
   if (!name) return fail(CAMO_E_ARG, "option name is null");
   if (std::strcmp(name, "sched16") == 0) { g_opt_sched16 = value; return 0; }
+  if (std::strcmp(name, "fused") == 0) { g_opt_fused = value; return 0; }
+  if (std::strcmp(name, "fused_save") == 0) { g_opt_fused_save = value; return 0; }
   return fail(CAMO_E_ARG, std::string("unknown option ") + name);
 }
 
@@ -809,12 +907,16 @@ int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int3
   if (check_dims(dims, B, T, Nk) || !name) return -1;
   char* base = reinterpret_cast<char*>(4096);
   const Ws w = carve(*dims, B, T, Nk, base);
-  const struct { const char* n; const float* p; } tab[] = {
+  const struct { const char* n; const void* p; } tab[] = {
+      {"R16", w.f.R16}, {"G16", w.f.G16}, {"Q16", w.f.Q16}, {"Q2_16", w.f.Q2_16}, {"KV16", w.f.KV16}, {"KV2_16", w.f.KV2_16},
+      {"O16", w.f.O16}, {"O2_16", w.f.O2_16}, {"Y16", w.f.Y16}, {"Y2_16", w.f.Y2_16}, {"XH16", w.f.XH16}, {"XH2_16", w.f.XH2_16},
+      {"rstd1", w.f.rstd1}, {"rstd2", w.f.rstd2}, {"mask1", w.f.mask1}, {"mask2", w.f.mask2}, {"lse2", w.f.lse2}, {"X16", w.f.X16},
+      {"Wqkv_rg", w.f.Wqkv_rg}, {"W1s", w.f.W1}, {"Ymean", w.Ymean}, {"H1mean", w.H1mean}, {"Y2mean", w.Y2mean}, {"H2mean", w.H2mean},
       {"R", w.R}, {"G", w.G}, {"Q", w.Q}, {"KV2", w.KV2}, {"KV", w.KV}, {"Q2", w.Q2}, {"P", w.P}, {"P2", w.P2},
       {"O", w.O}, {"O2", w.O2}, {"U", w.U}, {"U2", w.U2}, {"Y", w.Y}, {"Y2", w.Y2}, {"H1", w.H1}, {"H2", w.H2},
       {"comb", w.comb}, {"fused", w.fused}};
   for (const auto& e : tab)
-    if (std::strcmp(e.n, name) == 0 && e.p) return reinterpret_cast<const char*>(e.p) - base;
+    if (std::strcmp(e.n, name) == 0 && e.p) return static_cast<const char*>(e.p) - base;
   return -1;
 }
 

@@ -17,6 +17,24 @@ __global__ void rowmap_kernel(const int* __restrict__ offs, int* __restrict__ ro
   if (r == 0) inv_nr[b] = 1.0f / (float)nr;
 }
 
+// first 32-row tile of every sample (fused_rows.hip tiles a sample's rows in 32s): exclusive scan of ceil(Nr / 32)
+__global__ __launch_bounds__(256) void tileoff_kernel(const int* __restrict__ offs, int* __restrict__ tile_off, int B) {
+  __shared__ int part[256];
+  const int t = threadIdx.x, per = (B + 255) / 256, b0 = min(B, t * per), b1 = min(B, b0 + per);
+  int s = 0;
+  for (int b = b0; b < b1; ++b) s += (offs[b + 1] - offs[b] + 31) >> 5;
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = acc; acc += v; }
+    tile_off[B] = acc;
+  }
+  __syncthreads();
+  int acc = part[t];
+  for (int b = b0; b < b1; ++b) { tile_off[b] = acc; acc += (offs[b + 1] - offs[b] + 31) >> 5; }
+}
+
 // ---------------------------------------------------------------- LayerNorm forward
 // y = (u - mean) * rstd * gamma + beta, eps 1e-5 (nn.LayerNorm default, fusion_model.py:49-50)
 // A wave owns LNF_R consecutive rows.  Optional fused mean pool (S.mean): the wave keeps per-lane column sums
@@ -584,8 +602,9 @@ int launch_prep(PrepBatch& pb, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int B, int max_nr, hipStream_t stream) {
+int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int* tile_off, int B, int max_nr, hipStream_t stream) {
   hipLaunchKernelGGL(rowmap_kernel, dim3((max_nr + 255) / 256, B), dim3(256), 0, stream, offs, row_sample, inv_nr);
+  hipLaunchKernelGGL(tileoff_kernel, dim3(1), dim3(256), 0, stream, offs, tile_off, B);
   return (int)hipGetLastError();
 }
 

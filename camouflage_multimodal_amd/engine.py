@@ -65,10 +65,10 @@ def check_labels(mask_label, num_classes):
 
 class Batch:
     """A packed minibatch on the device, ready for the C ABI."""
-    __slots__ = ("rg", "kg", "offsets", "row_sample", "inv_nr", "nrs", "B", "T", "Nk", "max_nr")
+    __slots__ = ("rg", "kg", "offsets", "desc", "nrs", "B", "T", "Nk", "max_nr")
 
-    def __init__(self, rg, kg, offsets, row_sample, inv_nr, nrs):
-        self.rg, self.kg, self.offsets, self.row_sample, self.inv_nr, self.nrs = rg, kg, offsets, row_sample, inv_nr, nrs
+    def __init__(self, rg, kg, offsets, desc, nrs):
+        self.rg, self.kg, self.offsets, self.desc, self.nrs = rg, kg, offsets, desc, nrs
         self.B, self.T, self.Nk, self.max_nr = len(nrs), rg.shape[0], kg.shape[1], max(nrs)
 
 
@@ -197,20 +197,23 @@ class FusionEngine:
         key = tuple(nrs)
         desc = self._offsets_cache.get(key)
         if desc is None:
-            # batch descriptor (row offsets, row -> sample map, 1/Nr): built once per distinct shape tuple
+            # batch descriptor (row offsets + the library's opaque row/tile maps): built once per distinct shape tuple
             if len(self._offsets_cache) > 1024:
                 self._offsets_cache.clear()
             host = torch.zeros(B + 1, dtype=torch.int32)
             host[1:] = torch.tensor(nrs, dtype=torch.int32).cumsum(0)
             offs = host.to(rg_packed.device, non_blocking=False)
-            row_sample = torch.empty(sum(nrs), dtype=torch.int32, device=rg_packed.device)
-            inv_nr = torch.empty(B, dtype=torch.float32, device=rg_packed.device)
+            T = sum(nrs)
+            nbytes = _lib.lib().camo_batch_desc_bytes(B, T)
+            if nbytes == 0:
+                _lib.check(-1, "camo_batch_desc_bytes")
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=rg_packed.device)
             with _on(self.device):
-                _lib.check(_lib.lib().camo_prepare_batch(_ptr(offs), B, max(nrs), _ptr(row_sample), _ptr(inv_nr),
+                _lib.check(_lib.lib().camo_prepare_batch(_ptr(offs), B, T, max(nrs), _ptr(buf), nbytes,
                                                          _stream_ptr(self.device)), "camo_prepare_batch")
-            desc = (offs, row_sample, inv_nr)
+            desc = (offs, buf)
             self._offsets_cache[key] = desc
-        return Batch(rg_packed, kg, desc[0], desc[1], desc[2], nrs)
+        return Batch(rg_packed, kg, desc[0], desc[1], nrs)
 
     def workspace(self, batch, private=False):
         need = _lib.lib().camo_workspace_bytes(C.byref(self.dims), batch.B, batch.T, batch.Nk)
@@ -227,7 +230,8 @@ class FusionEngine:
         return (self._seed_base + 0x9E3779B97F4A7C15 * self._calls) & 0xFFFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------ raw calls
-    def forward_raw(self, batch, ws, training, seed, want_attention=False, outs=None):
+    def forward_raw(self, batch, ws, training, seed, want_attention=False, outs=None, inference=False):
+        """``inference``: no backward_raw will follow on this workspace (lets the library skip what it would save)."""
         mod = self.module()
         if outs is None:
             outs = torch.empty(batch.B, self.out_width, dtype=torch.float32, device=batch.rg.device)
@@ -237,8 +241,9 @@ class FusionEngine:
             a2 = torch.empty(batch.T, batch.Nk, dtype=torch.float32, device=batch.rg.device)
         with _on(self.device):
             rc = _lib.lib().camo_forward(C.byref(self.dims), self._ptab, _ptr(batch.rg), _ptr(batch.offsets),
-                                         _ptr(batch.row_sample), _ptr(batch.inv_nr), _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs),
-                                         _ptr(a1), _ptr(a2), int(bool(training)), seed, _PREC[mod.precision], _stream_ptr(self.device))
+                                         _ptr(batch.desc), _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs),
+                                         _ptr(a1), _ptr(a2), int(bool(training)), seed, _PREC[mod.precision],
+                                         _lib.FWD_INFERENCE if inference else 0, _stream_ptr(self.device))
         _lib.check(rc, "camo_forward")
         return outs, ((a1, a2) if a1 is not None else None)
 
@@ -247,7 +252,7 @@ class FusionEngine:
         self._same_device(d_outs, "d_outs")
         with _on(self.device):
             rc = _lib.lib().camo_backward(C.byref(self.dims), self._ptab, gtab, _ptr(batch.rg), _ptr(batch.offsets),
-                                          _ptr(batch.row_sample), _ptr(batch.inv_nr), _ptr(batch.kg), batch.B, batch.T,
+                                          _ptr(batch.desc), _ptr(batch.kg), batch.B, batch.T,
                                           batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs), _ptr(d_outs),
                                           int(bool(pre_activation)), int(bool(training)), seed, _PREC[mod.precision],
                                           _stream_ptr(self.device))
@@ -267,7 +272,7 @@ class FusionEngine:
         pred = torch.empty(batch.B, dtype=torch.int32, device=dev)
         with _on(self.device):
             rc = _lib.lib().camo_forward_loss_backward(
-                C.byref(self.dims), self._ptab, gtab, _ptr(batch.rg), _ptr(batch.offsets), _ptr(batch.row_sample), _ptr(batch.inv_nr),
+                C.byref(self.dims), self._ptab, gtab, _ptr(batch.rg), _ptr(batch.offsets), _ptr(batch.desc),
                 _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(y), _ptr(e), _ptr(s),
                 _ptr(outs), _ptr(terms), _ptr(pred), int(bool(training)), seed, _PREC[mod.precision], _stream_ptr(self.device))
         _lib.check(rc, "camo_forward_loss_backward")
@@ -282,7 +287,7 @@ class FusionEngine:
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         seed = self.next_seed()
         if not needs_grad:
-            return self.forward_raw(batch, self.workspace(batch), mod.training, seed, want_attention)
+            return self.forward_raw(batch, self.workspace(batch), mod.training, seed, want_attention, inference=True)
         ws = self.workspace(batch, private=True)   # saved activations live until this call's backward
         res = _FusionFn.apply(self, batch, ws, mod.training, seed, want_attention and self.cross, *params)
         if want_attention and self.cross:

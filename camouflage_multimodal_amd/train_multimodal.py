@@ -206,7 +206,7 @@ class NativeTrainer:
     def evaluate(self, rg_packed, nrs, kg):
         eng = self.engine
         batch = eng.make_batch(rg_packed, nrs, kg)
-        outs, _ = eng.forward_raw(batch, eng.workspace(batch), False, 0)
+        outs, _ = eng.forward_raw(batch, eng.workspace(batch), False, 0, inference=True)
         return outs
 
 
@@ -234,7 +234,7 @@ def validate_fixed(model, dataloader, device):
             rg, nrs, kg, y, _, _ = batch if isinstance(batch, tuple) else pack_samples(batch, device)
             y = y.to(device)
             b = eng.make_batch(rg, nrs, kg)
-            outs, _ = eng.forward_raw(b, eng.workspace(b), False, 0)
+            outs, _ = eng.forward_raw(b, eng.workspace(b), False, 0, inference=True)
             logits = outs[:, :C]
             ce.append(torch.logsumexp(logits, dim=1) - logits.gather(1, y[:, None]).squeeze(1))
             preds.append(logits.argmax(dim=1)); labels.append(y)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CAMO_ABI_VERSION 3
+#define CAMO_ABI_VERSION 4
 
 enum {
   CAMO_OK = 0,
@@ -95,8 +95,9 @@ size_t camo_workspace_bytes(const camo_dims_t* dims, int32_t B, int32_t T, int32
  * (:86-105, done by the host).
  *   rg          [T, rg_dim]           packed RG node embeddings
  *   rg_offsets  int32 [B+1]           device; rg_offsets[0]=0, rg_offsets[B]=T, every Nr_b >= 1
- *   row_sample  int32 [T]             device; sample index of every packed RG row  } derived from rg_offsets by
- *   inv_nr      float [B]             device; 1 / Nr_b                             } camo_prepare_batch()
+ *   batch_desc  opaque device buffer of camo_batch_desc_bytes(B, T) bytes filled by camo_prepare_batch() from
+ *               rg_offsets: row -> sample map, 1/Nr_b, first 32-row tile of every sample.  It depends on the
+ *               shape tuple (Nr_0 .. Nr_B-1) only, so a caller builds it once per distinct tuple.
  *   kg          [B*Nk, kg_dim]
  *   max_nr      host value: max_b Nr_b (grid sizing only)
  *   outs        [B, 2*num_classes+2]  = mask logits | instance logits | edge logit | sigmoid(score)
@@ -105,16 +106,20 @@ size_t camo_workspace_bytes(const camo_dims_t* dims, int32_t B, int32_t T, int32
  *                                     KG query j on RG key t (host transposes per sample to [Nk, Nr])
  *   training    0: eval (no dropout); 1: train, dropout p = dims->dropout with the
  *               counter-based mask of (seed, site, element index)
+ *   flags       CAMO_FWD_* bits.  CAMO_FWD_INFERENCE: no camo_backward will follow this call (validation,
+ *               prediction): nothing is saved for it and the workspace contents are undefined afterwards.
  */
-int camo_prepare_batch(const int32_t* rg_offsets, int32_t B, int32_t max_nr,
-                       int32_t* row_sample, float* inv_nr, void* stream);
+#define CAMO_FWD_INFERENCE 1
+size_t camo_batch_desc_bytes(int32_t B, int32_t T);
+int camo_prepare_batch(const int32_t* rg_offsets, int32_t B, int32_t T, int32_t max_nr,
+                       void* batch_desc, size_t batch_desc_bytes, void* stream);
 
 int camo_forward(const camo_dims_t* dims, const float* const* params,
-                 const float* rg, const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr,
+                 const float* rg, const int32_t* rg_offsets, const void* batch_desc,
                  const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr,
                  void* workspace, size_t workspace_bytes,
                  float* outs, float* attn_rg2kg, float* attn_kg2rg,
-                 int32_t training, uint64_t seed, int32_t precision, void* stream);
+                 int32_t training, uint64_t seed, int32_t precision, int32_t flags, void* stream);
 
 /* ---- backward ------------------------------------------------------------
  * Stands behind loss.backward() through the model (train_multimodal.py:270):
@@ -126,7 +131,7 @@ int camo_forward(const camo_dims_t* dims, const float* const* params,
  * column is instead taken w.r.t. the score head's pre-sigmoid value (what camo_loss's
  * d_pre output holds), which saves the conversion pass. */
 int camo_backward(const camo_dims_t* dims, const float* const* params, float* const* grads,
-                  const float* rg, const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr,
+                  const float* rg, const int32_t* rg_offsets, const void* batch_desc,
                   const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr,
                   void* workspace, size_t workspace_bytes,
                   const float* outs, const float* d_outs, int32_t d_outs_pre_activation,
@@ -168,7 +173,7 @@ int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sum
  * camo_backward.  Stands behind the body of the per-minibatch loop of train_epoch_fixed
  * (train_multimodal.py:245-270) for one packed minibatch. */
 int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
-                               const int32_t* rg_offsets, const int32_t* row_sample, const float* inv_nr, const float* kg,
+                               const int32_t* rg_offsets, const void* batch_desc, const float* kg,
                                int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes,
                                const int64_t* y, const float* e, const float* s, float* outs, float* loss_terms, int32_t* pred,
                                int32_t training, uint64_t seed, int32_t precision, void* stream);
@@ -179,7 +184,7 @@ int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* para
  *   C[M,N] (+)= epi(A.B + bias) (+res), flags = GF_* bits of csrc/gemm.h
  *   (1 relu, 4 atomic accumulate, 64 A k-major, 128 B k-major).
  * camo_debug_ws_offset: byte offset of a named saved activation inside the
- *   workspace (names: R G Q KV2 KV Q2 P P2 O O2 U U2 Y Y2 H1 H2 comb fused), or -1. */
+ *   workspace (names: R G Q KV2 KV Q2 P P2 O O2 U U2 Y Y2 H1 H2 comb fused, and the fused schedule's: see below), or -1. */
 int camo_debug_gemm(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
                     const float* bias, const float* res, int32_t ldr, float* bias_grad,
                     int32_t M, int32_t N, int32_t K, int32_t flags, int32_t precision, void* stream);
@@ -190,7 +195,11 @@ int camo_debug_gemm16(const void* A16, int32_t lda, const void* B16, int32_t ldb
                       int32_t M, int32_t N, int32_t K, int32_t flags, void* stream);
 int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int32_t Nk, const char* name);
 /* camo_debug_set_option: lets a test run two schedules of the same call in one process.
- *   "sched16": -1 (default) choose from the configuration, 0 never take the bf16-resident schedule. */
+ *   "sched16": -1 (default) choose from the configuration, 0 never take the bf16-resident schedule;
+ *   "fused":   -1 (default) choose from the configuration, 0 never take the fused row-tile schedule;
+ *   "fused_save": 1 makes inference calls of the fused schedule also write the tensors a backward would read
+ *              (names for camo_debug_ws_offset: R16 G16 Q16 Q2_16 KV16 KV2_16 O16 O2_16 Y16 Y2_16 XH16 XH2_16 rstd1 rstd2
+ *              mask1 mask2 lse2 X16 Wqkv_rg W1s Ymean H1mean Y2mean H2mean). */
 int camo_debug_set_option(const char* name, int32_t value);
 
 /* Opt-in launch timing for bench.py's roofline leg: between camo_prof_begin and camo_prof_end every

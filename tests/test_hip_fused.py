@@ -1,0 +1,148 @@
+"""The fused row-tile schedule (csrc/fused_rows.hip) against the oracle, stage by stage.  Needs an MI355X.
+
+The kernels keep a 32-row tile on chip through a chain of layers, so a wrong fragment map anywhere shows up only in the
+logits unless the intermediates are looked at: the testing hook ``fused_save`` makes an inference call write every tensor
+a backward would read, and each is compared with the oracle's cache at bf16 tolerances."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+from oracle import fusion_oracle as FO
+from oracle import params as OP
+from test_fragment_maps import frag_order
+from test_hip_parity import make_model, outs6, t2n
+
+pytestmark = pytest.mark.gpu
+
+
+def _opt(name, value):
+    from camouflage_multimodal_amd import _lib
+    _lib.check(_lib.lib().camo_debug_set_option(name.encode(), value), "camo_debug_set_option")
+
+
+@pytest.fixture
+def fused_opts():
+    yield _opt
+    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1)
+
+
+def bf16_round(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return (u.astype(np.uint32) << 16).view(np.float32)
+
+
+def _ws_raw(eng, batch, ws, name, nbytes):
+    from camouflage_multimodal_amd import _lib
+    off = _lib.lib().camo_debug_ws_offset(C.byref(eng.dims), batch.B, batch.T, batch.Nk, name.encode())
+    assert off >= 0, name
+    return ws[off:off + nbytes].cpu().numpy().copy()
+
+
+def ws_bf16(eng, batch, ws, name, rows, cols):
+    raw = _ws_raw(eng, batch, ws, name, 2 * rows * cols).view(np.uint16).astype(np.uint32)
+    return (raw << 16).view(np.float32).reshape(rows, cols)
+
+
+def ws_f32(eng, batch, ws, name, n):
+    return _ws_raw(eng, batch, ws, name, 4 * n).view(np.float32)
+
+
+def close_rel(got, want, rel, what, mean_rel=None):
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(float(np.abs(want).max()), 1e-6)
+    err = np.abs(got - want)
+    assert err.max() <= rel * scale, f"{what}: max |err| {err.max():.3e} > {rel} * scale {scale:.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    if mean_rel is not None:
+        assert err.mean() <= mean_rel * scale, f"{what}: mean |err| {err.mean():.3e} (scale {scale:.3e})"
+
+
+NRS = [303, 64, 1, 530, 65, 127, 31, 32, 33]
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_fused_forward_stage_by_stage(training, kg_real, fused_opts):
+    cfg = OP.full_cfg()
+    prm = OP.make_params(cfg, 0)
+    m = make_model(cfg, 0, "bf16")
+    m.train(training)
+    eng = m._engine
+    B, T, Nk = len(NRS), sum(NRS), 13
+    rg = [OP.make_rg(n, 128, seed=70 + i) for i, n in enumerate(NRS)]
+    kg = np.stack([kg_real * (1.0 + 0.05 * i) for i in range(B)]).astype(np.float32)      # (different keys per sample)
+    batch = eng.make_batch(torch.from_numpy(np.concatenate(rg)).cuda(), NRS, torch.from_numpy(kg).cuda())
+    seed = 0xABCDEF0123
+    fused_opts("fused_save", 1)
+    ws = eng.workspace(batch, private=True)
+    ws.zero_()
+    outs, _ = eng.forward_raw(batch, ws, training, seed, inference=True)
+    torch.cuda.synchronize()
+    orc = FO.FusionOracle(cfg, prm)
+    ref, caches = orc.forward_list(rg, kg, training=training, seed=seed)
+    cat = lambda k: np.concatenate([c[k] for c in caches])
+    H = 256
+    sc = np.float32(1.0 / np.sqrt(32.0))
+    # weight shadow of the RG in-projections = fragment order of [Wq1; Wk2; Wv2], bf16-rounded, bit for bit
+    Wcat = np.concatenate([prm["fusion.cross_attn_rg2kg.in_proj_weight"][:H], prm["fusion.cross_attn_kg2rg.in_proj_weight"][H:]])
+    got_sh = ws_bf16(eng, batch, ws, "Wqkv_rg", 1, 768 * 256)[0]
+    assert np.array_equal(got_sh, frag_order(bf16_round(Wcat))), "weight shadow order"
+    assert np.array_equal(ws_bf16(eng, batch, ws, "W1s", 1, 512 * 256)[0], frag_order(bf16_round(prm["fusion.ffn_rg.0.weight"])))
+    # front half
+    assert np.array_equal(ws_bf16(eng, batch, ws, "X16", T, 128), bf16_round(np.concatenate(rg)))
+    close_rel(ws_bf16(eng, batch, ws, "R16", T, H), cat("R"), 8e-3, "R16")
+    close_rel(ws_bf16(eng, batch, ws, "G16", B * Nk, H), cat("G"), 8e-3, "G16")
+    close_rel(ws_bf16(eng, batch, ws, "Q16", T, H), cat("Q") * sc, 1.2e-2, "Q16 (pre-scaled)")
+    close_rel(ws_bf16(eng, batch, ws, "KV2_16", T, 2 * H), np.concatenate([cat("K2"), cat("V2")], axis=1), 1.2e-2, "KV2_16")
+    close_rel(ws_bf16(eng, batch, ws, "Q2_16", B * Nk, H), cat("Q2") * sc, 1.2e-2, "Q2_16 (pre-scaled)")
+    close_rel(ws_bf16(eng, batch, ws, "KV16", B * Nk, 2 * H), np.concatenate([cat("Kk"), cat("Vk")], axis=1), 1.2e-2, "KV16")
+    # back half
+    close_rel(ws_bf16(eng, batch, ws, "O16", T, H), cat("O"), 2e-2, "O16 (RG->KG attention output)", 2e-3)
+    close_rel(ws_bf16(eng, batch, ws, "O2_16", B * Nk, H), cat("O2"), 2e-2, "O2_16 (KG->RG attention output)", 3e-3)
+    lse = ws_f32(eng, batch, ws, "lse2", B * 8 * 16 * 2).reshape(B, 8, 16, 2)
+    for b, c in enumerate(caches):
+        S2 = np.einsum("jhd,thd->thj", c["Q2"].reshape(Nk, 8, 32), c["K2"].reshape(-1, 8, 32)) * sc       # [Nr, nh, Nk]
+        mx = S2.max(axis=0)
+        close_rel(lse[b, :, :Nk, 0], mx, 2e-2, "KG->RG softmax max")
+        assert np.allclose(lse[b, :, :Nk, 1], np.exp(S2 - mx).sum(axis=0), rtol=3e-2), "KG->RG softmax sum"
+    close_rel(ws_bf16(eng, batch, ws, "XH16", T, H), cat("xh1"), 2.5e-2, "normalised LN input (RG)", 2e-3)
+    close_rel(ws_f32(eng, batch, ws, "rstd1", T), cat("rstd1")[:, 0], 1e-2, "rstd (RG)")
+    close_rel(ws_bf16(eng, batch, ws, "Y16", T, H), cat("Y"), 2.5e-2, "Y16", 2e-3)
+    close_rel(ws_bf16(eng, batch, ws, "Y2_16", B * Nk, H), cat("Y2"), 2.5e-2, "Y2_16", 3e-3)
+    close_rel(ws_bf16(eng, batch, ws, "XH2_16", B * Nk, H), cat("xh2"), 2.5e-2, "normalised LN input (KG)", 3e-3)
+    close_rel(ws_f32(eng, batch, ws, "Ymean", B * H).reshape(B, H), np.stack([c["Y"].mean(0) for c in caches]), 5e-3, "Ymean")
+    close_rel(ws_f32(eng, batch, ws, "Y2mean", B * H).reshape(B, H), np.stack([c["Y2"].mean(0) for c in caches]), 8e-3, "Y2mean")
+    close_rel(ws_f32(eng, batch, ws, "H1mean", B * 2 * H).reshape(B, 2 * H), np.stack([c["H1d"].mean(0) for c in caches]), 1e-2, "H1mean")
+    close_rel(ws_f32(eng, batch, ws, "H2mean", B * 2 * H).reshape(B, 2 * H), np.stack([c["H2d"].mean(0) for c in caches]), 2e-2, "H2mean")
+    # ReLU/dropout bit masks: bit f of row t = (activation after ReLU and dropout > 0); units within bf16 noise of 0 may differ
+    for name, key, rows in (("mask1", "H1d", T), ("mask2", "H2d", B * Nk)):
+        words = _ws_raw(eng, batch, ws, name, 4 * rows * 16).view(np.uint32).reshape(rows, 16)
+        bits = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(rows, 512).astype(bool)
+        want = cat(key) > 0
+        near = np.abs(cat(key.replace("d", ""))) < 2e-2                      # pre-dropout activation close to the ReLU threshold
+        assert (bits == want)[~near].mean() > 0.9995 and (bits == want).mean() > 0.99, name
+    assert_close(t2n(outs), outs6(ref), 1.5e-3 if training else 1e-3, 0, "logits of the fused schedule")
+    # and against the bf16-resident schedule of round 1 on the same call
+    fused_opts("fused", 0)
+    outs16, _ = eng.forward_raw(batch, eng.workspace(batch, private=True), training, seed, inference=True)
+    assert_close(t2n(outs), t2n(outs16), 1.5e-3, 0, "fused vs bf16-resident schedule")
+
+
+@pytest.mark.parametrize("nrs,nk", [([1], 1), ([5, 700, 32], 16), ([64] * 40, 13), ([2048, 17], 13)])
+def test_fused_forward_shapes(nrs, nk, fused_opts):
+    """Envelope of the fused schedule: one-node samples, Nk = 1 and 16, tiles that end on a sample boundary, more samples than
+    KG blocks per wave, a 2048-node sample (64 key chunks per KG block)."""
+    cfg = OP.full_cfg()
+    m = make_model(cfg, 2, "bf16").eval()
+    orc = FO.FusionOracle(cfg, OP.make_params(cfg, 2))
+    rg = [OP.make_rg(n, 128, seed=7 + i) for i, n in enumerate(nrs)]
+    kg = np.stack([OP.make_kg(nk, 128, seed=90 + i) for i in range(len(nrs))])
+    ref, _ = orc.forward_list(rg, kg)
+    with torch.no_grad():
+        o = m.forward_packed(torch.from_numpy(np.concatenate(rg)).cuda(), list(nrs), torch.from_numpy(kg).cuda())
+    got = np.concatenate([t2n(v) for v in o], axis=1)
+    assert np.isfinite(got).all()
+    assert_close(got, outs6(ref), 1e-3, 0, f"nrs={nrs[:4]} nk={nk}")
