@@ -48,8 +48,9 @@ def test_argument_validation_without_a_gpu():
     assert L.camo_workspace_bytes(ctypes.byref(d), 4, 100, 100) == 0 and b"attention kernels" in L.camo_last_error()
     late = _lib.CamoDims(128, 128, 256, 8, 2, _lib.FUSION_LATE, 0.3)
     assert 0 < L.camo_workspace_bytes(ctypes.byref(late), 16, 7700, 13) < 1e6
-    assert L.camo_forward(ctypes.byref(d), None, None, None, None, None, None, 4, 100, 13, 50, None, 0, None, None, None,
-                          0, 0, 0, None) == -1
+    assert L.camo_forward(ctypes.byref(d), None, None, None, None, None, 4, 100, 13, 50, None, 0, None, None, None,
+                          0, 0, 0, 0, None) == -1
+    assert L.camo_batch_desc_bytes(16, 7700) >= 4 * (7700 + 16 + 17) and L.camo_batch_desc_bytes(0, 5) == 0
     assert L.camo_loss(None, None, None, None, 4, 2, None, None, None, None, None) == -1
 
 
