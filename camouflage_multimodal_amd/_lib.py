@@ -22,7 +22,7 @@ NPARAMS_CROSS, NPARAMS_LATE = 44, 22
 # every symbol include/camo_fusion.h declares
 SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_batch_desc_bytes", "camo_prepare_batch", "camo_forward", "camo_backward", "camo_forward_loss_backward",
            "camo_loss", "camo_grad_sumsq", "camo_clip_adamw", "camo_debug_gemm", "camo_debug_gemm16", "camo_debug_ws_offset",
-           "camo_debug_set_option", "camo_prof_begin", "camo_prof_end")
+           "camo_debug_set_option", "camo_debug_set_stamps", "camo_prof_begin", "camo_prof_end")
 
 
 # every symbol include/camo_rg_gnn.h declares
@@ -93,6 +93,8 @@ def lib():
     L.camo_debug_ws_offset.argtypes = [C.POINTER(CamoDims), i32, i32, i32, C.c_char_p]
     L.camo_debug_set_option.restype = C.c_int
     L.camo_debug_set_option.argtypes = [C.c_char_p, i32]
+    L.camo_debug_set_stamps.restype = C.c_int
+    L.camo_debug_set_stamps.argtypes = [vp, i32]
     L.camo_prof_begin.restype = C.c_int
     L.camo_prof_begin.argtypes = [i32]
     L.camo_prof_end.restype = C.c_int

@@ -30,8 +30,8 @@ struct FrontStream {
   us16* R16; us16* Q16; us16* KV16;            // [M][256] projection, [M][256] queries (pre-scaled by 1/sqrt(32)), [M][512] keys|values
   int tile_begin;
 };
-struct FrontArgs { FrontStream s[2]; float qscale; int save; };
-int launch_fused_front(FrontArgs& a, hipStream_t stream);
+struct FrontArgs { FrontStream s[2]; float qscale; int save; unsigned long long* stamps; };
+int launch_fused_front(FrontArgs& a, int variant, hipStream_t stream);   // variant: 0 <depth 12>, 1 <depth 12, rotated k order> (default), 2 <depth 16, rotated>
 
 // ---- forward, back half
 struct BackStream {
@@ -48,10 +48,16 @@ struct BackArgs {
   const us16* Q2_16; const us16* KV2_16;       // KG queries [B*Nk][256]; RG keys|values [T][512]
   const int* off; const int* tile_off; const float* inv_nr;
   float* lse2;                                 // [B][8][16][2]: max and sum of the KG->RG softmax (saved for backward)
+  float* part; int* tickets; int max_splits;   // KG->RG attention runs as ceil(Nr / 64) split blocks per sample (max_splits = the
+                                               // largest count: grid sizing): partials [rg_tiles_max][8][FUSED_PART_FLOATS] indexed by
+                                               // the split's first 32-row tile, and one ZEROED arrival counter per sample
   int B, Nk, rg_tiles_max;
   DropCfg drop; int save;
+  unsigned long long* stamps;                  // developer timeline (null in product calls)
 };
-int launch_fused_back(BackArgs& a, hipStream_t stream);
+int launch_fused_back(BackArgs& a, int variant, hipStream_t stream);
 
+#define FUSED_PART_FLOATS 544
+#define FUSED_MAX_SPLITS 64
 size_t fused_front_lds();
 size_t fused_back_lds();

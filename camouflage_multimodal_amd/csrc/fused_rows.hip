@@ -43,24 +43,48 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // ---- one linear layer of a tile: acc[t] (+)= sum over KS k steps.  `wp` = the wave's fragment stream + lane (16-byte
 // units: fragment i of the stream is wp[64 i]); `act` = LDS address of this lane's first activation fragment (row
 // lane & 31, byte offset 16 (lane >> 5)); k step ks is 32 bytes further.  DEPTH weight fragments are kept in flight.
-constexpr int DEPTH = 12;
-template <int NT, int KS, bool W_IS_A>
-__device__ __forceinline__ void stage_mma(const u32x4* __restrict__ wp, const char* act, f32x16 (&acc)[NT]) {
-  constexpr int TOTAL = NT * KS;
-  constexpr int D = DEPTH < TOTAL ? DEPTH : TOTAL;
+// `rot` (block-uniform) rotates the order of the k steps (tiles of a launch all walk the SAME weight stream).
+// prefetch() issues the first DEPTH weight loads and may be called well before run() -- ahead of the epilogue or the
+// attention that produces the stage's input -- so that the stream is already flowing when the MFMAs start.
+template <int NT, int KS, bool W_IS_A, int DEPTH>
+struct Stage {
+  static constexpr int TOTAL = NT * KS;
+  static constexpr int D = DEPTH < TOTAL ? DEPTH : TOTAL;
+  static_assert((KS & (KS - 1)) == 0, "k steps: power of two");
   u32x4 buf[D];
+  const u32x4* wp; int rot;
+  __device__ __forceinline__ const u32x4* wptr(int i) const { return wp + 64 * ((((i / NT) + rot) & (KS - 1)) * NT + (i % NT)); }
+  __device__ __forceinline__ void prefetch(const u32x4* __restrict__ wp_, int rot_) {
+    wp = wp_; rot = rot_;
 #pragma unroll
-  for (int i = 0; i < D; ++i) buf[i] = wp[64 * i];
-  bf16x8 x;
-#pragma unroll
-  for (int i = 0; i < TOTAL; ++i) {
-    const int ks = i / NT, t = i % NT;
-    if (t == 0) x = *reinterpret_cast<const bf16x8*>(act + 32 * ks);
-    const bf16x8 wf = as_frag(buf[i % D]);
-    if (i + D < TOTAL) buf[i % D] = wp[64 * (i + D)];
-    if constexpr (W_IS_A) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, x, acc[t], 0, 0, 0);
-    else                  acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, wf, acc[t], 0, 0, 0);
+    for (int i = 0; i < D; ++i) buf[i] = *wptr(i);
   }
+  __device__ __forceinline__ void run(const char* act, f32x16 (&acc)[NT]) {
+    auto aptr = [&](int ks) { return act + 32 * ((ks + rot) & (KS - 1)); };
+    bf16x8 x = *reinterpret_cast<const bf16x8*>(aptr(0)), xn = x;
+    // One step = {issue the weight load DEPTH fragments ahead, (first tile of a k step: start the NEXT k step's activation
+    // read), MFMA}.  The scheduling barrier pins that order: left alone, hipcc sinks every load next to its use and the
+    // stream runs at one L2 round trip per fragment (measured: s_waitcnt vmcnt(1) in front of almost every MFMA).
+#pragma unroll
+    for (int i = 0; i < TOTAL; ++i) {
+      const int ks = i / NT, t = i % NT;
+      const bf16x8 wf = as_frag(buf[i % D]);
+      if (i + D < TOTAL) buf[i % D] = *wptr(i + D);
+      if (t == 0) {
+        x = xn;
+        if (ks + 1 < KS) xn = *reinterpret_cast<const bf16x8*>(aptr(ks + 1));
+      }
+      if constexpr (W_IS_A) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, x, acc[t], 0, 0, 0);
+      else                  acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, wf, acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
+
+// Developer timeline (testing hook "stamps"): when a buffer is given, wave 0 of every block records the 100 MHz wall clock
+// at its phase boundaries: stamps[block * 8 + k].  Product calls pass null and execute none of it.
+__device__ __forceinline__ void stamp(unsigned long long* stamps, int k) {
+  if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime();
 }
 
 // rows [0, nrows) of a bf16 LDS tile -> global, 16 bytes per thread, whole rows contiguous (LOG2C: log2 of 16-byte chunks per row)
@@ -119,6 +143,7 @@ constexpr int PR = 528;     // ... of a [32][256] bf16 tile: a ds_read_b128 lane
 constexpr int PQ = 1552;    // ... of the [32][768] bf16 [q | k' | v'] tile
 constexpr int F_BUFR = 32 * PX, F_BUFQ = F_BUFR + 32 * PR, F_LDS = F_BUFQ + 32 * PQ;      // 8704, 25600, 75264
 
+template <int DEPTH, bool ROT>
 __global__ __launch_bounds__(256, 2) void front_kernel(const FrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const FrontStream& S = a.s[(int)blockIdx.x >= a.s[1].tile_begin ? 1 : 0];
@@ -127,6 +152,10 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const FrontArgs a) {
   const int row0 = ((int)blockIdx.x - S.tile_begin) * 32;
   const int nrows = min(32, S.M - row0);
   char* bufX = smem; char* bufR = smem + F_BUFR; char* bufQ = smem + F_BUFQ;
+  const int rot = ROT ? (int)(blockIdx.x >> 3) : 0;         // (blocks b, b + 8, ... share an XCD's L2)
+  stamp(a.stamps, 0);
+  Stage<2, 8, true, DEPTH> st0;
+  st0.prefetch(reinterpret_cast<const u32x4*>(S.W0) + (size_t)w * (8 * 2 * 64) + lane, rot);
   {   // input tile: fp32 -> bf16, rows past the end cleared
     const int r = tid >> 3, c = tid & 7;
     const float4* src = reinterpret_cast<const float4*>(S.X + (size_t)(row0 + min(r, nrows - 1)) * 128 + 16 * c);
@@ -138,9 +167,11 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const FrontArgs a) {
   __syncthreads();
   if (a.save) copy_out<4>(bufX, PX, 0, S.X16, 128, row0, nrows);
   // projection 128 -> 256
+  Stage<6, 16, true, DEPTH> st1;
   {
     f32x16 acc[2] = {zero16(), zero16()};
-    stage_mma<2, 8, true>(reinterpret_cast<const u32x4*>(S.W0) + (size_t)w * (8 * 2 * 64) + lane, bufX + l31 * PX + 16 * h, acc);
+    st0.run(bufX + l31 * PX + 16 * h, acc);
+    st1.prefetch(reinterpret_cast<const u32x4*>(S.W1) + (size_t)w * (16 * 6 * 64) + lane, rot);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -152,13 +183,14 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const FrontArgs a) {
       }
   }
   __syncthreads();
+  stamp(a.stamps, 1);
   copy_out<5>(bufR, PR, 0, S.R16, 256, row0, nrows);
   // in-projections 256 -> [256 q | 512 k', v'] (24 feature tiles, 6 per wave)
   {
     f32x16 acc[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) acc[t] = zero16();
-    stage_mma<6, 16, true>(reinterpret_cast<const u32x4*>(S.W1) + (size_t)w * (16 * 6 * 64) + lane, bufR + l31 * PR + 16 * h, acc);
+    st1.run(bufR + l31 * PR + 16 * h, acc);
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
       const int tg = 6 * w + t;                                  // wave-uniform
@@ -175,8 +207,10 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const FrontArgs a) {
     }
   }
   __syncthreads();
+  stamp(a.stamps, 2);
   copy_out<5>(bufQ, PQ, 0, S.Q16, 256, row0, nrows);
   copy_out<6>(bufQ, PQ, 512, S.KV16, 512, row0, nrows);
+  stamp(a.stamps, 3);
 }
 
 // ------------------------------------------------------------------------------------------------ forward, back half
@@ -250,153 +284,228 @@ __device__ __forceinline__ void attn_rg_tile(const BackArgs& a, char* smem, int 
   }
 }
 
-// KG block: the Nk query rows of sample b against its nr RG keys (rows rb ..).  Two passes over the keys in 32-row chunks
-// (row max, then exp / sum / P.V), the key ROWS in the accumulator registers (lane = query), so nothing crosses lanes but
-// the final exchange between the lane halves.  Wave w owns heads 2w, 2w+1 and stages its value chunks privately.
-__device__ __forceinline__ void attn_kg_block(const BackArgs& a, char* smem, int b, int w, int lane) {
+// KG->RG attention, one SPLIT: the Nk query rows of sample b against 64 of its RG keys (rows rb + 64 sp ..).  The key ROWS
+// sit in the accumulator registers (lane = query j), so the row maximum and the sums are in-lane plus one exchange between
+// the lane halves; wave w owns heads 2w, 2w+1; every load of the split is issued up front.  Writes the flash-style partial
+// {m[16], l[16], Z[16][32]} per head (relative to the split's own maximum); the last split of a sample to finish combines.
+constexpr int SPLIT_ROWS = 64;
+constexpr int PART_FLOATS = 16 + 16 + 16 * 32;      // per (sample, split, head)
+static_assert(PART_FLOATS == FUSED_PART_FLOATS, "fused_rows.h");
+__device__ __forceinline__ void attn_kg_split(const BackArgs& a, char* smem, int b, int sp, int w, int lane) {
   const int l31 = lane & 31, h = lane >> 5, Nk = a.Nk;
-  const int rb = a.off[b], nr = a.off[b + 1] - rb, nch = (nr + 31) >> 5;
+  const int rb = a.off[b], nr = a.off[b + 1] - rb, r0 = SPLIT_ROWS * sp;
   char* Vt = smem + w * (32 * PVC);
-  char* bufO = smem + B_BUFO;
   const us16* qrow = a.Q2_16 + ((size_t)b * Nk + min(l31, Nk - 1)) * 256 + 64 * w + 8 * h;
+  const us16* kbase = a.KV2_16 + (size_t)rb * 512 + 64 * w + 8 * h;
+  const us16* vbase = a.KV2_16 + (size_t)rb * 512 + 256 + 64 * w;
   bf16x8 qf[2][2];
+  u32x4 kf[2][2][2], vv[2][4];
 #pragma unroll
   for (int hd = 0; hd < 2; ++hd)
 #pragma unroll
     for (int s = 0; s < 2; ++s) qf[hd][s] = as_frag(*reinterpret_cast<const u32x4*>(qrow + 32 * hd + 16 * s));
-  const us16* kbase = a.KV2_16 + (size_t)rb * 512 + 64 * w + 8 * h;
-  auto load_k = [&](u32x4 (&k)[2][2], int c) {
-    const us16* p = kbase + (size_t)min(32 * c + l31, nr - 1) * 512;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const us16* p = kbase + (size_t)min(r0 + 32 * c + l31, nr - 1) * 512;
 #pragma unroll
     for (int hd = 0; hd < 2; ++hd)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) k[hd][s] = *reinterpret_cast<const u32x4*>(p + 32 * hd + 16 * s);
-  };
-  auto scores = [&](const u32x4 (&k)[2][2], int hd) {
-    f32x16 S = zero16();
-#pragma unroll
-    for (int s = 0; s < 2; ++s) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(k[hd][s]), qf[hd][s], S, 0, 0, 0);
-    return S;                                            // S[row acc_row(i, h) of the chunk][query l31]
-  };
-  // pass 1: per query the maximum over all keys
-  float mx[2] = {-INFINITY, -INFINITY};
-  {
-    u32x4 kc[2][2], kn[2][2];
-    load_k(kc, 0);
-    for (int c = 0; c < nch; ++c) {
-      load_k(kn, min(c + 1, nch - 1));
-#pragma unroll
-      for (int hd = 0; hd < 2; ++hd) {
-        const f32x16 S = scores(kc, hd);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mx[hd] = (32 * c + acc_row(i, h) < nr) ? fmaxf(mx[hd], S[i]) : mx[hd];
-      }
-#pragma unroll
-      for (int hd = 0; hd < 2; ++hd)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) kc[hd][s] = kn[hd][s];
-    }
-    mx[0] = fmaxf(mx[0], __shfl_xor(mx[0], 32, 64));
-    mx[1] = fmaxf(mx[1], __shfl_xor(mx[1], 32, 64));
+      for (int s = 0; s < 2; ++s) kf[c][hd][s] = *reinterpret_cast<const u32x4*>(p + 32 * hd + 16 * s);
   }
-  // pass 2
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {      // value chunk: 32 rows x 128 bytes (this wave's two heads): slot id = lane + 64 i -> row id >> 3, 16-byte chunk id & 7
+      const int id = lane + 64 * i;
+      vv[c][i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)min(r0 + 32 * c + (id >> 3), nr - 1) * 512 + 8 * (id & 7));
+    }
+  // scores S[c][hd][row acc_row(i, h) of chunk c][query l31] (queries are pre-scaled), maximum over the split's valid keys
+  f32x16 S[2][2];
+  float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int hd = 0; hd < 2; ++hd) {
+      S[c][hd] = zero16();
+#pragma unroll
+      for (int s = 0; s < 2; ++s) S[c][hd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf[c][hd][s]), qf[hd][s], S[c][hd], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx[hd] = (r0 + 32 * c + acc_row(i, h) < nr) ? fmaxf(mx[hd], S[c][hd][i]) : mx[hd];
+    }
+  mx[0] = fmaxf(mx[0], __shfl_xor(mx[0], 32, 64));
+  mx[1] = fmaxf(mx[1], __shfl_xor(mx[1], 32, 64));
   f32x16 Z[2] = {zero16(), zero16()};
   float L[2] = {0.f, 0.f};
-  {
-    const bool dodrop = a.drop.p > 0.f;
-    const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
-    // value chunk: 32 rows x 128 bytes (this wave's two heads): lane-slot i covers row (lane + 64 i) >> 3, 16-byte chunk (lane + 64 i) & 7
-    const us16* vbase = a.KV2_16 + (size_t)rb * 512 + 256 + 64 * w;
-    auto load_v = [&](u32x4 (&v)[4], int c) {
+  const bool dodrop = a.drop.p > 0.f;
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int id = lane + 64 * i;
-        v[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)min(32 * c + (id >> 3), nr - 1) * 512 + 8 * (id & 7));
-      }
-    };
-    u32x4 kc[2][2], kn[2][2], vc[4], vn[4];
-    load_k(kc, 0); load_v(vc, 0);
-    for (int c = 0; c < nch; ++c) {
+  for (int c = 0; c < 2; ++c) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int id = lane + 64 * i; *reinterpret_cast<u32x4*>(Vt + (id >> 3) * PVC + 16 * (id & 7)) = vc[i]; }
-      const int cn = min(c + 1, nch - 1);
-      load_k(kn, cn); load_v(vn, cn);
+    for (int i = 0; i < 4; ++i) { const int id = lane + 64 * i; *reinterpret_cast<u32x4*>(Vt + (id >> 3) * PVC + 16 * (id & 7)) = vv[c][i]; }
 #pragma unroll
-      for (int hd = 0; hd < 2; ++hd) {
-        const f32x16 S = scores(kc, hd);
-        float e[16];
+    for (int hd = 0; hd < 2; ++hd) {
+      float e[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = 32 * c + acc_row(i, h);
-          e[i] = row < nr ? __expf(S[i] - mx[hd]) : 0.f;
-          L[hd] += e[i];
-          if (dodrop) e[i] *= drop_mult(a.drop, SITE_ATTN_KG2RG, ((uint32_t)(rb + row) * 8u + (uint32_t)(2 * w + hd)) * (uint32_t)Nk + (uint32_t)l31);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const bf16x8 ef = as_frag(u32x4{pack2(e[8 * s], e[8 * s + 1]), pack2(e[8 * s + 2], e[8 * s + 3]),
-                                          pack2(e[8 * s + 4], e[8 * s + 5]), pack2(e[8 * s + 6], e[8 * s + 7])});
-          const char* vp = Vt + (16 * s + 4 * h + q4) * PVC + 2 * (32 * hd + 16 * g1 + 4 * p4);
-          const bf16x8 vf = join(lds_tr16(vp), lds_tr16(vp + 8 * PVC));
-          Z[hd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ef, vf, Z[hd], 0, 0, 0);      // Z[query][feature] += E^T . V
-        }
+      for (int i = 0; i < 16; ++i) {
+        const int row = r0 + 32 * c + acc_row(i, h);
+        e[i] = row < nr ? __expf(S[c][hd][i] - mx[hd]) : 0.f;
+        L[hd] += e[i];
+        if (dodrop) e[i] *= drop_mult(a.drop, SITE_ATTN_KG2RG, ((uint32_t)(rb + row) * 8u + (uint32_t)(2 * w + hd)) * (uint32_t)Nk + (uint32_t)l31);
       }
 #pragma unroll
-      for (int hd = 0; hd < 2; ++hd)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) kc[hd][s] = kn[hd][s];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) vc[i] = vn[i];
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 ef = as_frag(u32x4{pack2(e[8 * s], e[8 * s + 1]), pack2(e[8 * s + 2], e[8 * s + 3]),
+                                        pack2(e[8 * s + 4], e[8 * s + 5]), pack2(e[8 * s + 6], e[8 * s + 7])});
+        const char* vp = Vt + (16 * s + 4 * h + q4) * PVC + 2 * (32 * hd + 16 * g1 + 4 * p4);
+        const bf16x8 vf = join(lds_tr16(vp), lds_tr16(vp + 8 * PVC));
+        Z[hd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ef, vf, Z[hd], 0, 0, 0);      // Z[query][feature] += E^T . V
+      }
     }
-    L[0] += __shfl_xor(L[0], 32, 64);
-    L[1] += __shfl_xor(L[1], 32, 64);
   }
-  // O2[j][feature] = Z / L[j]: Z has the query on its registers (0..7 -> j = acc_row(i, h) < 16), L lives on lane j
+  L[0] += __shfl_xor(L[0], 32, 64);
+  L[1] += __shfl_xor(L[1], 32, 64);
+  // partial of this split: Z has the query on its registers (0..7 -> j = acc_row(i, h) < 16) and the feature on the lane
 #pragma unroll
   for (int hd = 0; hd < 2; ++hd) {
+    float* part = a.part + (((size_t)a.tile_off[b] + 2 * sp) * 8 + 2 * w + hd) * PART_FLOATS;       // (a split = two 32-row tiles)
+    if (lane < 16) { part[lane] = mx[hd]; part[16 + lane] = L[hd]; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int j = acc_row(i, h);
-      const float Lj = __shfl(L[hd], j, 64);
-      if (j < Nk) *reinterpret_cast<us16*>(bufO + j * PR + 2 * (64 * w + 32 * hd + l31)) = f2bf(Z[hd][i] / Lj);
-    }
-    if (a.save && a.lse2 && lane < Nk) {
-      float* o = a.lse2 + (((size_t)b * 8 + 2 * w + hd) * 16 + lane) * 2;
-      o[0] = mx[hd]; o[1] = L[hd];
-    }
+    for (int i = 0; i < 8; ++i) part[32 + acc_row(i, h) * 32 + l31] = Z[hd][i];
   }
 }
 
+// The last split of sample b: combine the partials into the attention output (bf16, rows j < Nk of bufO).  The partials
+// were written by other CUs a moment ago, so every read is a long-latency miss: all loops run in batches of independent,
+// unconditional loads (split index clamped, contribution masked) instead of one round trip per split.
+__device__ __forceinline__ void attn_kg_combine(const BackArgs& a, char* smem, int b, int nsplit) {
+  const int tid = threadIdx.x, Nk = a.Nk;
+  float* sc = reinterpret_cast<float*>(smem);              // [nsplit][128] scale factors exp(m_s - M), then [128] 1 / L
+  float* invL = sc + nsplit * 128;
+  char* bufO = smem + B_BUFO;
+  const float* part = a.part + (size_t)a.tile_off[b] * 8 * PART_FLOATS;       // split s at + 2 s tiles
+  constexpr size_t SS = (size_t)2 * 8 * PART_FLOATS;                          // floats between consecutive splits
+  // the first batch of Z loads does not depend on the scale factors: it is issued together with the m / l loads, so the
+  // whole combine is (1 + number of further 4-split batches) memory round trips
+  const int hd2 = tid >> 5, f = tid & 31;
+  const float* z0 = part + (size_t)hd2 * PART_FLOATS + 32 + f;
+  float zv[4][16];
+  auto load_z = [&](int s0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float* z = z0 + (size_t)min(s0 + k, nsplit - 1) * SS;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) zv[k][j] = z[j * 32];
+    }
+  };
+  load_z(0);
+  if (tid < 128) {
+    const int hd = tid >> 4, j = tid & 15;
+    const float* p0 = part + (size_t)hd * PART_FLOATS + j;
+    float M = -INFINITY, L = 0.f;
+    if (nsplit <= 16) {                                      // (block-uniform) the usual case: every m / l value in one batch
+      float mv[16], lv[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const size_t o = (size_t)min(k, nsplit - 1) * SS; mv[k] = p0[o]; lv[k] = p0[o + 16]; }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) M = fmaxf(M, mv[k]);
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k < nsplit) { const float e = __expf(mv[k] - M); sc[k * 128 + tid] = e; L = fmaf(lv[k], e, L); }
+    } else {
+      for (int s0 = 0; s0 < nsplit; s0 += 8) {
+        float mv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mv[k] = p0[(size_t)min(s0 + k, nsplit - 1) * SS];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) M = fmaxf(M, mv[k]);
+      }
+      for (int s0 = 0; s0 < nsplit; s0 += 8) {
+        float mv[8], lv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const size_t o = (size_t)min(s0 + k, nsplit - 1) * SS; mv[k] = p0[o]; lv[k] = p0[o + 16]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (s0 + k < nsplit) { const float e = __expf(mv[k] - M); sc[(s0 + k) * 128 + tid] = e; L = fmaf(lv[k], e, L); }
+      }
+    }
+    invL[tid] = 1.0f / L;
+    if (a.save && a.lse2 && j < Nk) { float* o = a.lse2 + (((size_t)b * 8 + hd) * 16 + j) * 2; o[0] = M; o[1] = L; }
+  }
+  __syncthreads();
+  const int hd = hd2;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int s0 = 0; s0 < nsplit; s0 += 4) {
+    if (s0 > 0) load_z(s0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (s0 + k < nsplit) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = fmaf(zv[k][j], sc[(s0 + k) * 128 + hd * 16 + j], acc[j]);
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < Nk) *reinterpret_cast<us16*>(bufO + j * PR + 2 * (32 * hd + f)) = f2bf(acc[j] * invL[hd * 16 + j]);
+}
+
+template <int DEPTH, bool ROT>
 __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool kg = (int)blockIdx.x < a.B;                                   // the B long-running KG blocks are dispatched first
+  const int nkg = a.B * a.max_splits;
+  const bool kg = (int)blockIdx.x < nkg;                                   // the KG attention splits are dispatched first
+  const int rot = ROT ? (int)(blockIdx.x >> 3) : 0;
+  char* bufO = smem + B_BUFO; char* bufY = smem + B_BUFY;
+  float* red = reinterpret_cast<float*>(smem + B_RED);
+  float* tile32 = reinterpret_cast<float*>(smem);
   int b; size_t rowg0; int nrows; float inv_n;
+  stamp(a.stamps, 0);
+  const BackStream& S = a.s[kg ? 1 : 0];
+  Stage<2, 16, true, DEPTH> sto;
+  Stage<4, 16, false, DEPTH> stf;
+  if (!kg) sto.prefetch(reinterpret_cast<const u32x4*>(S.Wo) + (size_t)w * (16 * 2 * 64) + lane, rot);   // (flows during the attention)
   if (kg) {
-    b = blockIdx.x; rowg0 = (size_t)b * a.Nk; nrows = a.Nk; inv_n = 1.0f / (float)a.Nk;
+    b = (int)blockIdx.x / a.max_splits;
+    const int sp = (int)blockIdx.x - b * a.max_splits;
+    const int nsplit = (a.off[b + 1] - a.off[b] + SPLIT_ROWS - 1) / SPLIT_ROWS;
+    if (sp >= nsplit) return;
+    attn_kg_split(a, smem, b, sp, w, lane);
+    // hand the partial over (cdna_hip_programming.md, in-launch split-K reduction): every storing wave drains its stores, the
+    // block meets, one lane releases at agent scope and draws a ticket; the block that draws the last one acquires and combines.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(red);
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      flag[0] = __hip_atomic_fetch_add(a.tickets + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (flag[0] != nsplit - 1) return;                                     // (block-uniform)
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    for (int c = tid; c < 32 * PR / 16; c += 256) reinterpret_cast<u32x4*>(bufO)[c] = u32x4{0u, 0u, 0u, 0u};   // rows >= Nk stay zero
+    __syncthreads();
+    sto.prefetch(reinterpret_cast<const u32x4*>(S.Wo) + (size_t)w * (16 * 2 * 64) + lane, rot);
+    attn_kg_combine(a, smem, b, nsplit);
+    rowg0 = (size_t)b * a.Nk; nrows = a.Nk; inv_n = 1.0f / (float)a.Nk;
   } else {
-    const int tile = (int)blockIdx.x - a.B;
+    const int tile = (int)blockIdx.x - nkg;
     if (tile >= a.tile_off[a.B]) return;
     int lo = 0, hi = a.B - 1;                                              // sample of this tile: tile_off[b] <= tile < tile_off[b+1]
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_off[mid] <= tile) lo = mid; else hi = mid - 1; }
     b = lo;
     const int r0 = a.off[b] + 32 * (tile - a.tile_off[b]);
     rowg0 = r0; nrows = min(32, a.off[b + 1] - r0); inv_n = a.inv_nr[b];
-  }
-  const BackStream& S = a.s[kg ? 1 : 0];
-  char* bufO = smem + B_BUFO; char* bufY = smem + B_BUFY;
-  float* red = reinterpret_cast<float*>(smem + B_RED);
-  float* tile32 = reinterpret_cast<float*>(smem);
-
-  if (kg) {
-    for (int c = tid; c < 32 * PR / 16; c += 256) reinterpret_cast<u32x4*>(bufO)[c] = u32x4{0u, 0u, 0u, 0u};   // rows >= Nk stay zero
-    __syncthreads();
-    attn_kg_block(a, smem, b, w, lane);
-  } else {
     attn_rg_tile(a, smem, b, rowg0, nrows, w, lane);
   }
   __syncthreads();
+  stamp(a.stamps, 1);
   if (a.save) copy_out<5>(bufO, PR, 0, S.O16, 256, rowg0, nrows);
 
   // ---- out-projection + residual, LayerNorm (lane = row; wave w: features 64 w .. 64 w + 63)
@@ -404,7 +513,8 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
   float u[32];
   {
     f32x16 acc[2] = {zero16(), zero16()};
-    stage_mma<2, 16, true>(reinterpret_cast<const u32x4*>(S.Wo) + (size_t)w * (16 * 2 * 64) + lane, bufO + l31 * PR + 16 * h, acc);
+    sto.run(bufO + l31 * PR + 16 * h, acc);
+    stf.prefetch(reinterpret_cast<const u32x4*>(S.W1) + (size_t)w * (16 * 4 * 64) + lane, rot);           // (flows during the LayerNorm)
     float part = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -448,6 +558,7 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
       }
   }
   __syncthreads();
+  stamp(a.stamps, 2);
   {   // mean pool of the LayerNorm output: thread t owns feature t
     float sum = 0.f;
     for (int r = 0; r < nrows; ++r) sum += tile32[r * PT + tid];
@@ -458,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
   // ---- FFN layer 0 + ReLU + dropout, pooled over the rows (lane = feature; wave w: features 128 w .. 128 w + 127)
   {
     f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
-    stage_mma<4, 16, false>(reinterpret_cast<const u32x4*>(S.W1) + (size_t)w * (16 * 4 * 64) + lane, bufY + l31 * PR + 16 * h, acc);
+    stf.run(bufY + l31 * PR + 16 * h, acc);
     const bool dodrop = a.drop.p > 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -487,6 +598,7 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
       }
     }
   }
+  stamp(a.stamps, 3);
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -516,7 +628,7 @@ int launch_weight_shadows(ShadowBatch& sb, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-int launch_fused_front(FrontArgs& a, hipStream_t stream) {
+int launch_fused_front(FrontArgs& a, int variant, hipStream_t stream) {
   int total = 0;
   for (int i = 0; i < 2; ++i) {
     FrontStream& S = a.s[i];
@@ -528,16 +640,21 @@ int launch_fused_front(FrontArgs& a, hipStream_t stream) {
     total += (S.M + 31) / 32;
   }
   static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel<12, false>), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel<12, true>), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
     return true;
   }();
   (void)attr;
-  hipLaunchKernelGGL(front_kernel, dim3(total), dim3(256), F_LDS, stream, a);
+  if (variant == 0)      hipLaunchKernelGGL((front_kernel<12, false>), dim3(total), dim3(256), F_LDS, stream, a);
+  else if (variant == 2) hipLaunchKernelGGL((front_kernel<16, true>), dim3(total), dim3(256), F_LDS, stream, a);
+  else                   hipLaunchKernelGGL((front_kernel<12, true>), dim3(total), dim3(256), F_LDS, stream, a);
   return (int)hipGetLastError();
 }
 
-int launch_fused_back(BackArgs& a, hipStream_t stream) {
-  if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q16 || !a.KV16 || !a.Q2_16 || !a.KV2_16 || !a.off || !a.tile_off || !a.inv_nr)
+int launch_fused_back(BackArgs& a, int variant, hipStream_t stream) {
+  if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q16 || !a.KV16 || !a.Q2_16 || !a.KV2_16 || !a.off || !a.tile_off || !a.inv_nr ||
+      !a.part || !a.tickets || a.max_splits < 1 || a.max_splits > FUSED_MAX_SPLITS)
     return (int)hipErrorInvalidValue;
   for (int i = 0; i < 2; ++i) {
     const BackStream& S = a.s[i];
@@ -546,10 +663,15 @@ int launch_fused_back(BackArgs& a, hipStream_t stream) {
     if (!al16(S.bo) || !al16(S.ln_g) || !al16(S.ln_b) || !al16(S.Wo) || !al16(S.W1) || !al16(S.R16)) return (int)hipErrorInvalidValue;
   }
   static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&back_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&back_kernel<12, false>), hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&back_kernel<12, true>), hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&back_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS);
     return true;
   }();
   (void)attr;
-  hipLaunchKernelGGL(back_kernel, dim3(a.B + a.rg_tiles_max), dim3(256), B_LDS, stream, a);
+  const dim3 grid(a.B * a.max_splits + a.rg_tiles_max);
+  if (variant == 0)      hipLaunchKernelGGL((back_kernel<12, false>), grid, dim3(256), B_LDS, stream, a);
+  else if (variant == 2) hipLaunchKernelGGL((back_kernel<16, true>), grid, dim3(256), B_LDS, stream, a);
+  else                   hipLaunchKernelGGL((back_kernel<12, true>), grid, dim3(256), B_LDS, stream, a);
   return (int)hipGetLastError();
 }

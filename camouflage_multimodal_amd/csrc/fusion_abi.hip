@@ -34,6 +34,9 @@ thread_local std::string g_err;
 // schedule.  Set by tests that A/B the schedules in one process; never read from the environment.
 int g_opt_sched16 = -1;
 int g_opt_fused = -1;      // likewise for the fused row-tile schedule (fused_rows.h): 0 = never take it
+unsigned long long* g_dbg_stamps = nullptr;   // testing hook: timeline buffer of the fused kernels ([2][blocks][8] 100 MHz ticks)
+int g_dbg_stamp_blocks = 0;
+int g_opt_fused_variant = 1;                  // developer A/B of the fused kernels' weight streaming (fused_rows.h)
 int g_opt_fused_save = 0;  // 1 = inference calls of the fused schedule also write what a backward would need (tests read it back)
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -96,8 +99,9 @@ struct Ws {
   struct F17 {
     us16 *Wrg, *Wkg, *Wqkv_rg, *Wqkv_kg, *Wo1, *Wo2, *W1, *W2;
     us16 *X16, *KG16, *R16, *G16, *Q16, *Q2_16, *KV16, *KV2_16, *O16, *O2_16, *Y16, *Y2_16, *XH16, *XH2_16;
-    float *rstd1, *rstd2, *lse2; uint32_t *mask1, *mask2;
+    float *rstd1, *rstd2, *lse2, *part; uint32_t *mask1, *mask2;
   } f;
+  int* tickets;         // [B] arrival counters of the KG->RG attention splits (inside the zero block)
   size_t bytes;
 };
 
@@ -123,10 +127,13 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
     w.H1 = c.take<float>(T * 2 * H); w.H2 = c.take<float>(TK * 2 * H);
     w.means_n = (size_t)B * 6 * H;
     {   // one contiguous block so a single memset clears every atomically-accumulated buffer
-      const size_t nz = w.means_n + (size_t)B * H + TK * 2 * H;
+      const size_t nzt = ((size_t)B + 3) & ~size_t(3);                       // tickets: padded to 16 bytes
+      const size_t nz = w.means_n + (size_t)B * H + nzt + TK * 2 * H;
       float* z = c.take<float>(nz);
       w.zero_base = z; w.zero_bytes = nz * sizeof(float);
-      w.means = z; w.dfused = z ? z + w.means_n : nullptr; w.dKV = z ? w.dfused + (size_t)B * H : nullptr;
+      w.means = z; w.dfused = z ? z + w.means_n : nullptr;
+      w.tickets = z ? reinterpret_cast<int*>(w.dfused + (size_t)B * H) : nullptr;
+      w.dKV = z ? w.dfused + (size_t)B * H + nzt : nullptr;
     }
     if (w.means) { w.Ymean = w.means; w.H1mean = w.Ymean + B * H; w.Y2mean = w.H1mean + B * 2 * H; w.H2mean = w.Y2mean + B * H; }
     w.comb = c.take<float>(B * 2 * H); w.F1 = c.take<float>(B * H); w.fused = c.take<float>(B * H);
@@ -165,6 +172,7 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
         f.XH16 = c.take<us>(Tp * H); f.XH2_16 = c.take<us>(TKp * H);
         f.rstd1 = c.take<float>(Tp); f.rstd2 = c.take<float>(TKp); f.lse2 = c.take<float>((size_t)B * 8 * 16 * 2);
         f.mask1 = c.take<uint32_t>(Tp * 16); f.mask2 = c.take<uint32_t>(TKp * 16);
+        f.part = c.take<float>(((size_t)T / 32 + B + 2) * 8 * FUSED_PART_FLOATS);
       }
     }
   } else {
@@ -445,12 +453,13 @@ int forward_nodes16(const camo_dims_t& d, const float* const* P, const float* rg
 }
 
 // ---- node-level forward of the fused row-tile schedule: the same function in 3 launches (fused_rows.h) ----
-bool fused17_ok(const camo_dims_t& d, const float* const* P, int precision, int Nk) {
-  return g_opt_fused != 0 && precision == CAMO_PREC_BF16 && fused17_dims(d) && Nk <= 16 && P[CAMO_P_RG_PROJ_W] && P[CAMO_P_KG_PROJ_W];
+bool fused17_ok(const camo_dims_t& d, const float* const* P, int precision, int Nk, int max_nr) {
+  return g_opt_fused != 0 && precision == CAMO_PREC_BF16 && fused17_dims(d) && Nk <= 16 && max_nr <= 64 * FUSED_MAX_SPLITS &&
+         P[CAMO_P_RG_PROJ_W] && P[CAMO_P_KG_PROJ_W];
 }
 
 int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg, const int32_t* rg_offsets, const Desc& bd,
-                    const float* kg, int B, int T, int Nk, const Ws& w, const DropCfg& drop, bool save, hipStream_t st) {
+                    const float* kg, int B, int T, int Nk, int max_nr, const Ws& w, const DropCfg& drop, bool save, hipStream_t st) {
   const int H = 256, D = 128, TK = B * Nk;
   const size_t HH = (size_t)H * H;
   const Ws::F17& f = w.f;
@@ -474,7 +483,8 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   fa.qscale = 1.0f / sqrtf(32.0f); fa.save = save ? 1 : 0;
   fa.s[0] = FrontStream{rg, T, f.Wrg, P[CAMO_P_RG_PROJ_B], f.Wqkv_rg, P[CAMO_P_A1_IN_B], P[CAMO_P_A2_IN_B] + H, f.X16, f.R16, f.Q16, f.KV2_16, 0};
   fa.s[1] = FrontStream{kg, TK, f.Wkg, P[CAMO_P_KG_PROJ_B], f.Wqkv_kg, P[CAMO_P_A2_IN_B], P[CAMO_P_A1_IN_B] + H, f.KG16, f.G16, f.Q2_16, f.KV16, 0};
-  CK(launch_fused_front(fa, st), "fused forward, front half");
+  fa.stamps = g_dbg_stamps;
+  CK(launch_fused_front(fa, g_opt_fused_variant, st), "fused forward, front half");
   BackArgs ba; std::memset(&ba, 0, sizeof(ba));
   ba.s[0] = BackStream{f.Wo1, P[CAMO_P_A1_OUT_B], f.W1, P[CAMO_P_F1_B0], P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], f.R16,
                        f.O16, f.Y16, f.XH16, f.rstd1, f.mask1, w.Ymean, w.H1mean, SITE_FFN_RG};
@@ -483,8 +493,10 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   ba.Q16 = f.Q16; ba.KV16 = f.KV16; ba.Q2_16 = f.Q2_16; ba.KV2_16 = f.KV2_16;
   ba.off = rg_offsets; ba.tile_off = bd.tile_off; ba.inv_nr = bd.inv_nr; ba.lse2 = f.lse2;
   ba.B = B; ba.Nk = Nk; ba.rg_tiles_max = T / 32 + B;          // >= sum of ceil(Nr / 32); surplus blocks exit at once
+  ba.part = f.part; ba.tickets = w.tickets; ba.max_splits = (max_nr + 63) / 64;
   ba.drop = drop; ba.save = save ? 1 : 0;
-  CK(launch_fused_back(ba, st), "fused forward, back half");
+  ba.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)g_dbg_stamp_blocks * 8 : nullptr;
+  CK(launch_fused_back(ba, g_opt_fused_variant, st), "fused forward, back half");
   return 0;
 }
 
@@ -618,7 +630,7 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   // the bf16 schedule's prep launch does it along with its casts
   // inference calls (nothing saved for a backward, no attention maps asked for) at the reference configuration take the
   // fused row-tile schedule
-  const bool use17 = (flags & CAMO_FWD_INFERENCE) && !attn_rg2kg && !attn_kg2rg && fused17_ok(d, P, precision, Nk);
+  const bool use17 = (flags & CAMO_FWD_INFERENCE) && !attn_rg2kg && !attn_kg2rg && fused17_ok(d, P, precision, Nk, max_nr);
   const bool use16 = !use17 && sched16_ok(d, P, precision, T, Nk, max_nr);
   if (!use16 && !use17) CK((int)hipMemsetAsync(w.zero_base, 0, w.zero_bytes, st), "memset zero block");
 
@@ -642,7 +654,7 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   if (!P[CAMO_P_KG_PROJ_W] && Dk != H) return fail(CAMO_E_ARG, "kg_proj weight missing but kg_dim != hidden_dim");
   const size_t HH2 = (size_t)H * H;
   if (use17) {
-    if (int e = forward_nodes17(d, P, rg, rg_offsets, bd, kg, B, T, Nk, w, drop, g_opt_fused_save != 0, st)) return e;
+    if (int e = forward_nodes17(d, P, rg, rg_offsets, bd, kg, B, T, Nk, max_nr, w, drop, g_opt_fused_save != 0, st)) return e;
   } else if (use16) {
     if (int e = forward_nodes16(d, P, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, w, attn_rg2kg, attn_kg2rg, drop, st)) return e;
   } else {
@@ -888,7 +900,13 @@ int camo_debug_set_option(const char* name, int32_t value) {
   if (std::strcmp(name, "sched16") == 0) { g_opt_sched16 = value; return 0; }
   if (std::strcmp(name, "fused") == 0) { g_opt_fused = value; return 0; }
   if (std::strcmp(name, "fused_save") == 0) { g_opt_fused_save = value; return 0; }
+  if (std::strcmp(name, "fused_variant") == 0) { g_opt_fused_variant = value; return 0; }
   return fail(CAMO_E_ARG, std::string("unknown option ") + name);
+}
+
+int camo_debug_set_stamps(void* buf, int32_t blocks_per_kernel) {
+  g_dbg_stamps = static_cast<unsigned long long*>(buf); g_dbg_stamp_blocks = blocks_per_kernel;
+  return 0;
 }
 
 int camo_prof_begin(int32_t max_launches) {

@@ -201,6 +201,9 @@ int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int3
  *              (names for camo_debug_ws_offset: R16 G16 Q16 Q2_16 KV16 KV2_16 O16 O2_16 Y16 Y2_16 XH16 XH2_16 rstd1 rstd2
  *              mask1 mask2 lse2 X16 Wqkv_rg W1s Ymean H1mean Y2mean H2mean). */
 int camo_debug_set_option(const char* name, int32_t value);
+/* camo_debug_set_stamps: developer timeline of the fused kernels.  buf = device buffer of 2 * blocks_per_kernel * 8 uint64
+ * (or NULL to switch it off): wave 0 of every block stores the 100 MHz wall clock at its phase boundaries. */
+int camo_debug_set_stamps(void* buf, int32_t blocks_per_kernel);
 
 /* Opt-in launch timing for bench.py's roofline leg: between camo_prof_begin and camo_prof_end every
  * launch of the grouped GEMM kernel (the dominant kernel: >= 98 % of the path's FLOPs) is bracketed

@@ -1,0 +1,43 @@
+"""Developer aid: per-block phase timeline of the fused forward kernels (100 MHz wall clock stamps).
+   python tests/dev_timeline.py [B]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import make_batches  # noqa: E402
+from camouflage_multimodal_amd import NativeTrainer, _lib, build_multimodal_model  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+model = build_multimodal_model({}).cuda().set_precision("bf16").eval()
+tr = NativeTrainer(model)
+rg, nrs, kg, *_ = make_batches(1, B, 0)[0]
+rg, kg = torch.from_numpy(rg).cuda(), torch.from_numpy(kg).cuda()
+NB = 8192
+_lib.lib().camo_debug_set_option(b"fused_variant", variant)
+nkg = B * ((max(nrs) + 63) // 64)
+buf = torch.zeros(2 * NB * 8, dtype=torch.int64, device="cuda")
+for i in range(5):
+    tr.evaluate(rg, nrs, kg)
+_lib.lib().camo_debug_set_stamps(buf.data_ptr(), NB)
+tr.evaluate(rg, nrs, kg)
+torch.cuda.synchronize()
+_lib.lib().camo_debug_set_stamps(None, 0)
+st = buf.cpu().numpy().reshape(2, NB, 8)
+for k, name in enumerate(("front", "back")):
+    s = st[k]
+    act = s[:, 0] > 0
+    s = s[act].astype(np.float64)
+    t0 = s[:, 0].min()
+    print(f"--- {name} (variant {variant}): {act.sum()} blocks, kernel span {(s[:, 3].max() - t0) / 100:.2f} us; first block starts at 0, last starts at {(s[:, 0].max() - t0) / 100:.2f} us")
+    ph = np.diff(s[:, :4], axis=1) / 100.0
+    idx = np.nonzero(act)[0]
+    groups = [("KG splits", idx < nkg), ("RG tiles", idx >= nkg)] if name == "back" else [("all tiles", idx >= 0)]
+    for gname, sel in groups:
+        if sel.any():
+            print(f"  {gname:10s} n={sel.sum():4d}  phase durations us (median / max): " +
+                  "  ".join(f"{np.median(ph[sel, j]):.2f}/{ph[sel, j].max():.2f}" for j in range(3)) +
+                  f"   block total median {np.median(ph[sel].sum(1)):.2f} max {ph[sel].sum(1).max():.2f}")
