@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "libcamo_fusion.so")
 
 ABI_VERSION = 4
 FWD_INFERENCE = 1
+FLAG_ATTN_MAPS = 2
 SUMSQ_FLOATS = 257
 FUSION_CROSS_ATTENTION, FUSION_LATE = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -69,7 +70,7 @@ def lib():
     L.camo_forward.restype = C.c_int
     L.camo_forward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, vp, vp, i32, u64, i32, i32, vp]
     L.camo_backward.restype = C.c_int
-    L.camo_backward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, vp, i32, i32, u64, i32, vp]
+    L.camo_backward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, vp, i32, i32, u64, i32, i32, vp]
     L.camo_loss.restype = C.c_int
     L.camo_loss.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.camo_grad_sumsq.restype = C.c_int

@@ -17,8 +17,9 @@ typedef unsigned short us16;
 // A logical W is up to 3 source blocks stacked along N (transposed == 0: W[n][k] = src_i[(n - n0_i) * ld_i + k]) or, for the
 // backward's dy.W products, stacked along K and read transposed (transposed == 1: W[n][k] = src_i[(k - k0_i) * ld_i + n]).
 struct ShadowJob { us16* dst; int N, K, transposed, nsrc; const float* src[3]; int rows[3]; int ld[3]; int chunk_begin; };
-#define SHADOW_MAXJ 16
-struct ShadowBatch { ShadowJob j[SHADOW_MAXJ]; int n; void* zero_ptr; size_t zero_bytes; };
+#define SHADOW_MAXJ 24
+#define SHADOW_MAXZ 24
+struct ShadowBatch { ShadowJob j[SHADOW_MAXJ]; int n; void* zero_ptr[SHADOW_MAXZ]; size_t zero_bytes[SHADOW_MAXZ]; int nzero; };
 int launch_weight_shadows(ShadowBatch& sb, hipStream_t stream);
 
 // ---- forward, front half
@@ -56,6 +57,43 @@ struct BackArgs {
   unsigned long long* stamps;                  // developer timeline (null in product calls)
 };
 int launch_fused_back(BackArgs& a, int variant, hipStream_t stream);
+
+// ---- backward, first half (see fused_rows.hip)
+struct Bwd1Stream {
+  const us16* W1T; const us16* WoT;            // transposed shadows: [256 x 512] (dY = dH . W1), [256 x 256] (dO = dU . Wo)
+  const uint32_t* mask; const us16* XH16; const float* rstd; const float* ln_g;      // saved by the forward
+  const float* dHm; int ld_dHm;                // d(mean H)  [B][ld]: gradient w.r.t. the pooled FFN activation
+  const float* dcomb; int ld_dcomb;            // d(mean Z)  [B][ld] (+ this stream's column offset): pooled residual-path gradient
+  us16* dH16; us16* dU16;                      // out: [rows][512] FFN pre-activation gradient, [rows][256] LayerNorm input gradient
+  float* dgamma; float* dbeta;                 // += (atomics)
+};
+struct Bwd1Args {
+  Bwd1Stream s[2];                             // 0: RG rows, 1: KG rows
+  const us16* Q16; const us16* KV16;           // RG queries (pre-scaled) [T][256]; KG keys|values [B*Nk][512]
+  us16* dQKV16; float* dKV;                    // out: dQ into columns 0..255 of [T][768]; dK|dV [B*Nk][512] += (atomics, zeroed by the caller)
+  const us16* O2_16; us16* dO2_16; float* delta2;   // KG: attention output in, its gradient out [B*Nk][256], row-dots out [B][8][16]
+  const int* off; const int* tile_off; const float* inv_nr;
+  int B, Nk, rg_tiles_max; float qscale; DropCfg drop; unsigned long long* stamps;
+};
+int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream);
+size_t fused_bwd1_lds();
+
+// ---- backward, second half (see fused_rows.hip)
+struct Bwd2Args {
+  const us16* Q2_16; const us16* dO2_16; const float* lse2; const float* delta2;   // KG side, per sample: queries (pre-scaled), d(attention
+                                                                                    // output) [B*Nk][256], softmax {max, sum} [B][8][16][2], row-dots [B][8][16]
+  const us16* KV2_16;                          // RG keys|values [T][512]
+  us16* dQKV16;                                // [T][768]: dQ in (columns 0..255, first half), dK2|dV2 out (columns 256..767)
+  const us16* dU16; const us16* WcRgT; us16* dR16;    // dR = dU + [dQ|dK2|dV2] . [Wq1; Wk2; Wv2]: shadow [256 x 768] (transposed job), out [T][256]
+  float* dQ2acc;                               // [B*Nk][256] += (atomics; zeroed by the caller)
+  const float* dKV;                            // [B*Nk][512] dK|dV sums of the first half
+  const us16* dU2_16; const us16* WcKgT; us16* dQKVkg16; us16* dG16;              // KG rows: [B*Nk][768] out (weight-gradient operand), [B*Nk][256] out
+  int* tickets;                                // [B] zeroed arrival counters (one per sample)
+  const int* off; const int* tile_off;
+  int B, Nk, rg_tiles_max; float qscale; DropCfg drop; unsigned long long* stamps;
+};
+int launch_fused_bwd2(Bwd2Args& a, int variant, hipStream_t stream);
+size_t fused_bwd2_lds();
 
 #define FUSED_PART_FLOATS 544
 #define FUSED_MAX_SPLITS 64

@@ -46,22 +46,27 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // `rot` (block-uniform) rotates the order of the k steps (tiles of a launch all walk the SAME weight stream).
 // prefetch() issues the first DEPTH weight loads and may be called well before run() -- ahead of the epilogue or the
 // attention that produces the stage's input -- so that the stream is already flowing when the MFMAs start.
-template <int NT, int KS, bool W_IS_A, int DEPTH>
+template <int NT, int KS, bool W_IS_A, int DEPTH, bool USE_ROT = true>
 struct Stage {
   static constexpr int TOTAL = NT * KS;
   static constexpr int D = DEPTH < TOTAL ? DEPTH : TOTAL;
-  static_assert((KS & (KS - 1)) == 0, "k steps: power of two");
+  static_assert(!USE_ROT || (KS & (KS - 1)) == 0, "rotated k order: power-of-two k steps");
   u32x4 buf[D];
   const u32x4* wp; int rot;
-  __device__ __forceinline__ const u32x4* wptr(int i) const { return wp + 64 * ((((i / NT) + rot) & (KS - 1)) * NT + (i % NT)); }
+  __device__ __forceinline__ int keff(int ks) const { return USE_ROT ? ((ks + rot) & (KS - 1)) : ks; }
+  __device__ __forceinline__ const u32x4* wptr(int i) const { return wp + 64 * (keff(i / NT) * NT + (i % NT)); }
   __device__ __forceinline__ void prefetch(const u32x4* __restrict__ wp_, int rot_) {
     wp = wp_; rot = rot_;
 #pragma unroll
     for (int i = 0; i < D; ++i) buf[i] = *wptr(i);
   }
   __device__ __forceinline__ void run(const char* act, f32x16 (&acc)[NT]) {
-    auto aptr = [&](int ks) { return act + 32 * ((ks + rot) & (KS - 1)); };
-    bf16x8 x = *reinterpret_cast<const bf16x8*>(aptr(0)), xn = x;
+    run_f([&](int ks) { return *reinterpret_cast<const bf16x8*>(act + 32 * ks); }, acc);
+  }
+  // frag(ks): this lane's activation fragment of k step ks (the default reads it from the LDS tile)
+  template <class F>
+  __device__ __forceinline__ void run_f(F&& frag, f32x16 (&acc)[NT]) {
+    bf16x8 x = frag(keff(0)), xn = x;
     // One step = {issue the weight load DEPTH fragments ahead, (first tile of a k step: start the NEXT k step's activation
     // read), MFMA}.  The scheduling barrier pins that order: left alone, hipcc sinks every load next to its use and the
     // stream runs at one L2 round trip per fragment (measured: s_waitcnt vmcnt(1) in front of almost every MFMA).
@@ -72,7 +77,7 @@ struct Stage {
       if (i + D < TOTAL) buf[i % D] = *wptr(i + D);
       if (t == 0) {
         x = xn;
-        if (ks + 1 < KS) xn = *reinterpret_cast<const bf16x8*>(aptr(ks + 1));
+        if (ks + 1 < KS) xn = frag(keff(ks + 1));
       }
       if constexpr (W_IS_A) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, x, acc[t], 0, 0, 0);
       else                  acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, wf, acc[t], 0, 0, 0);
@@ -101,9 +106,9 @@ __device__ __forceinline__ void copy_out(const char* lds, int pitch, int col_byt
 // ------------------------------------------------------------------------------------------------ weight shadows
 __global__ __launch_bounds__(256) void shadow_kernel(const ShadowBatch sb, int total_chunks) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
-  if (sb.zero_ptr) {                                       // the step's atomics block rides along (grid-stride, 16 B per thread)
-    u32x4* z = static_cast<u32x4*>(sb.zero_ptr);
-    const size_t n16 = sb.zero_bytes >> 4;
+  for (int zi = 0; zi < sb.nzero; ++zi) {                  // the step's atomics block and operand pad rows ride along
+    u32x4* z = static_cast<u32x4*>(sb.zero_ptr[zi]);
+    const size_t n16 = sb.zero_bytes[zi] >> 4;
     for (size_t i = gid; i < n16; i += (size_t)gridDim.x * 256) z[i] = u32x4{0u, 0u, 0u, 0u};
   }
   if (gid >= total_chunks) return;
@@ -224,6 +229,22 @@ constexpr int B_VS = 16 * PK;                       // 8448
 constexpr int B_REGION_A = 32 * PT * 4;             // 33280 >= 8448 + 9216 (RG) and >= 4 * 32 * 192 (KG)
 constexpr int B_BUFO = B_REGION_A, B_BUFY = B_BUFO + 32 * PR, B_RED = B_BUFY + 32 * PR, B_LDS = B_RED + 1024;   // 33280, 50176, 67072, 68096
 
+// Softmax over the <= 16 keys of one RG row: S holds the (pre-scaled) scores of keys acc_row(i, h), i < 8, in this lane
+// and the other 8 keys in lane ^ 32.  p = probabilities (0 for keys >= Nk).  Forward and backward run this same code.
+__device__ __forceinline__ void rg_softmax(const f32x16& S, int h, int Nk, float (&p)[8]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { p[i] = acc_row(i, h) < Nk ? S[i] : -INFINITY; m = fmaxf(m, p[i]); }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { p[i] = __expf(p[i] - m); sum += p[i]; }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] *= inv;
+}
+
 // RG tile: rows [row0, row0 + nrows) of sample b against its Nk keys; wave w owns heads 2w, 2w+1.  Leaves the attention
 // output (bf16) in bufO.
 __device__ __forceinline__ void attn_rg_tile(const BackArgs& a, char* smem, int b, size_t row0, int nrows, int w, int lane) {
@@ -257,20 +278,12 @@ __device__ __forceinline__ void attn_rg_tile(const BackArgs& a, char* smem, int 
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (l31 & 15) * PK + 2 * (32 * head + 16 * s + 8 * h));
       S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[hd][s], S, 0, 0, 0);
     }
-    float e[8], m = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { e[i] = acc_row(i, h) < Nk ? S[i] : -INFINITY; m = fmaxf(m, e[i]); }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { e[i] = __expf(e[i] - m); sum += e[i]; }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    float e[8];
+    rg_softmax(S, h, Nk, e);
     const uint32_t ibase = ((uint32_t)(row0 + l31) * 8u + (uint32_t)head) * (uint32_t)Nk;
+    if (dodrop) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      e[i] *= inv;
-      if (dodrop) e[i] *= drop_mult(a.drop, SITE_ATTN_RG2KG, ibase + (uint32_t)acc_row(i, h));
+      for (int i = 0; i < 8; ++i) e[i] *= drop_mult(a.drop, SITE_ATTN_RG2KG, ibase + (uint32_t)acc_row(i, h));
     }
     const bf16x8 pf = as_frag(u32x4{pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])});
     // O^T = V_h^T . P^T: one k step over the 16 keys; A fragment (lane = feature) element jj = key 8 (jj >> 2) + 4 h + (jj & 3)
@@ -601,6 +614,463 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
   stamp(a.stamps, 3);
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward, first half
+// Per tile (RG: 32 rows of a sample; KG: the Nk rows of a sample), from the pooled gradients the per-sample tail left:
+//   dH = mask(H) * d(mean H) / n          (virtual: built from the forward's bit mask while the weights stream; also written
+//                                           out as the weight-gradient operand)
+//   dY = d(mean Z) / n + dH . W1 ;  dU = LayerNorm_backward(dY) (+ dgamma, dbeta) ;  dO = dU . Wo
+// RG tiles go on with the RG->KG attention backward (scores recomputed from the saved queries): dQ per row, dK / dV summed
+// over the tile into the sample's rows with fp32 atomics.  KG blocks emit dO2 and the softmax row-dots delta2 = dO2 . O2 that
+// the second half needs for the KG->RG direction.
+constexpr int W_GTAB = 0, W_BUFDU = 1024, W_KS = W_BUFDU + 32 * PR, W_VS = W_KS + 16 * PK, W_BUFDO = W_VS + 16 * PK,
+              W_IMGS = W_BUFDO + 32 * PR, W_RED = W_IMGS + 16384, W_LDS = W_RED + 1024;          // 69120 bytes
+static_assert(32 * PR + 16384 == 32 * PT * 4, "the fp32 column-sum tile aliases [bufdO | images]");
+
+template <int DEPTH, bool ROT>
+__global__ __launch_bounds__(256, 2) void bwd1_kernel(const Bwd1Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool kg = (int)blockIdx.x < a.B;
+  const int rot = ROT ? (int)(blockIdx.x >> 3) : 0;
+  int b; size_t rowg0; int nrows; float inv_n;
+  if (kg) {
+    b = blockIdx.x; rowg0 = (size_t)b * a.Nk; nrows = a.Nk; inv_n = 1.0f / (float)a.Nk;
+  } else {
+    const int tile = (int)blockIdx.x - a.B;
+    if (tile >= a.tile_off[a.B]) return;
+    int lo = 0, hi = a.B - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_off[mid] <= tile) lo = mid; else hi = mid - 1; }
+    b = lo;
+    const int r0 = a.off[b] + 32 * (tile - a.tile_off[b]);
+    rowg0 = r0; nrows = min(32, a.off[b + 1] - r0); inv_n = a.inv_nr[b];
+  }
+  const Bwd1Stream& S = a.s[kg ? 1 : 0];
+  us16* gtab = reinterpret_cast<us16*>(smem + W_GTAB);
+  char* bufdU = smem + W_BUFDU; char* bufQ = bufdU;                      // (the query tile moves in once dU is consumed)
+  char* Ks = smem + W_KS; char* Vs = smem + W_VS; char* bufdO = smem + W_BUFDO; char* imgs = smem + W_IMGS + w * 4096;
+  float* red = reinterpret_cast<float*>(smem + W_RED);
+  float* tile32 = reinterpret_cast<float*>(smem + W_BUFDO);
+  stamp(a.stamps, 0);
+  Stage<2, 32, true, DEPTH, false> st1;                                  // k order fixed: the mask words are indexed statically
+  st1.prefetch(reinterpret_cast<const u32x4*>(S.W1T) + (size_t)w * (32 * 2 * 64) + lane, 0);
+  const size_t vrow = rowg0 + min(l31, nrows - 1);                       // this lane's row, clamped into the tile
+  const bool rok = l31 < nrows;
+  // per-sample FFN gradient row -> bf16 table (what a set mask bit selects); this row's 512 mask bits
+  {
+    const float gs = inv_n * a.drop.scale;
+    for (int f = tid; f < 512; f += 256) gtab[f] = f2bf(S.dHm[(size_t)b * S.ld_dHm + f] * gs);
+  }
+  u32x4 mw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) mw[i] = reinterpret_cast<const u32x4*>(S.mask + vrow * 16)[i];
+  u32x4 qreg[4];
+  if (!kg) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                        // query tile: slot id -> row id >> 5, 16-byte chunk id & 31
+      const int id = tid + 256 * i;
+      qreg[i] = *reinterpret_cast<const u32x4*>(a.Q16 + (rowg0 + min(id >> 5, nrows - 1)) * 256 + 8 * (id & 31));
+    }
+    for (int c = tid; c < 16 * 64; c += 256) {                           // the sample's key | value rows, rows Nk..15 cleared
+      const int j = c >> 6, ch = c & 63;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (j < a.Nk) v = *reinterpret_cast<const u32x4*>(a.KV16 + ((size_t)b * a.Nk + j) * 512 + 8 * ch);
+      if (ch < 32) *reinterpret_cast<u32x4*>(Ks + j * PK + 16 * ch) = v;
+      else         *reinterpret_cast<u32x4*>(Vs + j * PK + 16 * (ch - 32)) = v;
+    }
+  }
+  __syncthreads();
+  Stage<2, 16, true, DEPTH> st2;
+  f32x16 acc1[2] = {zero16(), zero16()};
+  st1.run_f([&](int ks) {
+    // features 16 ks + 8 h .. + 7 of this row: mask word ks >> 1, bits 16 (ks & 1) + 8 h ..
+    const uint32_t word = mw[ks >> 3][(ks >> 1) & 3];
+    const uint32_t bits = (word >> (16 * (ks & 1))) >> (8 * h);
+    const u32x4 g = *reinterpret_cast<const u32x4*>(smem + W_GTAB + 2 * (16 * ks + 8 * h));
+    u32x4 fr;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      fr[d] = (((bits >> (2 * d)) & 1u) ? (g[d] & 0xFFFFu) : 0u) | (((bits >> (2 * d + 1)) & 1u) ? (g[d] & 0xFFFF0000u) : 0u);
+    if (rok) *reinterpret_cast<u32x4*>(S.dH16 + (rowg0 + l31) * 512 + 16 * ks + 8 * h) = fr;
+    return as_frag(fr);
+  }, acc1);
+  st2.prefetch(reinterpret_cast<const u32x4*>(S.WoT) + (size_t)w * (16 * 2 * 64) + lane, rot);
+  stamp(a.stamps, 1);
+  // ---- LayerNorm backward: g = dy * gamma, du = (g - mean(g) - xhat * mean(g * xhat)) * rstd; dgamma += dy * xhat, dbeta += dy
+  {
+    float gg[32], xh[32];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
+        const float4 dc = *reinterpret_cast<const float4*>(S.dcomb + (size_t)b * S.ld_dcomb + c0);
+        const float4 gm = *reinterpret_cast<const float4*>(S.ln_g + c0);
+        const u32x2 xv = *reinterpret_cast<const u32x2*>(S.XH16 + vrow * 256 + c0);
+        float* G = gg + 16 * t + 4 * g; float* X = xh + 16 * t + 4 * g;
+        X[0] = bf_lo(xv.x); X[1] = bf_hi(xv.x); X[2] = bf_lo(xv.y); X[3] = bf_hi(xv.y);
+        const float d0 = fmaf(dc.x, inv_n, acc1[t][4 * g]), d1 = fmaf(dc.y, inv_n, acc1[t][4 * g + 1]);
+        const float d2 = fmaf(dc.z, inv_n, acc1[t][4 * g + 2]), d3 = fmaf(dc.w, inv_n, acc1[t][4 * g + 3]);
+        *reinterpret_cast<float4*>(tile32 + l31 * PT + c0) = make_float4(d0 * X[0], d1 * X[1], d2 * X[2], d3 * X[3]);
+        acc1[t][4 * g] = d0; acc1[t][4 * g + 1] = d1; acc1[t][4 * g + 2] = d2; acc1[t][4 * g + 3] = d3;      // keep dy
+        G[0] = d0 * gm.x; G[1] = d1 * gm.y; G[2] = d2 * gm.z; G[3] = d3 * gm.w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s1 += G[i]; s2 = fmaf(G[i], X[i], s2); }
+      }
+    auto row_total = [&](float p, int slot) {
+      p += __shfl_xor(p, 32, 64);
+      if (h == 0) red[slot * 128 + w * 32 + l31] = p;
+      __syncthreads();
+      return (red[slot * 128 + l31] + red[slot * 128 + 32 + l31]) + (red[slot * 128 + 64 + l31] + red[slot * 128 + 96 + l31]);
+    };
+    const float m1 = row_total(s1, 0) * (1.0f / 256.0f);
+    const float m2 = row_total(s2, 1) * (1.0f / 256.0f);
+    {   // dgamma: column sums of dy * xhat over the tile's rows (thread t owns feature t)
+      float sum = 0.f;
+      for (int r = 0; r < nrows; ++r) sum += tile32[r * PT + tid];
+      atomicAdd(S.dgamma + tid, sum);
+    }
+    const float rstd = S.rstd[vrow];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
+        const float* G = gg + 16 * t + 4 * g; const float* X = xh + 16 * t + 4 * g;
+        float du[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) du[i] = rok ? (G[i] - m1 - X[i] * m2) * rstd : 0.f;
+        *reinterpret_cast<u32x2*>(bufdU + l31 * PR + 2 * c0) = u32x2{pack2(du[0], du[1]), pack2(du[2], du[3])};
+      }
+    __syncthreads();                                                     // dgamma pass done with the tile; dU tile complete
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
+        *reinterpret_cast<float4*>(tile32 + l31 * PT + c0) = make_float4(acc1[t][4 * g], acc1[t][4 * g + 1], acc1[t][4 * g + 2], acc1[t][4 * g + 3]);
+      }
+    __syncthreads();
+    {   // dbeta: column sums of dy
+      float sum = 0.f;
+      for (int r = 0; r < nrows; ++r) sum += tile32[r * PT + tid];
+      atomicAdd(S.dbeta + tid, sum);
+    }
+  }
+  copy_out<5>(bufdU, PR, 0, S.dU16, 256, rowg0, nrows);
+  stamp(a.stamps, 2);
+  // ---- dO^T = Wo^T-side product: lane = row, wave w: the 64 features of heads 2w, 2w+1
+  f32x16 acc2[2] = {zero16(), zero16()};
+  st2.run(bufdU + l31 * PR + 16 * h, acc2);
+  if (kg) {
+    // dO2 (bf16, the second half's MFMA operand) and delta2[head][j] = sum_f dO2[j][f] * O2[j][f]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float dot = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
+        const u32x2 ov = *reinterpret_cast<const u32x2*>(a.O2_16 + vrow * 256 + c0);
+        dot = fmaf(acc2[t][4 * g], bf_lo(ov.x), dot); dot = fmaf(acc2[t][4 * g + 1], bf_hi(ov.x), dot);
+        dot = fmaf(acc2[t][4 * g + 2], bf_lo(ov.y), dot); dot = fmaf(acc2[t][4 * g + 3], bf_hi(ov.y), dot);
+        if (rok) *reinterpret_cast<u32x2*>(a.dO2_16 + (rowg0 + l31) * 256 + c0) =
+            u32x2{pack2(acc2[t][4 * g], acc2[t][4 * g + 1]), pack2(acc2[t][4 * g + 2], acc2[t][4 * g + 3])};
+      }
+      dot += __shfl_xor(dot, 32, 64);
+      if (h == 0 && rok) a.delta2[((size_t)b * 8 + 2 * w + t) * 16 + l31] = dot;
+    }
+    stamp(a.stamps, 3);
+    return;
+  }
+  // ---- RG->KG attention backward
+  __syncthreads();                                                       // every wave is done with the dU tile and the fp32 tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int id = tid + 256 * i; *reinterpret_cast<u32x4*>(bufQ + (id >> 5) * PR + 16 * (id & 31)) = qreg[i]; }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                                        // dO tile (bf16): read back transposed for dV
+      const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
+      *reinterpret_cast<u32x2*>(bufdO + l31 * PR + 2 * c0) =
+          rok ? u32x2{pack2(acc2[t][4 * g], acc2[t][4 * g + 1]), pack2(acc2[t][4 * g + 2], acc2[t][4 * g + 3])} : u32x2{0u, 0u};
+    }
+  __syncthreads();
+  const bool dodrop = a.drop.p > 0.f;
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int head = 2 * w + t;
+    // scores and probabilities, exactly as the forward computed them
+    f32x16 Sc = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (l31 & 15) * PK + 2 * (32 * head + 16 * s + 8 * h));
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(bufQ + l31 * PR + 2 * (32 * head + 16 * s + 8 * h));
+      Sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, Sc, 0, 0, 0);
+    }
+    float pr[8], mm[8];
+    rg_softmax(Sc, h, a.Nk, pr);
+    const uint32_t ibase = ((uint32_t)(rowg0 + l31) * 8u + (uint32_t)head) * (uint32_t)a.Nk;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mm[i] = dodrop ? drop_mult(a.drop, SITE_ATTN_RG2KG, ibase + (uint32_t)acc_row(i, h)) : 1.0f;
+    // dPd^T[j][row] = V_h[j] . dO_h[row]: the dO accumulator is the B operand (k order of its registers), so the A fragment
+    // takes features 16 s + 4 h .. + 3 and 16 s + 8 + 4 h .. + 3 of value row j
+    f32x16 dP = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const char* vp = Vs + (l31 & 15) * PK + 2 * (32 * head + 16 * s + 4 * h);
+      const u32x2 v0 = *reinterpret_cast<const u32x2*>(vp), v1 = *reinterpret_cast<const u32x2*>(vp + 16);
+      const bf16x8 vf = as_frag(u32x4{v0.x, v0.y, v1.x, v1.y});
+      const bf16x8 of = as_frag(u32x4{pack2(acc2[t][8 * s], acc2[t][8 * s + 1]), pack2(acc2[t][8 * s + 2], acc2[t][8 * s + 3]),
+                                      pack2(acc2[t][8 * s + 4], acc2[t][8 * s + 5]), pack2(acc2[t][8 * s + 6], acc2[t][8 * s + 7])});
+      dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, of, dP, 0, 0, 0);
+    }
+    float ds[8], pd[8], delta = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ds[i] = dP[i] * mm[i]; delta = fmaf(pr[i], ds[i], delta); pd[i] = pr[i] * mm[i]; }
+    delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ds[i] = rok ? pr[i] * (ds[i] - delta) : 0.f; if (!rok) pd[i] = 0.f; }
+    const u32x4 dsf = u32x4{pack2(ds[0], ds[1]), pack2(ds[2], ds[3]), pack2(ds[4], ds[5]), pack2(ds[6], ds[7])};
+    const u32x4 pdf = u32x4{pack2(pd[0], pd[1]), pack2(pd[2], pd[3]), pack2(pd[4], pd[5]), pack2(pd[6], pd[7])};
+    {   // dQ^T = scale * K_h^T . dS^T: lane = row
+      const char* kp = Ks + (4 * h + q4) * PK + 2 * (32 * head + 16 * g1 + 4 * p4);
+      const bf16x8 kt = join(lds_tr16(kp), lds_tr16(kp + 8 * PK));
+      const f32x16 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, as_frag(dsf), zero16(), 0, 0, 0);
+      if (rok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<u32x2*>(a.dQKV16 + (rowg0 + l31) * 768 + 32 * head + 8 * g + 4 * h) =
+              u32x2{pack2(dq[4 * g] * a.qscale, dq[4 * g + 1] * a.qscale), pack2(dq[4 * g + 2] * a.qscale, dq[4 * g + 3] * a.qscale)};
+      }
+    }
+    // dS / Pd images [row][16 keys] (bf16): keys 4 h .. + 3 at byte 8 h, keys 8 + 4 h .. at byte 16 + 8 h
+    char* imS = imgs + t * 2048; char* imP = imS + 1024;
+    *reinterpret_cast<u32x2*>(imS + l31 * 32 + 8 * h) = u32x2{dsf.x, dsf.y};
+    *reinterpret_cast<u32x2*>(imS + l31 * 32 + 16 + 8 * h) = u32x2{dsf.z, dsf.w};
+    *reinterpret_cast<u32x2*>(imP + l31 * 32 + 8 * h) = u32x2{pdf.x, pdf.y};
+    *reinterpret_cast<u32x2*>(imP + l31 * 32 + 16 + 8 * h) = u32x2{pdf.z, pdf.w};
+    // dK_h[j][f] += sum_rows dS[j][row] * Qs[row][f];  dV_h[j][f] += sum_rows Pd[j][row] * dO[row][f]  (lane = f, registers = j)
+    f32x16 dK = zero16(), dV = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int r0 = 16 * s + 8 * h + q4;
+      const bf16x8 sA = join(lds_tr16(imS + r0 * 32 + 8 * p4), lds_tr16(imS + (r0 + 4) * 32 + 8 * p4));
+      const bf16x8 pA = join(lds_tr16(imP + r0 * 32 + 8 * p4), lds_tr16(imP + (r0 + 4) * 32 + 8 * p4));
+      const int co = 2 * (32 * head + 16 * g1 + 4 * p4);
+      const bf16x8 qB = join(lds_tr16(bufQ + r0 * PR + co), lds_tr16(bufQ + (r0 + 4) * PR + co));
+      const bf16x8 oB = join(lds_tr16(bufdO + r0 * PR + co), lds_tr16(bufdO + (r0 + 4) * PR + co));
+      dK = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sA, qB, dK, 0, 0, 0);
+      dV = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA, oB, dV, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = acc_row(i, h);
+      if (j < a.Nk) {
+        float* dst = a.dKV + ((size_t)b * a.Nk + j) * 512 + 32 * head + l31;
+        atomicAdd(dst, dK[i]);
+        atomicAdd(dst + 256, dV[i]);
+      }
+    }
+  }
+  stamp(a.stamps, 3);
+}
+
+// ------------------------------------------------------------------------------------------------ backward, second half
+// RG tiles: the KG->RG attention backward for the tile's 32 key/value rows (probabilities recomputed from the saved softmax
+// max / sum), i.e. dK2, dV2 per row and the tile's contribution to the sample's dQ2 (fp32 atomics); then the input
+// gradient of the three in-projections in ONE product, dR = dU + [dQ | dK2 | dV2] . [Wq1; Wk2; Wv2]  (K = 768).
+// The last tile of a sample to finish (arrival counter, as in the forward) runs the same product for the sample's KG rows:
+// dG = dU2 + [dQ2 | dK | dV] . [Wq2; Wk1; Wv1].
+constexpr int X_Q2S = 0, X_DO2S = 16 * PK, X_TABS = 2 * 16 * PK, X_BUFT = X_TABS + 1536, X_IMGS = X_BUFT + 32 * PQ,
+              X_RED = X_IMGS + 8192, X_LDS = X_RED + 64;                                        // 76352 bytes
+
+template <int DEPTH, bool ROT>
+__global__ __launch_bounds__(256, 2) void bwd2_kernel(const Bwd2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x;
+  if (tile >= a.tile_off[a.B]) return;
+  int lo = 0, hi = a.B - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_off[mid] <= tile) lo = mid; else hi = mid - 1; }
+  const int b = lo, Nk = a.Nk;
+  const int r0t = a.off[b] + 32 * (tile - a.tile_off[b]);
+  const size_t rowg0 = r0t;
+  const int nrows = min(32, a.off[b + 1] - r0t);
+  const bool rok = l31 < nrows;
+  const size_t vrow = rowg0 + min(l31, nrows - 1);
+  char* Q2s = smem + X_Q2S; char* dO2s = smem + X_DO2S; float* tabs = reinterpret_cast<float*>(smem + X_TABS);
+  char* bufT = smem + X_BUFT; char* imgs = smem + X_IMGS;
+  int* flag = reinterpret_cast<int*>(smem + X_RED);
+  stamp(a.stamps, 0);
+  Stage<2, 48, true, DEPTH, false> sr;
+  sr.prefetch(reinterpret_cast<const u32x4*>(a.WcRgT) + (size_t)w * (48 * 2 * 64) + lane, 0);
+  // per-sample inputs: the Nk pre-scaled queries, the gradient of their attention output, softmax max / 1/sum, row-dots
+  for (int c = tid; c < 16 * 32; c += 256) {
+    const int j = c >> 5, ch = c & 31;
+    u32x4 q = u32x4{0u, 0u, 0u, 0u}, o = q;
+    if (j < Nk) {
+      q = *reinterpret_cast<const u32x4*>(a.Q2_16 + ((size_t)b * Nk + j) * 256 + 8 * ch);
+      o = *reinterpret_cast<const u32x4*>(a.dO2_16 + ((size_t)b * Nk + j) * 256 + 8 * ch);
+    }
+    *reinterpret_cast<u32x4*>(Q2s + j * PK + 16 * ch) = q;
+    *reinterpret_cast<u32x4*>(dO2s + j * PK + 16 * ch) = o;
+  }
+  if (tid < 128) {
+    const int j = tid & 15;
+    const size_t o = (size_t)b * 128 + tid;                  // [b][head][16]
+    const bool ok = j < Nk;
+    tabs[tid] = ok ? a.lse2[2 * o] : 0.f;
+    tabs[128 + tid] = ok ? 1.0f / a.lse2[2 * o + 1] : 0.f;
+    tabs[256 + tid] = ok ? a.delta2[o] : 0.f;
+  }
+  u32x4 dqreg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                              // slot id -> row id >> 5, 16-byte chunk id & 31: key tile into LDS, dQ tile into registers
+    const int id = tid + 256 * i;
+    const size_t r = rowg0 + min(id >> 5, nrows - 1);
+    *reinterpret_cast<u32x4*>(bufT + (id >> 5) * PQ + 16 * (id & 31)) = *reinterpret_cast<const u32x4*>(a.KV2_16 + r * 512 + 8 * (id & 31));
+    dqreg[i] = *reinterpret_cast<const u32x4*>(a.dQKV16 + r * 768 + 8 * (id & 31));
+  }
+  bf16x8 kf[2][2], vf[2][2];
+  {
+    const us16* kp = a.KV2_16 + vrow * 512 + 64 * w + 8 * h;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        kf[t][s] = as_frag(*reinterpret_cast<const u32x4*>(kp + 32 * t + 16 * s));
+        vf[t][s] = as_frag(*reinterpret_cast<const u32x4*>(kp + 256 + 32 * t + 16 * s));
+      }
+  }
+  __syncthreads();
+  const bool dodrop = a.drop.p > 0.f;
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int head = 2 * w + t;
+    f32x16 S2 = zero16(), dP = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int co = (l31 & 15) * PK + 2 * (32 * head + 16 * s + 8 * h);
+      S2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Q2s + co), kf[t][s], S2, 0, 0, 0);     // [query j][row]
+      dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(dO2s + co), vf[t][s], dP, 0, 0, 0);    // dO2[j] . V2[row]
+    }
+    float ds[8], pd[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = acc_row(i, h);
+      const float p = (j < Nk && rok) ? __expf(S2[i] - tabs[head * 16 + j]) * tabs[128 + head * 16 + j] : 0.f;
+      const float mm = dodrop ? drop_mult(a.drop, SITE_ATTN_KG2RG, ((uint32_t)(rowg0 + l31) * 8u + (uint32_t)head) * (uint32_t)Nk + (uint32_t)j) : 1.0f;
+      ds[i] = p * (dP[i] * mm - tabs[256 + head * 16 + j]);
+      pd[i] = p * mm;
+    }
+    const u32x4 dsf = u32x4{pack2(ds[0], ds[1]), pack2(ds[2], ds[3]), pack2(ds[4], ds[5]), pack2(ds[6], ds[7])};
+    const u32x4 pdf = u32x4{pack2(pd[0], pd[1]), pack2(pd[2], pd[3]), pack2(pd[4], pd[5]), pack2(pd[6], pd[7])};
+    // dV2^T = dO2_h^T . P2d,  dK2^T = Q2s_h^T . dS2: lane = row, registers = the head's 32 features -> bf16 tile [dQ | dK2 | dV2]
+    const int tro = (4 * h + q4) * PK + 2 * (32 * head + 16 * g1 + 4 * p4);
+    const f32x16 dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join(lds_tr16(dO2s + tro), lds_tr16(dO2s + tro + 8 * PK)), as_frag(pdf), zero16(), 0, 0, 0);
+    const f32x16 dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join(lds_tr16(Q2s + tro), lds_tr16(Q2s + tro + 8 * PK)), as_frag(dsf), zero16(), 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * head + 8 * g + 4 * h;
+      *reinterpret_cast<u32x2*>(bufT + l31 * PQ + 2 * (256 + c)) = u32x2{pack2(dk[4 * g], dk[4 * g + 1]), pack2(dk[4 * g + 2], dk[4 * g + 3])};
+      *reinterpret_cast<u32x2*>(bufT + l31 * PQ + 2 * (512 + c)) = u32x2{pack2(dv[4 * g], dv[4 * g + 1]), pack2(dv[4 * g + 2], dv[4 * g + 3])};
+    }
+    // dQ2_h[j][f] += scale * sum_rows dS2[j][row] * K2[row][f]: dS2 image [row][16 queries] and the key tile read transposed
+    char* im = imgs + head * 1024;
+    *reinterpret_cast<u32x2*>(im + l31 * 32 + 8 * h) = u32x2{dsf.x, dsf.y};
+    *reinterpret_cast<u32x2*>(im + l31 * 32 + 16 + 8 * h) = u32x2{dsf.z, dsf.w};
+    f32x16 dq2 = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int r0 = 16 * s + 8 * h + q4;
+      const bf16x8 sA = join(lds_tr16(im + r0 * 32 + 8 * p4), lds_tr16(im + (r0 + 4) * 32 + 8 * p4));
+      const int co = 2 * (32 * head + 16 * g1 + 4 * p4);
+      const bf16x8 kB = join(lds_tr16(bufT + r0 * PQ + co), lds_tr16(bufT + (r0 + 4) * PQ + co));
+      dq2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sA, kB, dq2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = acc_row(i, h);
+      if (j < Nk) atomicAdd(a.dQ2acc + ((size_t)b * Nk + j) * 256 + 32 * head + l31, dq2[i] * a.qscale);
+    }
+  }
+  __syncthreads();                                           // key tile consumed by every wave; dK2 | dV2 tile complete
+  stamp(a.stamps, 1);
+  copy_out<6>(bufT, PQ, 512, a.dQKV16 + 256, 768, rowg0, nrows);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int id = tid + 256 * i; *reinterpret_cast<u32x4*>(bufT + (id >> 5) * PQ + 16 * (id & 31)) = dqreg[i]; }
+  __syncthreads();
+  {
+    f32x16 acc[2] = {zero16(), zero16()};
+    sr.run(bufT + l31 * PQ + 16 * h, acc);
+    if (rok) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
+          const u32x2 uv = *reinterpret_cast<const u32x2*>(a.dU16 + (rowg0 + l31) * 256 + c0);
+          *reinterpret_cast<u32x2*>(a.dR16 + (rowg0 + l31) * 256 + c0) =
+              u32x2{pack2(acc[t][4 * g] + bf_lo(uv.x), acc[t][4 * g + 1] + bf_hi(uv.x)), pack2(acc[t][4 * g + 2] + bf_lo(uv.y), acc[t][4 * g + 3] + bf_hi(uv.y))};
+        }
+    }
+  }
+  stamp(a.stamps, 2);
+  // ---- arrival: the last tile of the sample takes its KG rows through the same product
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flag[0] = __hip_atomic_fetch_add(a.tickets + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (flag[0] != a.tile_off[b + 1] - a.tile_off[b] - 1) return;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  Stage<2, 48, true, DEPTH, false> sg;
+  sg.prefetch(reinterpret_cast<const u32x4*>(a.WcKgT) + (size_t)w * (48 * 2 * 64) + lane, 0);
+  // [dQ2 | dK | dV] of the sample's Nk rows: fp32 sums -> bf16 tile (rows >= Nk cleared)
+  for (int c = tid; c < 32 * 96; c += 256) {                 // 96 chunks of 8 columns per row
+    const int j = c / 96, ch = c - 96 * j;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (j < Nk) {
+      const float* src = ch < 32 ? a.dQ2acc + ((size_t)b * Nk + j) * 256 + 8 * ch : a.dKV + ((size_t)b * Nk + j) * 512 + 8 * (ch - 32);
+      const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+      v = u32x4{pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w)};
+    }
+    *reinterpret_cast<u32x4*>(bufT + j * PQ + 16 * ch) = v;
+  }
+  __syncthreads();
+  const size_t krow0 = (size_t)b * Nk;
+  copy_out<5>(bufT, PQ, 0, a.dQKVkg16, 768, krow0, Nk);
+  copy_out<6>(bufT, PQ, 512, a.dQKVkg16 + 256, 768, krow0, Nk);
+  {
+    f32x16 acc[2] = {zero16(), zero16()};
+    sg.run(bufT + l31 * PQ + 16 * h, acc);
+    if (l31 < Nk) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
+          const u32x2 uv = *reinterpret_cast<const u32x2*>(a.dU2_16 + (krow0 + l31) * 256 + c0);
+          *reinterpret_cast<u32x2*>(a.dG16 + (krow0 + l31) * 256 + c0) =
+              u32x2{pack2(acc[t][4 * g] + bf_lo(uv.x), acc[t][4 * g + 1] + bf_hi(uv.x)), pack2(acc[t][4 * g + 2] + bf_lo(uv.y), acc[t][4 * g + 3] + bf_hi(uv.y))};
+        }
+    }
+  }
+  stamp(a.stamps, 3);
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -620,9 +1090,11 @@ int launch_weight_shadows(ShadowBatch& sb, hipStream_t stream) {
     J.chunk_begin = total;
     total += J.N * J.K / 8;
   }
-  if (sb.zero_ptr && (!al16(sb.zero_ptr) || (sb.zero_bytes & 15))) return (int)hipErrorInvalidValue;
+  if (sb.nzero < 0 || sb.nzero > SHADOW_MAXZ) return (int)hipErrorInvalidValue;
+  for (int i = 0; i < sb.nzero; ++i)
+    if (!sb.zero_ptr[i] || !al16(sb.zero_ptr[i]) || (sb.zero_bytes[i] & 15)) return (int)hipErrorInvalidValue;
   int blocks = (total + 255) / 256;
-  if (sb.zero_ptr && blocks < 64) blocks = 64;
+  if (sb.nzero && blocks < 64) blocks = 64;
   if (blocks == 0) return 0;
   hipLaunchKernelGGL(shadow_kernel, dim3(blocks), dim3(256), 0, stream, sb, total);
   return (int)hipGetLastError();
@@ -673,5 +1145,47 @@ int launch_fused_back(BackArgs& a, int variant, hipStream_t stream) {
   if (variant == 0)      hipLaunchKernelGGL((back_kernel<12, false>), grid, dim3(256), B_LDS, stream, a);
   else if (variant == 2) hipLaunchKernelGGL((back_kernel<16, true>), grid, dim3(256), B_LDS, stream, a);
   else                   hipLaunchKernelGGL((back_kernel<12, true>), grid, dim3(256), B_LDS, stream, a);
+  return (int)hipGetLastError();
+}
+
+size_t fused_bwd1_lds() { return W_LDS; }
+
+int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
+  if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q16 || !a.KV16 || !a.dQKV16 || !a.dKV || !a.O2_16 || !a.dO2_16 || !a.delta2 ||
+      !a.off || !a.tile_off || !a.inv_nr)
+    return (int)hipErrorInvalidValue;
+  for (int i = 0; i < 2; ++i) {
+    const Bwd1Stream& S = a.s[i];
+    if (!S.W1T || !S.WoT || !S.mask || !S.XH16 || !S.rstd || !S.ln_g || !S.dHm || !S.dcomb || !S.dH16 || !S.dU16 || !S.dgamma || !S.dbeta)
+      return (int)hipErrorInvalidValue;
+    if (!al16(S.W1T) || !al16(S.WoT) || !al16(S.mask) || !al16(S.ln_g) || !al16(S.dcomb) || (S.ld_dcomb & 3) || !al16(S.dH16) || !al16(S.dU16))
+      return (int)hipErrorInvalidValue;
+  }
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd1_kernel<12, false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd1_kernel<12, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+    return true;
+  }();
+  (void)attr;
+  const dim3 grid(a.B + a.rg_tiles_max);
+  if (variant == 0) hipLaunchKernelGGL((bwd1_kernel<12, false>), grid, dim3(256), W_LDS, stream, a);
+  else              hipLaunchKernelGGL((bwd1_kernel<12, true>), grid, dim3(256), W_LDS, stream, a);
+  return (int)hipGetLastError();
+}
+
+size_t fused_bwd2_lds() { return X_LDS; }
+
+int launch_fused_bwd2(Bwd2Args& a, int variant, hipStream_t stream) {
+  (void)variant;
+  if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q2_16 || !a.dO2_16 || !a.lse2 || !a.delta2 || !a.KV2_16 || !a.dQKV16 ||
+      !a.dU16 || !a.WcRgT || !a.dR16 || !a.dQ2acc || !a.dKV || !a.dU2_16 || !a.WcKgT || !a.dQKVkg16 || !a.dG16 || !a.tickets || !a.off || !a.tile_off)
+    return (int)hipErrorInvalidValue;
+  if (!al16(a.dQKV16) || !al16(a.dQKVkg16) || !al16(a.WcRgT) || !al16(a.WcKgT) || !al16(a.dQ2acc) || !al16(a.dKV)) return (int)hipErrorInvalidValue;
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd2_kernel<12, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS);
+    return true;
+  }();
+  (void)attr;
+  hipLaunchKernelGGL((bwd2_kernel<12, false>), dim3(a.rg_tiles_max), dim3(256), X_LDS, stream, a);
   return (int)hipGetLastError();
 }

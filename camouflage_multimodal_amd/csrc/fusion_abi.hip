@@ -100,8 +100,13 @@ struct Ws {
     us16 *Wrg, *Wkg, *Wqkv_rg, *Wqkv_kg, *Wo1, *Wo2, *W1, *W2;
     us16 *X16, *KG16, *R16, *G16, *Q16, *Q2_16, *KV16, *KV2_16, *O16, *O2_16, *Y16, *Y2_16, *XH16, *XH2_16;
     float *rstd1, *rstd2, *lse2, *part; uint32_t *mask1, *mask2;
+    // backward: transposed shadows, the bf16 gradients that are weight-gradient operands, per-sample exchange buffers
+    us16 *W1T, *W2T, *Wo1T, *Wo2T, *WcRgT, *WcKgT;
+    us16 *dH16, *dH2_16, *dU16, *dU2_16, *dQKV16, *dQKVkg16, *dR16, *dG16, *dO2_16;
+    float* delta2;
   } f;
-  int* tickets;         // [B] arrival counters of the KG->RG attention splits (inside the zero block)
+  int* tickets;         // [2][B] arrival counters (forward: KG->RG attention splits; backward: a sample's RG tiles), in the zero block
+  float* dQ2acc;        // [TK][H] fp32 sums of the KG->RG query gradient (in the zero block, fused backward)
   size_t bytes;
 };
 
@@ -127,13 +132,14 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
     w.H1 = c.take<float>(T * 2 * H); w.H2 = c.take<float>(TK * 2 * H);
     w.means_n = (size_t)B * 6 * H;
     {   // one contiguous block so a single memset clears every atomically-accumulated buffer
-      const size_t nzt = ((size_t)B + 3) & ~size_t(3);                       // tickets: padded to 16 bytes
-      const size_t nz = w.means_n + (size_t)B * H + nzt + TK * 2 * H;
+      const size_t nzt = ((size_t)2 * B + 3) & ~size_t(3);                   // tickets: padded to 16 bytes
+      const size_t nz = w.means_n + (size_t)B * H + nzt + TK * 2 * H + TK * H;
       float* z = c.take<float>(nz);
       w.zero_base = z; w.zero_bytes = nz * sizeof(float);
       w.means = z; w.dfused = z ? z + w.means_n : nullptr;
       w.tickets = z ? reinterpret_cast<int*>(w.dfused + (size_t)B * H) : nullptr;
       w.dKV = z ? w.dfused + (size_t)B * H + nzt : nullptr;
+      w.dQ2acc = z ? w.dKV + TK * 2 * H : nullptr;
     }
     if (w.means) { w.Ymean = w.means; w.H1mean = w.Ymean + B * H; w.Y2mean = w.H1mean + B * 2 * H; w.H2mean = w.Y2mean + B * H; }
     w.comb = c.take<float>(B * 2 * H); w.F1 = c.take<float>(B * H); w.fused = c.take<float>(B * H);
@@ -173,6 +179,11 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
         f.rstd1 = c.take<float>(Tp); f.rstd2 = c.take<float>(TKp); f.lse2 = c.take<float>((size_t)B * 8 * 16 * 2);
         f.mask1 = c.take<uint32_t>(Tp * 16); f.mask2 = c.take<uint32_t>(TKp * 16);
         f.part = c.take<float>(((size_t)T / 32 + B + 2) * 8 * FUSED_PART_FLOATS);
+        f.W1T = c.take<us>(2 * H * H); f.W2T = c.take<us>(2 * H * H); f.Wo1T = c.take<us>(H * H); f.Wo2T = c.take<us>(H * H);
+        f.WcRgT = c.take<us>(3 * H * H); f.WcKgT = c.take<us>(3 * H * H);
+        f.dH16 = c.take<us>(Tp * 2 * H); f.dH2_16 = c.take<us>(TKp * 2 * H); f.dU16 = c.take<us>(Tp * H); f.dU2_16 = c.take<us>(TKp * H);
+        f.dQKV16 = c.take<us>(Tp * 3 * H); f.dQKVkg16 = c.take<us>(TKp * 3 * H); f.dR16 = c.take<us>(Tp * H); f.dG16 = c.take<us>(TKp * H);
+        f.dO2_16 = c.take<us>(TKp * H); f.delta2 = c.take<float>((size_t)B * 8 * 16);
       }
     }
   } else {
@@ -475,8 +486,29 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
     job(f.Wqkv_kg, 3 * H, H, P[CAMO_P_A2_IN_W], H, P[CAMO_P_A1_IN_W] + HH, 2 * H);       // [Wq2; Wk1; Wv1]
     job(f.Wo1, H, H, P[CAMO_P_A1_OUT_W], H); job(f.Wo2, H, H, P[CAMO_P_A2_OUT_W], H);
     job(f.W1, 2 * H, H, P[CAMO_P_F1_W0], 2 * H); job(f.W2, 2 * H, H, P[CAMO_P_F2_W0], 2 * H);
-    sb.zero_ptr = w.zero_base;
-    sb.zero_bytes = ((size_t)(reinterpret_cast<char*>(w.dKV) - reinterpret_cast<char*>(w.zero_base)) + 15) & ~size_t(15);
+    auto zero = [&](void* ptr, size_t bytes) { if (bytes) { sb.zero_ptr[sb.nzero] = ptr; sb.zero_bytes[sb.nzero++] = (bytes + 15) & ~size_t(15); } };
+    if (save) {
+      // transposed shadows of the backward's dy . W products; K-concatenated where one product serves three in-projections
+      auto jobT = [&](us* dst, int N, int K, const float* s0, int r0, const float* s1 = nullptr, int r1 = 0) {
+        ShadowJob& J = sb.j[sb.n++];
+        J.dst = dst; J.N = N; J.K = K; J.transposed = 1; J.nsrc = s1 ? 2 : 1;
+        J.src[0] = s0; J.rows[0] = r0; J.ld[0] = N; J.src[1] = s1; J.rows[1] = r1; J.ld[1] = N;
+      };
+      jobT(f.W1T, H, 2 * H, P[CAMO_P_F1_W0], 2 * H); jobT(f.W2T, H, 2 * H, P[CAMO_P_F2_W0], 2 * H);
+      jobT(f.Wo1T, H, H, P[CAMO_P_A1_OUT_W], H); jobT(f.Wo2T, H, H, P[CAMO_P_A2_OUT_W], H);
+      jobT(f.WcRgT, H, 3 * H, P[CAMO_P_A1_IN_W], H, P[CAMO_P_A2_IN_W] + HH, 2 * H);      // dR = [dQ | dK2 | dV2] . [Wq1; Wk2; Wv2]
+      jobT(f.WcKgT, H, 3 * H, P[CAMO_P_A2_IN_W], H, P[CAMO_P_A1_IN_W] + HH, 2 * H);      // dG = [dQ2 | dK | dV] . [Wq2; Wk1; Wv1]
+      zero(w.zero_base, w.zero_bytes);                       // means, dfused, arrival counters, dK|dV and dQ2 sums
+      // pad rows (row count rounded up to 128) of every weight-gradient operand: the contraction runs over whole 64-row tiles
+      const size_t t = T, tk = TK;
+      auto pad = [&](us* buf, size_t rows, size_t rows_p, size_t width) { zero(buf + rows * width, (rows_p - rows) * width * sizeof(us)); };
+      pad(f.X16, t, w.Tp, D); pad(f.R16, t, w.Tp, H); pad(f.O16, t, w.Tp, H); pad(f.Y16, t, w.Tp, H); pad(f.dH16, t, w.Tp, 2 * H);
+      pad(f.dU16, t, w.Tp, H); pad(f.dQKV16, t, w.Tp, 3 * H); pad(f.dR16, t, w.Tp, H);
+      pad(f.KG16, tk, w.TKp, D); pad(f.G16, tk, w.TKp, H); pad(f.O2_16, tk, w.TKp, H); pad(f.Y2_16, tk, w.TKp, H); pad(f.dH2_16, tk, w.TKp, 2 * H);
+      pad(f.dU2_16, tk, w.TKp, H); pad(f.dQKVkg16, tk, w.TKp, 3 * H); pad(f.dG16, tk, w.TKp, H);
+    } else {
+      zero(w.zero_base, (size_t)(reinterpret_cast<char*>(w.dKV) - reinterpret_cast<char*>(w.zero_base)));
+    }
     CK(launch_weight_shadows(sb, st), "weight shadows");
   }
   FrontArgs fa; std::memset(&fa, 0, sizeof(fa));
@@ -499,6 +531,10 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   CK(launch_fused_back(ba, g_opt_fused_variant, st), "fused forward, back half");
   return 0;
 }
+
+// ---- node-level backward of the fused row-tile schedule (w.dcomb, w.dHm1, w.dHm2 hold the pooled gradients) ----
+int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* Gr, const int32_t* rg_offsets, const Desc& bd,
+                     int B, int T, int Nk, const Ws& w, const DropCfg& drop, hipStream_t st);
 
 // ---- node-level backward of the bf16 schedule (w.dcomb, w.dHm1, w.dHm2 hold the pooled gradients) ----
 int backward_nodes16(const camo_dims_t& d, const float* const* P, float* const* Gr, const int32_t* rg_offsets,
@@ -580,6 +616,47 @@ int backward_nodes16(const camo_dims_t& d, const float* const* P, float* const* 
   return 0;
 }
 
+int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* Gr, const int32_t* rg_offsets, const Desc& bd,
+                     int B, int T, int Nk, const Ws& w, const DropCfg& drop, hipStream_t st) {
+  const int H = 256, D = 128, TK = B * Nk;
+  const size_t HH = (size_t)H * H;
+  const Ws::F17& f = w.f;
+  Bwd1Args a1; std::memset(&a1, 0, sizeof(a1));
+  a1.s[0] = Bwd1Stream{f.W1T, f.Wo1T, f.mask1, f.XH16, f.rstd1, P[CAMO_P_LN1_W], w.dHm1, 2 * H, w.dcomb, 2 * H, f.dH16, f.dU16,
+                       Gr[CAMO_P_LN1_W], Gr[CAMO_P_LN1_B]};
+  a1.s[1] = Bwd1Stream{f.W2T, f.Wo2T, f.mask2, f.XH2_16, f.rstd2, P[CAMO_P_LN2_W], w.dHm2, 2 * H, w.dcomb + H, 2 * H, f.dH2_16, f.dU2_16,
+                       Gr[CAMO_P_LN2_W], Gr[CAMO_P_LN2_B]};
+  a1.Q16 = f.Q16; a1.KV16 = f.KV16; a1.dQKV16 = f.dQKV16; a1.dKV = w.dKV;
+  a1.O2_16 = f.O2_16; a1.dO2_16 = f.dO2_16; a1.delta2 = f.delta2;
+  a1.off = rg_offsets; a1.tile_off = bd.tile_off; a1.inv_nr = bd.inv_nr;
+  a1.B = B; a1.Nk = Nk; a1.rg_tiles_max = T / 32 + B; a1.qscale = 1.0f / sqrtf(32.0f); a1.drop = drop;
+  a1.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)2 * g_dbg_stamp_blocks * 8 : nullptr;
+  CK(launch_fused_bwd1(a1, g_opt_fused_variant, st), "fused backward, first half");
+  Bwd2Args a2; std::memset(&a2, 0, sizeof(a2));
+  a2.Q2_16 = f.Q2_16; a2.dO2_16 = f.dO2_16; a2.lse2 = f.lse2; a2.delta2 = f.delta2; a2.KV2_16 = f.KV2_16; a2.dQKV16 = f.dQKV16;
+  a2.dU16 = f.dU16; a2.WcRgT = f.WcRgT; a2.dR16 = f.dR16; a2.dQ2acc = w.dQ2acc; a2.dKV = w.dKV;
+  a2.dU2_16 = f.dU2_16; a2.WcKgT = f.WcKgT; a2.dQKVkg16 = f.dQKVkg16; a2.dG16 = f.dG16;
+  a2.tickets = w.tickets + B; a2.off = rg_offsets; a2.tile_off = bd.tile_off;
+  a2.B = B; a2.Nk = Nk; a2.rg_tiles_max = T / 32 + B; a2.qscale = a1.qscale; a2.drop = drop;
+  a2.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)3 * g_dbg_stamp_blocks * 8 : nullptr;
+  CK(launch_fused_bwd2(a2, g_opt_fused_variant, st), "fused backward, second half");
+  // every node-level weight gradient: dW += dy^T . x over the rows of a stream (bf16 operands the fused kernels wrote)
+  GB16 g(drop, st);
+  g.tn(f.dH16, 2 * H, f.Y16, H, Gr[CAMO_P_F1_W0], H, Gr[CAMO_P_F1_B0], 2 * H, H, T);
+  g.tn(f.dU16, H, f.O16, H, Gr[CAMO_P_A1_OUT_W], H, Gr[CAMO_P_A1_OUT_B], H, H, T);
+  g.tn(f.dQKV16, 3 * H, f.R16, H, Gr[CAMO_P_A1_IN_W], H, Gr[CAMO_P_A1_IN_B], H, H, T);
+  g.tn(f.dQKV16 + H, 3 * H, f.R16, H, Gr[CAMO_P_A2_IN_W] + HH, H, Gr[CAMO_P_A2_IN_B] + H, 2 * H, H, T);
+  g.tn(f.dR16, H, f.X16, D, Gr[CAMO_P_RG_PROJ_W], D, Gr[CAMO_P_RG_PROJ_B], H, D, T);
+  g.tn(f.dH2_16, 2 * H, f.Y2_16, H, Gr[CAMO_P_F2_W0], H, Gr[CAMO_P_F2_B0], 2 * H, H, TK);
+  g.tn(f.dU2_16, H, f.O2_16, H, Gr[CAMO_P_A2_OUT_W], H, Gr[CAMO_P_A2_OUT_B], H, H, TK);
+  g.tn(f.dQKVkg16, 3 * H, f.G16, H, Gr[CAMO_P_A2_IN_W], H, Gr[CAMO_P_A2_IN_B], H, H, TK);
+  CK(g.run(), "weight gradients (1/2)");
+  g.tn(f.dQKVkg16 + H, 3 * H, f.G16, H, Gr[CAMO_P_A1_IN_W] + HH, H, Gr[CAMO_P_A1_IN_B] + H, 2 * H, H, TK);
+  g.tn(f.dG16, H, f.KG16, D, Gr[CAMO_P_KG_PROJ_W], D, Gr[CAMO_P_KG_PROJ_B], H, D, TK);
+  CK(g.run(), "weight gradients (2/2)");
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -628,9 +705,9 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   GB gt(drop, CAMO_PREC_F32, st);   // per-sample (B-row) GEMMs
   // one clear of everything this step accumulates into with atomics (means now, dfused/dKV in backward);
   // the bf16 schedule's prep launch does it along with its casts
-  // inference calls (nothing saved for a backward, no attention maps asked for) at the reference configuration take the
-  // fused row-tile schedule
-  const bool use17 = (flags & CAMO_FWD_INFERENCE) && !attn_rg2kg && !attn_kg2rg && fused17_ok(d, P, precision, Nk, max_nr);
+  // calls at the reference configuration that do not ask for attention maps take the fused row-tile schedule
+  const bool use17 = !attn_rg2kg && !attn_kg2rg && !(flags & CAMO_FLAG_ATTN_MAPS) && fused17_ok(d, P, precision, Nk, max_nr);
+  const bool save17 = !(flags & CAMO_FWD_INFERENCE) || g_opt_fused_save != 0;
   const bool use16 = !use17 && sched16_ok(d, P, precision, T, Nk, max_nr);
   if (!use16 && !use17) CK((int)hipMemsetAsync(w.zero_base, 0, w.zero_bytes, st), "memset zero block");
 
@@ -654,7 +731,7 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   if (!P[CAMO_P_KG_PROJ_W] && Dk != H) return fail(CAMO_E_ARG, "kg_proj weight missing but kg_dim != hidden_dim");
   const size_t HH2 = (size_t)H * H;
   if (use17) {
-    if (int e = forward_nodes17(d, P, rg, rg_offsets, bd, kg, B, T, Nk, max_nr, w, drop, g_opt_fused_save != 0, st)) return e;
+    if (int e = forward_nodes17(d, P, rg, rg_offsets, bd, kg, B, T, Nk, max_nr, w, drop, save17, st)) return e;
   } else if (use16) {
     if (int e = forward_nodes16(d, P, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, w, attn_rg2kg, attn_kg2rg, drop, st)) return e;
   } else {
@@ -716,7 +793,7 @@ static int backward_impl(const camo_dims_t* dims, const float* const* params, fl
                          const int32_t* rg_offsets, const void* desc, const float* kg, int32_t B,
                          int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes, const float* outs,
                          const float* d_outs, int32_t d_outs_pre_activation, int32_t training, uint64_t seed, int32_t precision,
-                         void* stream, bool heads_out_done) {
+                         int32_t flags, void* stream, bool heads_out_done) {
   if (int e = check_dims(dims, B, T, Nk)) return e;
   if (!params || !grads || !rg || !rg_offsets || !desc || !kg || !workspace || !outs || (!d_outs && !heads_out_done))
     return fail(CAMO_E_ARG, "null pointer argument");
@@ -766,6 +843,8 @@ static int backward_impl(const camo_dims_t* dims, const float* const* params, fl
   gt.tn(w.dcomb, 2 * H, w.H1mean, 2 * H, Gr[CAMO_P_F1_W3], 2 * H, Gr[CAMO_P_F1_B3], H, 2 * H, B);
   gt.tn(w.dcomb + H, 2 * H, w.H2mean, 2 * H, Gr[CAMO_P_F2_W3], 2 * H, Gr[CAMO_P_F2_B3], H, 2 * H, B);
   CK(gt.run(), "ffn layer 3 bwd (pooled)");
+  if (!(flags & CAMO_FLAG_ATTN_MAPS) && fused17_ok(d, P, precision, Nk, max_nr))
+    return backward_nodes17(d, P, Gr, rg_offsets, bd, B, T, Nk, w, drop, st);
   if (sched16_ok(d, P, precision, T, Nk, max_nr))
     return backward_nodes16(d, P, Gr, rg_offsets, row_sample, inv_nr, B, T, Nk, max_nr, w, drop, st);
   {
@@ -814,9 +893,9 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
                   const int32_t* rg_offsets, const void* batch_desc, const float* kg, int32_t B,
                   int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes, const float* outs,
                   const float* d_outs, int32_t d_outs_pre_activation, int32_t training, uint64_t seed, int32_t precision,
-                  void* stream) {
+                  int32_t flags, void* stream) {
   return backward_impl(dims, params, grads, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
-                       d_outs, d_outs_pre_activation, training, seed, precision, stream, false);
+                       d_outs, d_outs_pre_activation, training, seed, precision, flags, stream, false);
 }
 
 int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
@@ -832,7 +911,7 @@ int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* para
     if (int rc = forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
                               nullptr, nullptr, training, seed, precision, 0, stream, &fl)) return rc;
     return backward_impl(dims, params, grads, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes,
-                         outs, nullptr, 1, training, seed, precision, stream, true);
+                         outs, nullptr, 1, training, seed, precision, 0, stream, true);
   }
   // large batches / many classes: the three steps as separate launches, d(loss)/d(pre-activation) staged in the workspace
   if (int rc = forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
@@ -841,7 +920,7 @@ int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* para
   CK(launch_loss(outs, reinterpret_cast<const long long*>(y), e, s, B, dims->num_classes, loss_terms, nullptr, w.dlog, pred,
                  static_cast<hipStream_t>(stream)), "loss");
   return backward_impl(dims, params, grads, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes,
-                       outs, w.dlog, 1, training, seed, precision, stream, false);
+                       outs, w.dlog, 1, training, seed, precision, 0, stream, false);
 }
 
 int camo_loss(const float* outs, const int64_t* y, const float* e, const float* s, int32_t B, int32_t num_classes,
@@ -929,7 +1008,9 @@ int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int3
       {"R16", w.f.R16}, {"G16", w.f.G16}, {"Q16", w.f.Q16}, {"Q2_16", w.f.Q2_16}, {"KV16", w.f.KV16}, {"KV2_16", w.f.KV2_16},
       {"O16", w.f.O16}, {"O2_16", w.f.O2_16}, {"Y16", w.f.Y16}, {"Y2_16", w.f.Y2_16}, {"XH16", w.f.XH16}, {"XH2_16", w.f.XH2_16},
       {"rstd1", w.f.rstd1}, {"rstd2", w.f.rstd2}, {"mask1", w.f.mask1}, {"mask2", w.f.mask2}, {"lse2", w.f.lse2}, {"X16", w.f.X16},
-      {"Wqkv_rg", w.f.Wqkv_rg}, {"W1s", w.f.W1}, {"Ymean", w.Ymean}, {"H1mean", w.H1mean}, {"Y2mean", w.Y2mean}, {"H2mean", w.H2mean},
+      {"Wqkv_rg", w.f.Wqkv_rg}, {"W1s", w.f.W1}, {"W1T", w.f.W1T}, {"WcRgT", w.f.WcRgT}, {"dH16", w.f.dH16}, {"dH2_16", w.f.dH2_16},
+      {"dU16", w.f.dU16}, {"dU2_16", w.f.dU2_16}, {"dQKV16", w.f.dQKV16}, {"dQKVkg16", w.f.dQKVkg16}, {"dR16", w.f.dR16}, {"dG16", w.f.dG16},
+      {"dO2_16", w.f.dO2_16}, {"delta2", w.f.delta2}, {"dKV", w.dKV}, {"dQ2acc", w.dQ2acc}, {"Ymean", w.Ymean}, {"H1mean", w.H1mean}, {"Y2mean", w.Y2mean}, {"H2mean", w.H2mean},
       {"R", w.R}, {"G", w.G}, {"Q", w.Q}, {"KV2", w.KV2}, {"KV", w.KV}, {"Q2", w.Q2}, {"P", w.P}, {"P2", w.P2},
       {"O", w.O}, {"O2", w.O2}, {"U", w.U}, {"U2", w.U2}, {"Y", w.Y}, {"Y2", w.Y2}, {"H1", w.H1}, {"H2", w.H2},
       {"comb", w.comb}, {"fused", w.fused}};

@@ -16,7 +16,7 @@
 #include "common.h"
 #include "gemm.h"   // GF_* flags
 
-#define GEMM16_MAXP 8
+#define GEMM16_MAXP 12
 
 struct Gemm16Prob {
   const unsigned short* A; const unsigned short* B;   // bf16 bit patterns

@@ -247,7 +247,8 @@ class FusionEngine:
         _lib.check(rc, "camo_forward")
         return outs, ((a1, a2) if a1 is not None else None)
 
-    def backward_raw(self, batch, ws, outs, d_outs, training, seed, gtab, pre_activation=False):
+    def backward_raw(self, batch, ws, outs, d_outs, training, seed, gtab, pre_activation=False, had_attention=False):
+        """``had_attention``: the forward_raw call that filled ``ws`` was asked for attention maps."""
         mod = self.module()
         self._same_device(d_outs, "d_outs")
         with _on(self.device):
@@ -255,7 +256,7 @@ class FusionEngine:
                                           _ptr(batch.desc), _ptr(batch.kg), batch.B, batch.T,
                                           batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs), _ptr(d_outs),
                                           int(bool(pre_activation)), int(bool(training)), seed, _PREC[mod.precision],
-                                          _stream_ptr(self.device))
+                                          _lib.FLAG_ATTN_MAPS if had_attention else 0, _stream_ptr(self.device))
         _lib.check(rc, "camo_backward")
 
     def train_raw(self, batch, ws, mask_label, edge_label, score_label, training, seed, gtab):
@@ -301,7 +302,7 @@ class _FusionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, batch, ws, training, seed, want_attention, *params):
         outs, attn = eng.forward_raw(batch, ws, training, seed, want_attention)
-        ctx.eng, ctx.batch, ctx.ws, ctx.training, ctx.seed = eng, batch, ws, training, seed
+        ctx.eng, ctx.batch, ctx.ws, ctx.training, ctx.seed, ctx.had_attention = eng, batch, ws, training, seed, bool(want_attention)
         ctx.save_for_backward(outs)
         ctx.n_params = len(params)
         if attn is not None:
@@ -315,7 +316,7 @@ class _FusionFn(torch.autograd.Function):
         (outs,) = ctx.saved_tensors
         g = torch.zeros_like(eng.flat_params)
         eng.backward_raw(ctx.batch, ctx.ws, outs, d_outs.contiguous().to(torch.float32), ctx.training, ctx.seed,
-                         eng._grad_table(g))
+                         eng._grad_table(g), had_attention=ctx.had_attention)
         ctx.ws = None
         grads = [g[o:o + n].view(shape) for _, _, o, n, shape in eng._layout]
         return (None, None, None, None, None, None, *grads)

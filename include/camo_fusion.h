@@ -110,6 +110,7 @@ size_t camo_workspace_bytes(const camo_dims_t* dims, int32_t B, int32_t T, int32
  *               prediction): nothing is saved for it and the workspace contents are undefined afterwards.
  */
 #define CAMO_FWD_INFERENCE 1
+#define CAMO_FLAG_ATTN_MAPS 2   /* camo_backward only: the forward call of this workspace was given attention-map pointers */
 size_t camo_batch_desc_bytes(int32_t B, int32_t T);
 int camo_prepare_batch(const int32_t* rg_offsets, int32_t B, int32_t T, int32_t max_nr,
                        void* batch_desc, size_t batch_desc_bytes, void* stream);
@@ -129,13 +130,14 @@ int camo_forward(const camo_dims_t* dims, const float* const* params,
  * none is produced.  Arguments as camo_forward; `workspace` is the one that
  * call filled.  d_outs is d(loss)/d(outs); with d_outs_pre_activation = 1 its last
  * column is instead taken w.r.t. the score head's pre-sigmoid value (what camo_loss's
- * d_pre output holds), which saves the conversion pass. */
+ * d_pre output holds), which saves the conversion pass.  flags: CAMO_FLAG_ATTN_MAPS when the forward call
+ * that filled the workspace returned attention maps (it then ran a schedule that materialises them). */
 int camo_backward(const camo_dims_t* dims, const float* const* params, float* const* grads,
                   const float* rg, const int32_t* rg_offsets, const void* batch_desc,
                   const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr,
                   void* workspace, size_t workspace_bytes,
                   const float* outs, const float* d_outs, int32_t d_outs_pre_activation,
-                  int32_t training, uint64_t seed, int32_t precision, void* stream);
+                  int32_t training, uint64_t seed, int32_t precision, int32_t flags, void* stream);
 
 /* ---- loss ----------------------------------------------------------------
  * Per-sample loss of train_multimodal.py:256-268 --

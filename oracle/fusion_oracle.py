@@ -250,8 +250,9 @@ class FusionOracle:
             dfused = dfused + dh @ P[f"{hn}.0.weight"]
         return dfused
 
-    def backward_sample(self, ca, d, g):
-        """Accumulate this sample's parameter gradients into dict ``g``."""
+    def backward_sample(self, ca, d, g, dbg=None):
+        """Accumulate this sample's parameter gradients into dict ``g``.  ``dbg``: optional dict that receives the
+        intermediate activation gradients (tests compare the fused backward kernels with them stage by stage)."""
         P, c = self.p, self.cfg
         dfused = self._heads_bwd(ca, d, g)
         if ca.get("late"):
@@ -288,6 +289,8 @@ class FusionOracle:
             if m_ is not None:
                 dH = dH * m_
             dH = dH * (H_ > 0)
+            if dbg is not None:
+                dbg["dH_" + pre] = dH
             _acc(g, f"fusion.{pre}.0.weight", dH.T @ Y_); _acc(g, f"fusion.{pre}.0.bias", dH.sum(0))
             dY = dZ_ + dH @ P[f"fusion.{pre}.0.weight"]
             dU, dgam, dbet = _layernorm_bwd(dY, xh_, rstd_, P[f"fusion.{ln}.weight"])
@@ -327,6 +330,9 @@ class FusionOracle:
         gW2 = np.concatenate([dQ2.T @ ca["G"], dK2.T @ ca["R"], dV2.T @ ca["R"]], axis=0)
         _acc(g, f"{a}.in_proj_weight", gW2); _acc(g, f"{a}.in_proj_bias", np.concatenate([dQ2.sum(0), dK2.sum(0), dV2.sum(0)]))
         dG += dQ2 @ Wi2[:H]; dR += dK2 @ Wi2[H:2 * H] + dV2 @ Wi2[2 * H:]
+        if dbg is not None:
+            dbg.update(dU=dU, dU2=dU2, dO=dO.reshape(Nr, H), dO2=dO2.reshape(Nk, H), dQ=dQ, dKk=dKk, dVk=dVk, dQ2=dQ2, dK2=dK2, dV2=dV2,
+                       dR=dR, dG=dG)
         # --- input projections
         if "fusion.rg_proj.weight" in P:
             _acc(g, "fusion.rg_proj.weight", dR.T @ ca["rg"]); _acc(g, "fusion.rg_proj.bias", dR.sum(0))
@@ -453,20 +459,22 @@ def cosine_warm_restarts_lr(base_lr, epoch, T_0=10, T_mult=2, eta_min=0.0):
     return eta_min + (base_lr - eta_min) * (1 + np.cos(np.pi * t / Ti)) / 2
 
 
-def train_step(oracle, opt, rg_list, kg, y, e, s, training=True, seed=0, lr=None, max_norm=1.0):
+def train_step(oracle, opt, rg_list, kg, y, e, s, training=True, seed=0, lr=None, max_norm=1.0, debug=False):
     """One optimizer step over a minibatch with the reference's semantics
     (train_multimodal.py:238-279): per-sample forward/backward, gradients
     SUMMED over the minibatch, one clip, one AdamW step.
     Returns dict(loss_terms [B,4], losses [B], grad_norm, grads (clipped), outs)."""
     outs, caches = oracle.forward_list(rg_list, kg, training=training, seed=seed)
     g = oracle.zero_grads()
-    losses, terms = [], []
+    losses, terms, dbgs = [], [], []
     for b, ca in enumerate(caches):
         ob = {k: outs[k][b] for k in ("mask", "instance", "edge", "score")}
         l, t, d = sample_loss(ob, int(y[b]), float(e[b]), float(s[b]))
-        oracle.backward_sample(ca, d, g)
-        losses.append(l); terms.append(t)
+        dbg = {} if debug else None
+        oracle.backward_sample(ca, d, g, dbg)
+        losses.append(l); terms.append(t); dbgs.append(dbg)
     raw = {k: v.copy() for k, v in g.items()}
     norm = clip_grad_norm(g, max_norm)
     opt.step(oracle.p, g, lr=lr)
-    return dict(losses=np.array(losses, f32), loss_terms=np.stack(terms), grad_norm=norm, grads=g, raw_grads=raw, outs=outs)
+    return dict(losses=np.array(losses, f32), loss_terms=np.stack(terms), grad_norm=norm, grads=g, raw_grads=raw, outs=outs,
+                caches=caches, dbg=dbgs)

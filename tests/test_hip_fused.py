@@ -146,3 +146,60 @@ def test_fused_forward_shapes(nrs, nk, fused_opts):
     got = np.concatenate([t2n(v) for v in o], axis=1)
     assert np.isfinite(got).all()
     assert_close(got, outs6(ref), 1e-3, 0, f"nrs={nrs[:4]} nk={nk}")
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_fused_backward_stage_by_stage(training, kg_real, fused_opts):
+    """The fused backward kernels against the oracle's intermediate activation gradients, then every parameter gradient."""
+    cfg = OP.full_cfg()
+    prm = OP.make_params(cfg, 0)
+    m = make_model(cfg, 0, "bf16")
+    m.train(training)
+    eng = m._engine
+    B, T, Nk, H = len(NRS), sum(NRS), 13, 256
+    rg = [OP.make_rg(n, 128, seed=70 + i) for i, n in enumerate(NRS)]
+    kg = np.stack([kg_real * (1.0 + 0.05 * i) for i in range(B)]).astype(np.float32)
+    y, e, s = OP.make_labels(B, seed=5)
+    batch = eng.make_batch(torch.from_numpy(np.concatenate(rg)).cuda(), NRS, torch.from_numpy(kg).cuda())
+    seed = 0x1234ABCD5678
+    ws = eng.workspace(batch, private=True)
+    ws.zero_()
+    g = eng.ensure_flat_grads(attach=True)
+    g.zero_()
+    outs, terms, pred = eng.train_raw(batch, ws, torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s), training, seed, eng._gtab)
+    torch.cuda.synchronize()
+    orc = FO.FusionOracle(cfg, prm)
+    ref = FO.train_step(orc, FO.AdamW(orc.p), rg, kg, y, e, s, training=training, seed=seed, debug=True)
+    assert_close(t2n(terms), ref["loss_terms"], 2e-3, 2e-3, "loss terms")
+    dbg, caches = ref["dbg"], ref["caches"]
+    cat = lambda k: np.concatenate([d[k] for d in dbg])
+    sc = np.float32(1.0 / np.sqrt(32.0))
+    close_rel(ws_bf16(eng, batch, ws, "dH16", T, 2 * H), cat("dH_ffn_rg"), 3e-2, "dH (RG)", 1e-3)
+    close_rel(ws_bf16(eng, batch, ws, "dH2_16", B * Nk, 2 * H), cat("dH_ffn_kg"), 3e-2, "dH (KG)", 2e-3)
+    close_rel(ws_bf16(eng, batch, ws, "dU16", T, H), cat("dU"), 3e-2, "dU", 3e-3)
+    close_rel(ws_bf16(eng, batch, ws, "dU2_16", B * Nk, H), cat("dU2"), 3e-2, "dU2", 4e-3)
+    close_rel(ws_bf16(eng, batch, ws, "dO2_16", B * Nk, H), cat("dO2"), 3e-2, "dO2", 4e-3)
+    d2 = ws_f32(eng, batch, ws, "delta2", B * 8 * 16).reshape(B, 8, 16)
+    want_d2 = np.stack([(d["dO2"].reshape(Nk, 8, 32) * c["O2"].reshape(Nk, 8, 32)).sum(-1).T for d, c in zip(dbg, caches)])   # [B][8][Nk]
+    close_rel(d2[:, :, :Nk], want_d2, 4e-2, "delta2 = dO2 . O2")
+    dqkv = ws_bf16(eng, batch, ws, "dQKV16", T, 3 * H)
+    close_rel(dqkv[:, :H], cat("dQ"), 4e-2, "dQ", 4e-3)
+    close_rel(dqkv[:, H:2 * H], cat("dK2"), 4e-2, "dK2", 4e-3)
+    close_rel(dqkv[:, 2 * H:], cat("dV2"), 4e-2, "dV2", 4e-3)
+    close_rel(ws_f32(eng, batch, ws, "dKV", B * Nk * 2 * H).reshape(B * Nk, 2 * H), np.concatenate([cat("dKk"), cat("dVk")], axis=1), 3e-2, "dK | dV sums", 4e-3)
+    close_rel(ws_f32(eng, batch, ws, "dQ2acc", B * Nk * H).reshape(B * Nk, H), cat("dQ2"), 4e-2, "dQ2 sums", 4e-3)
+    close_rel(ws_bf16(eng, batch, ws, "dQKVkg16", B * Nk, 3 * H), np.concatenate([cat("dQ2"), cat("dKk"), cat("dVk")], axis=1), 4e-2, "dQKV (KG rows)", 4e-3)
+    close_rel(ws_bf16(eng, batch, ws, "dR16", T, H), cat("dR"), 4e-2, "dR", 4e-3)
+    close_rel(ws_bf16(eng, batch, ws, "dG16", B * Nk, H), cat("dG"), 4e-2, "dG", 5e-3)
+    num = den = 0.0
+    rels = []
+    for k, p in m.named_parameters():
+        want = ref["raw_grads"][k].astype(np.float64); got = t2n(p.grad).astype(np.float64)
+        num += ((got - want) ** 2).sum(); den += (want ** 2).sum()
+        rels.append((np.sqrt(((got - want) ** 2).sum()) / max(np.sqrt((want ** 2).sum()), 1e-30), np.sqrt((want ** 2).sum()), k))
+    rels.sort(reverse=True)
+    total = np.sqrt(num / den)
+    print("fused backward: global relative gradient error", total, "worst", [(f"{r:.3f}", f"{n:.2e}", k) for r, n, k in rels[:6]])
+    assert total < 5e-2
+    gn = np.sqrt(den)
+    assert all(r < 0.12 for r, n, _ in rels if n > 1e-3 * gn), rels[:6]

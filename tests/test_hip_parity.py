@@ -305,15 +305,20 @@ def test_product_path_loaded_native_library():
 
 
 def _set_sched16(value):
-    """-1: schedule chosen from the configuration (default); 0: general schedule forced (testing hook of the C ABI)."""
+    """-1: the bf16-resident schedule of round 1 where the configuration allows it; 0: general schedule forced.  Both legs
+    switch the fused row-tile schedule (the default at the reference configuration) off: these tests are about the two
+    grouped-GEMM schedules it falls back to."""
     from camouflage_multimodal_amd import _lib
+    _lib.check(_lib.lib().camo_debug_set_option(b"fused", 0), "camo_debug_set_option")
     _lib.check(_lib.lib().camo_debug_set_option(b"sched16", value), "camo_debug_set_option")
 
 
 @pytest.fixture
 def sched_switch():
     yield _set_sched16
-    _set_sched16(-1)
+    from camouflage_multimodal_amd import _lib
+    _lib.check(_lib.lib().camo_debug_set_option(b"fused", -1), "camo_debug_set_option")
+    _lib.check(_lib.lib().camo_debug_set_option(b"sched16", -1), "camo_debug_set_option")
 
 
 def _ws_get(eng, batch, ws, name, shape):
