@@ -20,22 +20,35 @@ NB = 8192
 _lib.lib().camo_debug_set_option(b"fused_variant", variant)
 nkg = B * ((max(nrs) + 63) // 64)
 buf = torch.zeros(2 * NB * 8, dtype=torch.int64, device="cuda")
+train = len(sys.argv) > 3 and sys.argv[3] == "train"
+buf = torch.zeros(4 * NB * 8, dtype=torch.int64, device="cuda")
+if train:
+    model.train()
+    y, e, s_ = (torch.from_numpy(x).cuda() for x in make_batches(1, B, 0)[0][3:])
+    step = lambda: tr.step(rg, nrs, kg, y, e, s_)
+else:
+    step = lambda: tr.evaluate(rg, nrs, kg)
 for i in range(5):
-    tr.evaluate(rg, nrs, kg)
+    step()
 _lib.lib().camo_debug_set_stamps(buf.data_ptr(), NB)
-tr.evaluate(rg, nrs, kg)
+step()
 torch.cuda.synchronize()
 _lib.lib().camo_debug_set_stamps(None, 0)
-st = buf.cpu().numpy().reshape(2, NB, 8)
-for k, name in enumerate(("front", "back")):
+st = buf.cpu().numpy().reshape(4, NB, 8)
+for k, name in enumerate(("front", "back", "bwd1", "bwd2") if train else ("front", "back")):
     s = st[k]
-    act = s[:, 0] > 0
+    act = (s[:, 0] > 0) & (s[:, 3] > 0)          # (blocks that return early leave later stamps empty)
     s = s[act].astype(np.float64)
     t0 = s[:, 0].min()
     print(f"--- {name} (variant {variant}): {act.sum()} blocks, kernel span {(s[:, 3].max() - t0) / 100:.2f} us; first block starts at 0, last starts at {(s[:, 0].max() - t0) / 100:.2f} us")
     ph = np.diff(s[:, :4], axis=1) / 100.0
     idx = np.nonzero(act)[0]
-    groups = [("KG splits", idx < nkg), ("RG tiles", idx >= nkg)] if name == "back" else [("all tiles", idx >= 0)]
+    if name == "back":
+        groups = [("KG splits", idx < nkg), ("RG tiles", idx >= nkg)]
+    elif name == "bwd1":
+        groups = [("KG blocks", idx < B), ("RG tiles", idx >= B)]
+    else:
+        groups = [("all tiles", idx >= 0)]
     for gname, sel in groups:
         if sel.any():
             print(f"  {gname:10s} n={sel.sum():4d}  phase durations us (median / max): " +
