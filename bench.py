@@ -14,10 +14,10 @@ reference has no RGB+D image encoder; one "image" is one sample = (RG node embed
 Nr drawn from the real 303..530 histogram, 13 KG category embeddings [13,128]); batch 16 per GPU,
 bf16 MFMA operands with fp32 accumulation/activations.  Weak scaling: 16 samples per GPU.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the grouped MFMA GEMM --
-gemm16_kernel on bf16-resident operands in bf16 mode, gemm_grouped_kernel in f32 mode; >= 98 % of the
-FLOPs) with HIP events recorded on its launch stream during the timed steps;
-`cpu_baseline` times the CPU oracle (a numpy port of the reference path) on the same workload.
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant node-level kernel (in bf16 mode one of the fused row-tile
+kernels of csrc/fused_rows.hip; in f32 mode the grouped MFMA GEMM) with HIP events recorded on its launch stream, and lists
+every kernel family of the step under `roofline.kernels`; `forward`, `sweep` and `f32` are the inference rate, the batch
+sweep and the exact-f32 step; `cpu_baseline` times the CPU restatements of the reference path on the same workload.
 """
 import argparse
 import ctypes as C
@@ -219,45 +219,58 @@ def main():
     if rank == 0 and not args.no_kernel_timing:
         ms, n, fl = C.c_double(), C.c_int32(), C.c_double()
         _lib.check(L.camo_prof_end(C.byref(ms), C.byref(n), C.byref(fl)), "camo_prof_end")
-        alg = sum(algorithmic_flops(batches[i % len(batches)][1]) for i in range(args.warmup, args.warmup + k))
         # An event pair also times its own marker packets: an EMPTY pair on the same stream is reported next to the
-        # figure (not subtracted: it over-corrects -- rocprofv3's kernel-only average, profiles/, sits in between).
+        # figures (not subtracted: it over-corrects -- rocprofv3's kernel-only averages, profiles/, sit in between).
         pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
         for a_, b_ in pairs:
             a_.record(); b_.record()
         torch.cuda.synchronize()
         ev_us = sorted(a_.elapsed_time(b_) * 1e3 for a_, b_ in pairs)[len(pairs) // 2]
-        gemm_s = ms.value * 1e-3
-        achieved = alg / gemm_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
-        # HBM bytes of the same kernel from the PMC passes (profiles/summarize_pmc.py), per launch
-        traffic, tnote = None, None
-        kname = "gemm16_kernel" if args.precision == "bf16" else "gemm_grouped_kernel"
-        pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        pm = None
-        if os.path.exists(pj):
-            with open(pj) as f:
-                pm = json.load(f)
-        if pm is not None and pm.get("kernel") == kname:
-            traffic = round(pm["hbm_bytes_per_launch"])
-            tnote = {"hbm_bytes_per_step": round(pm["hbm_bytes_per_step"]), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                     "separate passes of this bench (profiles/pmc_traffic.json): " + pm["correction"]}
+        names = ["grouped GEMM (gemm16_kernel / gemm_grouped_kernel: weight gradients in the fused schedule)", "front_kernel (fused forward: projection + in-projections)",
+                 "back_kernel (fused forward: attention + out-projection + LayerNorm + FFN)", "bwd1_kernel (fused backward, first half)",
+                 "bwd2_kernel (fused backward, second half)", "per-sample tail (gemm_skinny_kernel, heads_loss_kernel)",
+                 "optimizer (sumsq_kernel, clip_adamw_kernel)", "shadow_kernel (bf16 weight shadows + clears)", "attention kernels (unfused schedules)", "other"]
+        table = []
+        for kind, nm in enumerate(names):
+            kms, kn, kfl = C.c_double(), C.c_int32(), C.c_double()
+            _lib.check(L.camo_prof_kind(kind, C.byref(kms), C.byref(kn), C.byref(kfl)), "camo_prof_kind")
+            if kn.value:
+                table.append({"kind": kind, "kernel": nm, "launches_per_step": round(kn.value / k, 2), "us_per_launch": round(kms.value * 1e3 / kn.value, 2),
+                              "us_per_step": round(kms.value * 1e3 / k, 2), "executed_gflop_per_step": round(kfl.value / k / 1e9, 3),
+                              "executed_tflops": round(kfl.value / max(kms.value, 1e-9) / 1e9, 1) if kfl.value else None})
         whole = alg_step / (elapsed / args.steps) / 1e12
-        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_note": tnote,
-                "kernel": kname + ("<bf16-resident operands>" if args.precision == "bf16" else "<f32>"),
-                "launches_per_step": round(n.value / k, 1),
-                "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
-                "empty_event_pair_us": round(ev_us, 2),
-                "kernel_ms_per_step": round(ms.value / k, 4),
-                "algorithmic_gflop_per_step": round(alg / k / 1e9, 3),
-                "executed_gflop_per_step": round(fl.value / k / 1e9, 3),
-                "share_of_step_time": round(gemm_s / t_prof, 3),
-                "whole_step": {"achieved": round(whole, 2), "unit": "TFLOP/s", "frac": round(whole / peak, 5),
-                               "note": "algorithmic fwd+bwd FLOPs of one step / measured step time (all launches, optimizer included)"}}
-        if traffic:      # the same launches seen from the other roof: measured HBM bytes / launch time vs 8 TB/s
-            gbps = traffic / (ms.value * 1e-3 / max(n.value, 1)) / 1e9
-            roof["hbm_view"] = {"achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
+        # dominant kernel = the node-level kernel with the most time per step; its ALGORITHMIC FLOPs per launch from SURVEY 8(d)'s
+        # per-row figures: front 458 752 (128->256, 256->768), back 681 984 (both attention directions 2 x 13 312, out-projection
+        # 131 072, FFN 2 x 262 144 -- the pooled second layer's work is credited to the kernel that makes it unnecessary);
+        # backward kernels and the weight-gradient GEMM: their executed FLOPs (= algorithmic: nothing is skipped there)
+        rows = float(np.mean([sum(b[1]) for b in host])); kgrows = args.batch * 13.0
+        alg_per_launch = {1: (rows + kgrows) * 458752.0, 2: (rows + kgrows) * 681984.0}
+        node = [t for t in table if t["kind"] in (0, 1, 2, 3, 4)]
+        dom = max(node, key=lambda t: t["us_per_step"]) if node else None
+        if dom is not None:
+            dfl = alg_per_launch.get(dom["kind"], dom["executed_gflop_per_step"] * 1e9 / max(dom["launches_per_step"], 1e-9))
+            achieved = dfl / (dom["us_per_launch"] * 1e-6) / 1e12
+            roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
+                    "traffic": None, "kernel": dom["kernel"], "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["us_per_launch"],
+                    "algorithmic_gflop_per_launch": round(dfl / 1e9, 3), "empty_event_pair_us": round(ev_us, 2),
+                    "note": "achieved = algorithmic FLOPs of one launch / its HIP-event duration on the launch stream; at B = 16 a launch is one "
+                            "32-row tile per CU, bound by streaming each layer's weights from L2 (DESIGN.md 6), not by the MFMA pipe"}
+            pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pj):
+                with open(pj) as f:
+                    pm = json.load(f)
+                ent = pm.get("kernels", {}).get(dom["kernel"].split(" ")[0])
+                if ent:
+                    roof["traffic"] = round(ent["hbm_bytes_per_launch"])
+                    roof["traffic_note"] = pm.get("correction")
+                    gbps = ent["hbm_bytes_per_launch"] / (dom["us_per_launch"] * 1e-6) / 1e9
+                    roof["hbm_view"] = {"achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
+            roof["whole_step"] = {"achieved": round(whole, 2), "unit": "TFLOP/s", "frac": round(whole / peak, 5),
+                                  "algorithmic_gflop_per_step": round(alg_step / 1e9, 3), "launches_per_step": round(n.value / k, 1),
+                                  "event_timed_ms_per_step": round(ms.value / k, 4),
+                                  "note": "algorithmic fwd+bwd FLOPs of one step / measured step time (all launches, optimizer included)"}
+            roof["kernels"] = table
     if world > 1:
         dist.barrier()
 

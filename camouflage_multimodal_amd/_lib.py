@@ -23,7 +23,7 @@ NPARAMS_CROSS, NPARAMS_LATE = 44, 22
 # every symbol include/camo_fusion.h declares
 SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_batch_desc_bytes", "camo_prepare_batch", "camo_forward", "camo_backward", "camo_forward_loss_backward",
            "camo_loss", "camo_grad_sumsq", "camo_clip_adamw", "camo_debug_gemm", "camo_debug_gemm16", "camo_debug_ws_offset",
-           "camo_debug_set_option", "camo_debug_set_stamps", "camo_prof_begin", "camo_prof_end")
+           "camo_debug_set_option", "camo_debug_set_stamps", "camo_prof_begin", "camo_prof_end", "camo_prof_kind")
 
 
 # every symbol include/camo_rg_gnn.h declares
@@ -100,6 +100,8 @@ def lib():
     L.camo_prof_begin.argtypes = [i32]
     L.camo_prof_end.restype = C.c_int
     L.camo_prof_end.argtypes = [C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(C.c_double)]
+    L.camo_prof_kind.restype = C.c_int
+    L.camo_prof_kind.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(C.c_double)]
     v = L.camo_abi_version()
     if v != ABI_VERSION:
         raise CamoError(f"libcamo_fusion.so has ABI version {v}, this package expects {ABI_VERSION}: rebuild it")

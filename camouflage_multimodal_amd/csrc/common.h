@@ -34,12 +34,13 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
 }
 
 // keep-multiplier (0 or 1/(1-p)) of element `idx` at `site`.  Same arithmetic as
-// oracle/fusion_oracle.py::dropout_keep, so masks agree element for element.
+// oracle/fusion_oracle.py::dropout_keep, so masks agree element for element.  One murmur3 finaliser over the
+// element counter offset by a per-(site, seed) constant and whitened with the seed's high word: two 32-bit
+// multiplies per element (v_mul_lo_u32 is quarter rate on gfx950; the two-round version of round 1 cost ~150
+// cycles per element and showed up as microseconds in every epilogue that draws a mask).
 __device__ __forceinline__ float drop_mult(const DropCfg& d, uint32_t site, uint32_t idx) {
-  uint32_t x = idx * 0x9E3779B1u + site * 0x85EBCA77u + d.seed_lo;
-  x = fmix32(x);
-  x = fmix32(x ^ d.seed_hi);
-  float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+  const uint32_t x = fmix32((idx + (site * 0x85EBCA77u + d.seed_lo)) ^ d.seed_hi);
+  const float u = (float)(x >> 8) * (1.0f / 16777216.0f);
   return u >= d.p ? d.scale : 0.0f;
 }
 

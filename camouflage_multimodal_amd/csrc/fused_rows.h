@@ -52,7 +52,7 @@ struct BackArgs {
   float* part; int* tickets; int max_splits;   // KG->RG attention runs as ceil(Nr / 64) split blocks per sample (max_splits = the
                                                // largest count: grid sizing): partials [rg_tiles_max][8][FUSED_PART_FLOATS] indexed by
                                                // the split's first 32-row tile, and one ZEROED arrival counter per sample
-  int B, Nk, rg_tiles_max;
+  int B, Nk, rg_tiles_max, rows_rg;             // rows_rg = T (launch-timing bookkeeping only)
   DropCfg drop; int save;
   unsigned long long* stamps;                  // developer timeline (null in product calls)
 };
@@ -73,7 +73,7 @@ struct Bwd1Args {
   us16* dQKV16; float* dKV;                    // out: dQ into columns 0..255 of [T][768]; dK|dV [B*Nk][512] += (atomics, zeroed by the caller)
   const us16* O2_16; us16* dO2_16; float* delta2;   // KG: attention output in, its gradient out [B*Nk][256], row-dots out [B][8][16]
   const int* off; const int* tile_off; const float* inv_nr;
-  int B, Nk, rg_tiles_max; float qscale; DropCfg drop; unsigned long long* stamps;
+  int B, Nk, rg_tiles_max, rows_rg; float qscale; DropCfg drop; unsigned long long* stamps;
 };
 int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream);
 size_t fused_bwd1_lds();
@@ -90,7 +90,7 @@ struct Bwd2Args {
   const us16* dU2_16; const us16* WcKgT; us16* dQKVkg16; us16* dG16;              // KG rows: [B*Nk][768] out (weight-gradient operand), [B*Nk][256] out
   int* tickets;                                // [B] zeroed arrival counters (one per sample)
   const int* off; const int* tile_off;
-  int B, Nk, rg_tiles_max; float qscale; DropCfg drop; unsigned long long* stamps;
+  int B, Nk, rg_tiles_max, rows_rg; float qscale; DropCfg drop; unsigned long long* stamps;
 };
 int launch_fused_bwd2(Bwd2Args& a, int variant, hipStream_t stream);
 size_t fused_bwd2_lds();

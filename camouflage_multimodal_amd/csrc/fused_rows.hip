@@ -15,6 +15,7 @@
 // the next MFMA's operand").  Stages whose epilogue reduces over ROWS (the pooled FFN activation) swap the operands:
 // lane = feature, registers = rows.
 #include "fused_rows.h"
+#include "gemm.h"      // launch timing hooks (gemm_prof_open / close)
 
 namespace {
 
@@ -1096,7 +1097,9 @@ int launch_weight_shadows(ShadowBatch& sb, hipStream_t stream) {
   int blocks = (total + 255) / 256;
   if (sb.nzero && blocks < 64) blocks = 64;
   if (blocks == 0) return 0;
+  const int prof = gemm_prof_open(stream, 0.0, PROF_SHADOW);
   hipLaunchKernelGGL(shadow_kernel, dim3(blocks), dim3(256), 0, stream, sb, total);
+  gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
 
@@ -1118,9 +1121,12 @@ int launch_fused_front(FrontArgs& a, int variant, hipStream_t stream) {
     return true;
   }();
   (void)attr;
+  // executed FLOPs: per row 128 -> 256 and 256 -> 768
+  const int prof = gemm_prof_open(stream, 2.0 * ((double)a.s[0].M + a.s[1].M) * (128.0 * 256.0 + 256.0 * 768.0), PROF_FRONT);
   if (variant == 0)      hipLaunchKernelGGL((front_kernel<12, false>), dim3(total), dim3(256), F_LDS, stream, a);
   else if (variant == 2) hipLaunchKernelGGL((front_kernel<16, true>), dim3(total), dim3(256), F_LDS, stream, a);
   else                   hipLaunchKernelGGL((front_kernel<12, true>), dim3(total), dim3(256), F_LDS, stream, a);
+  gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
 
@@ -1142,9 +1148,13 @@ int launch_fused_back(BackArgs& a, int variant, hipStream_t stream) {
   }();
   (void)attr;
   const dim3 grid(a.B * a.max_splits + a.rg_tiles_max);
+  // executed FLOPs per row: out-projection 256 -> 256, FFN layer 0 256 -> 512, both attention directions (2 x 2 x Nk x 256)
+  const double rows = (double)a.rows_rg + (double)a.B * a.Nk;
+  const int prof = gemm_prof_open(stream, 2.0 * rows * (256.0 * 256.0 + 256.0 * 512.0) + 8.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BACK);
   if (variant == 0)      hipLaunchKernelGGL((back_kernel<12, false>), grid, dim3(256), B_LDS, stream, a);
   else if (variant == 2) hipLaunchKernelGGL((back_kernel<16, true>), grid, dim3(256), B_LDS, stream, a);
   else                   hipLaunchKernelGGL((back_kernel<12, true>), grid, dim3(256), B_LDS, stream, a);
+  gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
 
@@ -1168,8 +1178,12 @@ int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
   }();
   (void)attr;
   const dim3 grid(a.B + a.rg_tiles_max);
+  // executed FLOPs per row: dY (512 -> 256), dO (256 -> 256); RG rows: the RG->KG attention backward (5 products of Nk x 256)
+  const double rows = (double)a.rows_rg + (double)a.B * a.Nk;
+  const int prof = gemm_prof_open(stream, 2.0 * rows * (512.0 * 256.0 + 256.0 * 256.0) + 10.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BWD1);
   if (variant == 0) hipLaunchKernelGGL((bwd1_kernel<12, false>), grid, dim3(256), W_LDS, stream, a);
   else              hipLaunchKernelGGL((bwd1_kernel<12, true>), grid, dim3(256), W_LDS, stream, a);
+  gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
 
@@ -1186,6 +1200,10 @@ int launch_fused_bwd2(Bwd2Args& a, int variant, hipStream_t stream) {
     return true;
   }();
   (void)attr;
+  // executed FLOPs per row: dR / dG (768 -> 256); RG rows: the KG->RG attention backward (5 products of Nk x 256)
+  const double rows = (double)a.rows_rg + (double)a.B * a.Nk;
+  const int prof = gemm_prof_open(stream, 2.0 * rows * 768.0 * 256.0 + 10.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BWD2);
   hipLaunchKernelGGL((bwd2_kernel<12, false>), dim3(a.rg_tiles_max), dim3(256), X_LDS, stream, a);
+  gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }

@@ -524,7 +524,7 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
                        f.O2_16, f.Y2_16, f.XH2_16, f.rstd2, f.mask2, w.Y2mean, w.H2mean, SITE_FFN_KG};
   ba.Q16 = f.Q16; ba.KV16 = f.KV16; ba.Q2_16 = f.Q2_16; ba.KV2_16 = f.KV2_16;
   ba.off = rg_offsets; ba.tile_off = bd.tile_off; ba.inv_nr = bd.inv_nr; ba.lse2 = f.lse2;
-  ba.B = B; ba.Nk = Nk; ba.rg_tiles_max = T / 32 + B;          // >= sum of ceil(Nr / 32); surplus blocks exit at once
+  ba.B = B; ba.Nk = Nk; ba.rows_rg = T; ba.rg_tiles_max = T / 32 + B;          // >= sum of ceil(Nr / 32); surplus blocks exit at once
   ba.part = f.part; ba.tickets = w.tickets; ba.max_splits = (max_nr + 63) / 64;
   ba.drop = drop; ba.save = save ? 1 : 0;
   ba.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)g_dbg_stamp_blocks * 8 : nullptr;
@@ -629,7 +629,7 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   a1.Q16 = f.Q16; a1.KV16 = f.KV16; a1.dQKV16 = f.dQKV16; a1.dKV = w.dKV;
   a1.O2_16 = f.O2_16; a1.dO2_16 = f.dO2_16; a1.delta2 = f.delta2;
   a1.off = rg_offsets; a1.tile_off = bd.tile_off; a1.inv_nr = bd.inv_nr;
-  a1.B = B; a1.Nk = Nk; a1.rg_tiles_max = T / 32 + B; a1.qscale = 1.0f / sqrtf(32.0f); a1.drop = drop;
+  a1.B = B; a1.Nk = Nk; a1.rows_rg = T; a1.rg_tiles_max = T / 32 + B; a1.qscale = 1.0f / sqrtf(32.0f); a1.drop = drop;
   a1.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)2 * g_dbg_stamp_blocks * 8 : nullptr;
   CK(launch_fused_bwd1(a1, g_opt_fused_variant, st), "fused backward, first half");
   Bwd2Args a2; std::memset(&a2, 0, sizeof(a2));
@@ -637,7 +637,7 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   a2.dU16 = f.dU16; a2.WcRgT = f.WcRgT; a2.dR16 = f.dR16; a2.dQ2acc = w.dQ2acc; a2.dKV = w.dKV;
   a2.dU2_16 = f.dU2_16; a2.WcKgT = f.WcKgT; a2.dQKVkg16 = f.dQKVkg16; a2.dG16 = f.dG16;
   a2.tickets = w.tickets + B; a2.off = rg_offsets; a2.tile_off = bd.tile_off;
-  a2.B = B; a2.Nk = Nk; a2.rg_tiles_max = T / 32 + B; a2.qscale = a1.qscale; a2.drop = drop;
+  a2.B = B; a2.Nk = Nk; a2.rows_rg = T; a2.rg_tiles_max = T / 32 + B; a2.qscale = a1.qscale; a2.drop = drop;
   a2.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)3 * g_dbg_stamp_blocks * 8 : nullptr;
   CK(launch_fused_bwd2(a2, g_opt_fused_variant, st), "fused backward, second half");
   // every node-level weight gradient: dW += dy^T . x over the rows of a stream (bf16 operands the fused kernels wrote)
@@ -650,10 +650,9 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   g.tn(f.dH2_16, 2 * H, f.Y2_16, H, Gr[CAMO_P_F2_W0], H, Gr[CAMO_P_F2_B0], 2 * H, H, TK);
   g.tn(f.dU2_16, H, f.O2_16, H, Gr[CAMO_P_A2_OUT_W], H, Gr[CAMO_P_A2_OUT_B], H, H, TK);
   g.tn(f.dQKVkg16, 3 * H, f.G16, H, Gr[CAMO_P_A2_IN_W], H, Gr[CAMO_P_A2_IN_B], H, H, TK);
-  CK(g.run(), "weight gradients (1/2)");
   g.tn(f.dQKVkg16 + H, 3 * H, f.G16, H, Gr[CAMO_P_A1_IN_W] + HH, H, Gr[CAMO_P_A1_IN_B] + H, 2 * H, H, TK);
   g.tn(f.dG16, H, f.KG16, D, Gr[CAMO_P_KG_PROJ_W], D, Gr[CAMO_P_KG_PROJ_B], H, D, TK);
-  CK(g.run(), "weight gradients (2/2)");
+  CK(g.run(), "node-level weight gradients");
   return 0;
 }
 
@@ -990,6 +989,13 @@ int camo_debug_set_stamps(void* buf, int32_t blocks_per_kernel) {
 
 int camo_prof_begin(int32_t max_launches) {
   CK(gemm_prof_begin(max_launches), "prof begin");
+  return 0;
+}
+
+int camo_prof_kind(int32_t kind, double* ms, int32_t* launches, double* flops) {
+  int n = 0;
+  CK(gemm_prof_kind(kind, ms, &n, flops), "prof kind");
+  if (launches) *launches = n;
   return 0;
 }
 

@@ -49,5 +49,8 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream);
 int gemm_prof_begin(int max_launches);
 int gemm_prof_end(double* total_ms, int* launches, double* total_flops);
 // used by the launchers of both grouped-GEMM kernels: returns a slot (or -1 when timing is off)
-int gemm_prof_open(hipStream_t stream, double flops);
+enum : int { PROF_GEMM = 0, PROF_FRONT = 1, PROF_BACK = 2, PROF_BWD1 = 3, PROF_BWD2 = 4, PROF_TAIL = 5, PROF_OPT = 6, PROF_SHADOW = 7,
+             PROF_ATTN = 8, PROF_OTHER = 9, PROF_KINDS = 10 };
+int gemm_prof_open(hipStream_t stream, double flops, int kind = PROF_GEMM);
+int gemm_prof_kind(int kind, double* ms, int* launches, double* flops);
 void gemm_prof_close(int slot, hipStream_t stream);

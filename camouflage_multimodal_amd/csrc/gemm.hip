@@ -559,7 +559,7 @@ __device__ __forceinline__ void skinny_tile_body(const GemmProb& P, const DropCf
     auto ldb_ = [&](int kb) { const int k = kb * 16 + 4 * q; if constexpr (bkm) return raw_ks(ob, n0 + x, k); else return raw_mm<VEC>(ob, n0 + x, k); };
     // D k blocks in flight in D statically indexed register stages (rotating the stages through moves would make
     // every move wait for its load); raw loads are address-clamped, blocks past K are masked to zero
-    constexpr int D = 4;
+    constexpr int D = 8;        // (K = 512 over 4 waves = 8 k blocks: the whole operand slice is requested up front)
     float4 sa[D], sb[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) { sa[d] = lda_(kb0 + d * kbstep); sb[d] = ldb_(kb0 + d * kbstep); }
@@ -654,7 +654,10 @@ struct Prof {
   bool on = false;
   std::vector<hipEvent_t> ev;     // 2 per launch
   std::vector<double> flops;
+  std::vector<int> kind;
   size_t used = 0;
+  double kind_ms[PROF_KINDS] = {}, kind_fl[PROF_KINDS] = {};
+  int kind_n[PROF_KINDS] = {};
 } g_prof;
 }  // namespace
 
@@ -666,7 +669,7 @@ int gemm_prof_begin(int max_launches) {
     if (r != hipSuccess) return (int)r;
     g_prof.ev.push_back(e);
   }
-  g_prof.flops.clear();
+  g_prof.flops.clear(); g_prof.kind.clear();
   g_prof.used = 0;
   g_prof.on = true;
   return 0;
@@ -675,12 +678,15 @@ int gemm_prof_begin(int max_launches) {
 int gemm_prof_end(double* total_ms, int* launches, double* total_flops) {
   g_prof.on = false;
   double ms = 0.0, fl = 0.0;
+  for (int k = 0; k < PROF_KINDS; ++k) { g_prof.kind_ms[k] = 0.0; g_prof.kind_fl[k] = 0.0; g_prof.kind_n[k] = 0; }
   for (size_t i = 0; i < g_prof.used; ++i) {
     hipError_t r = hipEventSynchronize(g_prof.ev[2 * i + 1]);
     if (r != hipSuccess) return (int)r;
     float t = 0.f;
     r = hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
     if (r != hipSuccess) return (int)r;
+    const int k = g_prof.kind[i];
+    g_prof.kind_ms[k] += t; g_prof.kind_fl[k] += g_prof.flops[i]; g_prof.kind_n[k] += 1;
     ms += t; fl += g_prof.flops[i];
   }
   if (total_ms) *total_ms = ms;
@@ -689,9 +695,17 @@ int gemm_prof_end(double* total_ms, int* launches, double* total_flops) {
   return 0;
 }
 
-int gemm_prof_open(hipStream_t stream, double flops) {
+int gemm_prof_kind(int kind, double* ms, int* launches, double* flops) {
+  if (kind < 0 || kind >= PROF_KINDS) return (int)hipErrorInvalidValue;
+  if (ms) *ms = g_prof.kind_ms[kind];
+  if (launches) *launches = g_prof.kind_n[kind];
+  if (flops) *flops = g_prof.kind_fl[kind];
+  return 0;
+}
+
+int gemm_prof_open(hipStream_t stream, double flops, int kind) {
   if (!g_prof.on || 2 * (g_prof.used + 1) > g_prof.ev.size()) return -1;
-  g_prof.flops.push_back(flops);
+  g_prof.flops.push_back(flops); g_prof.kind.push_back(kind < 0 || kind >= PROF_KINDS ? PROF_OTHER : kind);
   (void)hipEventRecord(g_prof.ev[2 * g_prof.used], stream);
   return (int)g_prof.used;
 }
@@ -715,7 +729,11 @@ static int launch_skinny(GemmBatch& gb, hipStream_t stream) {
     total += (p.flags & GF_A_KMAJOR) ? (tiles + nw - 1) / nw : tiles;
   }
   if (total == 0) return 0;
+  double fl = 0.0;
+  for (int i = 0; i < gb.n; ++i) fl += 2.0 * gb.p[i].M * (double)gb.p[i].N * gb.p[i].K;
+  const int prof = gemm_prof_open(stream, fl, PROF_TAIL);
   hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(total), dim3(256), 0, stream, gb);
+  gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 // clip + AdamW optimizer step.  One wave (64 lanes) per row wherever a row reduction is
 // needed; everything streams coalesced fp32.
 #include "misc.h"
+#include "gemm.h"      // launch timing hooks
 
 
 namespace {
@@ -675,12 +676,16 @@ int heads_loss_ok(int B, int C) { return B >= 1 && C >= 1 && 2 * C + 2 <= HEADS_
 int launch_heads_loss(const float* hid, const HeadsOut& hp, const long long* y, const float* e, const float* s, int B, int C,
                       int Fh, float scale, float* outs, float* terms, int* pred, float* dhid, hipStream_t stream) {
   if (!heads_loss_ok(B, C)) return (int)hipErrorInvalidValue;
+  const int prof = gemm_prof_open(stream, 0.0, PROF_TAIL);
   hipLaunchKernelGGL(heads_loss_kernel, dim3(B), dim3(256), 0, stream, hid, hp, y, e, s, C, Fh, scale, outs, terms, pred, dhid);
+  gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
 
 int launch_sumsq(const float* g, size_t n, float* out, hipStream_t stream) {
+  const int prof = gemm_prof_open(stream, 0.0, PROF_OPT);
   hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, g, n, out);
+  gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
 
@@ -690,7 +695,9 @@ int launch_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* s
   size_t nb = (n / 4 + 255) / 256;
   if (nb < 1) nb = 1;
   if (nb > 1024) nb = 1024;
+  const int prof = gemm_prof_open(stream, 0.0, PROF_OPT);
   hipLaunchKernelGGL(clip_adamw_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p, g, m, v, n, sumsq, max_norm, lr,
                      b1, b2, eps, wd, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), zero_grads);
+  gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }

@@ -208,12 +208,17 @@ int camo_debug_set_option(const char* name, int32_t value);
 int camo_debug_set_stamps(void* buf, int32_t blocks_per_kernel);
 
 /* Opt-in launch timing for bench.py's roofline leg: between camo_prof_begin and camo_prof_end every
- * launch of the grouped GEMM kernel (the dominant kernel: >= 98 % of the path's FLOPs) is bracketed
+ * launch of the path's kernels (the grouped GEMMs, the fused row-tile kernels, the tail GEMMs, weight shadows) is bracketed
  * by two HIP events recorded on the launch stream.  camo_prof_end synchronises on them and returns
  * the summed kernel time, the number of launches and the FLOPs those launches executed.  This is the
  * one piece of process-global state in the library: single-threaded use, not for production loops. */
 int camo_prof_begin(int32_t max_launches);
 int camo_prof_end(double* gemm_ms, int32_t* gemm_launches, double* gemm_flops);
+/* After camo_prof_end: the same three figures per kernel family.  kind: 0 grouped GEMMs (weight gradients in the fused
+ * schedule), 1 fused forward front half, 2 fused forward back half, 3 fused backward first half, 4 second half,
+ * 5 per-sample tail GEMMs, 6 optimizer, 7 weight shadows + clears, 8 attention kernels of the unfused schedules, 9 other.
+ * (camo_prof_end's own outputs are the totals over all kinds.) */
+int camo_prof_kind(int32_t kind, double* ms, int32_t* launches, double* flops);
 
 #ifdef __cplusplus
 }

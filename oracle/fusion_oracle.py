@@ -41,12 +41,11 @@ def _fmix32(x):
 
 def dropout_keep(seed, site, idx, p):
     """Boolean keep-mask for element indices ``idx`` (any shape, < 2**32).
-    u = top 24 bits of a two-round murmur3 finaliser; keep iff u >= p."""
+    u = top 24 bits of a murmur3 finaliser over (idx + site constant + seed_lo) ^ seed_hi; keep iff u >= p."""
     idx = np.asarray(idx, dtype=np.uint64)
     lo = np.uint64(seed & 0xFFFFFFFF)
     hi = np.uint64((seed >> 32) & 0xFFFFFFFF)
-    x = (idx * np.uint64(0x9E3779B1) + np.uint64(site) * np.uint64(0x85EBCA77) + lo) & np.uint64(0xFFFFFFFF)
-    x = _fmix32(x)
+    x = (idx + ((np.uint64(site) * np.uint64(0x85EBCA77) + lo) & np.uint64(0xFFFFFFFF))) & np.uint64(0xFFFFFFFF)
     x = _fmix32(x ^ hi)
     u = (x >> np.uint64(8)).astype(np.float32) * f32(1.0 / 16777216.0)
     return u >= f32(p)

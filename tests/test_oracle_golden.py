@@ -134,8 +134,15 @@ def test_dropout_hash_statistics():
     a = FO.dropout_keep(1, FO.SITE_FFN_RG, idx, 0.3); b = FO.dropout_keep(2, FO.SITE_FFN_RG, idx, 0.3)
     c = FO.dropout_keep(1, FO.SITE_FFN_KG, idx, 0.3)
     assert 0.55 < (a == b).mean() < 0.61 and 0.55 < (a == c).mean() < 0.61   # independent streams: 0.7^2+0.3^2
-    # neighbouring elements uncorrelated
-    assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 0.01
+    # neighbouring elements uncorrelated, also at the strides the kernels index with (row pitch 512, head pitch 13, 104)
+    for lag in (1, 2, 13, 104, 512, 4096):
+        assert abs(np.corrcoef(a[:-lag], a[lag:])[0, 1]) < 0.01, lag
+    # the streams of two sites are not shifted copies of each other at small shifts
+    for lag in range(1, 64):
+        assert abs(np.corrcoef(a[:-lag], c[lag:])[0, 1]) < 0.02 and abs(np.corrcoef(c[:-lag], a[lag:])[0, 1]) < 0.02
+    # seeds that differ only in the high word give independent masks
+    d = FO.dropout_keep(1 | (7 << 32), FO.SITE_FFN_RG, idx, 0.3)
+    assert 0.55 < (a == d).mean() < 0.61
 
 
 def test_train_mode_dropout_gradcheck():
