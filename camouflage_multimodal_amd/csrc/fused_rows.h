@@ -74,6 +74,7 @@ struct Bwd1Args {
   const us16* O2_16; us16* dO2_16; float* delta2;   // KG: attention output in, its gradient out [B*Nk][256], row-dots out [B][8][16]
   const int* off; const int* tile_off; const float* inv_nr;
   int B, Nk, rg_tiles_max, rows_rg; float qscale; DropCfg drop; unsigned long long* stamps;
+  int writer_blocks;                           // (filled by the launcher)
 };
 int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream);
 size_t fused_bwd1_lds();
@@ -88,6 +89,7 @@ struct Bwd2Args {
   float* dQ2acc;                               // [B*Nk][256] += (atomics; zeroed by the caller)
   const float* dKV;                            // [B*Nk][512] dK|dV sums of the first half
   const us16* dU2_16; const us16* WcKgT; us16* dQKVkg16; us16* dG16;              // KG rows: [B*Nk][768] out (weight-gradient operand), [B*Nk][256] out
+  float* dGpart;                               // [B*Nk][256] fp32 scratch: the part of dG an early block computes while the RG tiles run
   int* tickets;                                // [B] zeroed arrival counters (one per sample)
   const int* off; const int* tile_off;
   int B, Nk, rg_tiles_max, rows_rg; float qscale; DropCfg drop; unsigned long long* stamps;

@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const FrontArgs a) {
     *reinterpret_cast<u32x4*>(bufX + r * PX + 32 * c + 16) = u32x4{pack2(v2.x, v2.y), pack2(v2.z, v2.w), pack2(v3.x, v3.y), pack2(v3.z, v3.w)};
   }
   __syncthreads();
-  if (a.save) copy_out<4>(bufX, PX, 0, S.X16, 128, row0, nrows);
-  // projection 128 -> 256
+  // projection 128 -> 256  (every global store of the tile waits for the end of the kernel: vmcnt counts stores too and
+  // retires in order, so a store issued in front of a weight stream makes the stream's first waits sit out its write latency)
   Stage<6, 16, true, DEPTH> st1;
   {
     f32x16 acc[2] = {zero16(), zero16()};
@@ -190,7 +190,6 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const FrontArgs a) {
   }
   __syncthreads();
   stamp(a.stamps, 1);
-  copy_out<5>(bufR, PR, 0, S.R16, 256, row0, nrows);
   // in-projections 256 -> [256 q | 512 k', v'] (24 feature tiles, 6 per wave)
   {
     f32x16 acc[6];
@@ -216,6 +215,8 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const FrontArgs a) {
   stamp(a.stamps, 2);
   copy_out<5>(bufQ, PQ, 0, S.Q16, 256, row0, nrows);
   copy_out<6>(bufQ, PQ, 512, S.KV16, 512, row0, nrows);
+  copy_out<5>(bufR, PR, 0, S.R16, 256, row0, nrows);
+  if (a.save) copy_out<4>(bufX, PX, 0, S.X16, 128, row0, nrows);
   stamp(a.stamps, 3);
 }
 
@@ -381,10 +382,14 @@ __device__ __forceinline__ void attn_kg_split(const BackArgs& a, char* smem, int
   // partial of this split: Z has the query on its registers (0..7 -> j = acc_row(i, h) < 16) and the feature on the lane
 #pragma unroll
   for (int hd = 0; hd < 2; ++hd) {
+    // write-through (sc1) stores: the hand-off below then needs no agent-scope release, i.e. no write-back of this XCD's L2
     float* part = a.part + (((size_t)a.tile_off[b] + 2 * sp) * 8 + 2 * w + hd) * PART_FLOATS;       // (a split = two 32-row tiles)
-    if (lane < 16) { part[lane] = mx[hd]; part[16 + lane] = L[hd]; }
+    if (lane < 16) {
+      __hip_atomic_store(part + lane, mx[hd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(part + 16 + lane, L[hd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) part[32 + acc_row(i, h) * 32 + l31] = Z[hd][i];
+    for (int i = 0; i < 8; ++i) __hip_atomic_store(part + 32 + acc_row(i, h) * 32 + l31, Z[hd][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -487,17 +492,15 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
     const int nsplit = (a.off[b + 1] - a.off[b] + SPLIT_ROWS - 1) / SPLIT_ROWS;
     if (sp >= nsplit) return;
     attn_kg_split(a, smem, b, sp, w, lane);
-    // hand the partial over (cdna_hip_programming.md, in-launch split-K reduction): every storing wave drains its stores, the
-    // block meets, one lane releases at agent scope and draws a ticket; the block that draws the last one acquires and combines.
+    stamp(a.stamps, 4);
+    // hand the partial over (cdna_hip_programming.md, in-launch split-K reduction, write-through form): every storing wave
+    // drains its sc1 stores, the block meets, one lane draws a ticket; the block that draws the last one acquires and combines.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* flag = reinterpret_cast<int*>(red);
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      flag[0] = __hip_atomic_fetch_add(a.tickets + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid == 0) flag[0] = __hip_atomic_fetch_add(a.tickets + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    stamp(a.stamps, 5);
     if (flag[0] != nsplit - 1) return;                                     // (block-uniform)
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -507,6 +510,7 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
     __syncthreads();
     sto.prefetch(reinterpret_cast<const u32x4*>(S.Wo) + (size_t)w * (16 * 2 * 64) + lane, rot);
     attn_kg_combine(a, smem, b, nsplit);
+    stamp(a.stamps, 6);
     rowg0 = (size_t)b * a.Nk; nrows = a.Nk; inv_n = 1.0f / (float)a.Nk;
   } else {
     const int tile = (int)blockIdx.x - nkg;
@@ -520,11 +524,11 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
   }
   __syncthreads();
   stamp(a.stamps, 1);
-  if (a.save) copy_out<5>(bufO, PR, 0, S.O16, 256, rowg0, nrows);
 
   // ---- out-projection + residual, LayerNorm (lane = row; wave w: features 64 w .. 64 w + 63)
   const size_t rrow = rowg0 + min(l31, nrows - 1);
-  float u[32];
+  float u[32];                                            // out-projection + residual, then (in place) the normalised LayerNorm input
+  float rstd_keep = 0.f;
   {
     f32x16 acc[2] = {zero16(), zero16()};
     sto.run(bufO + l31 * PR + 16 * h, acc);
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) { u[i] -= mean; sq = fmaf(u[i], u[i], sq); }
     const float rstd = 1.0f / sqrtf(row_total(sq, 1) * (1.0f / 256.0f) + 1e-5f);
-    if (a.save && w == 0 && h == 0 && l31 < nrows) S.rstd[rowg0 + l31] = rstd;
+    rstd_keep = rstd;
     // (both barriers of row_total are behind every wave's out-projection MFMAs: region A is free for the fp32 tile)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -567,8 +571,7 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
         const float4 y = make_float4(x0 * gm.x + bt.x, x1 * gm.y + bt.y, x2 * gm.z + bt.z, x3 * gm.w + bt.w);
         *reinterpret_cast<u32x2*>(bufY + l31 * PR + 2 * c0) = u32x2{pack2(y.x, y.y), pack2(y.z, y.w)};
         *reinterpret_cast<float4*>(tile32 + l31 * PT + c0) = y;
-        if (a.save && l31 < nrows)
-          *reinterpret_cast<u32x2*>(S.XH16 + (rowg0 + l31) * 256 + c0) = u32x2{pack2(x0, x1), pack2(x2, x3)};
+        o[0] = x0; o[1] = x1; o[2] = x2; o[3] = x3;       // (kept for the save at the end of the kernel)
       }
   }
   __syncthreads();
@@ -578,7 +581,6 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
     for (int r = 0; r < nrows; ++r) sum += tile32[r * PT + tid];
     atomicAdd(S.Ymean + (size_t)b * 256 + tid, sum * inv_n);
   }
-  if (a.save) copy_out<5>(bufY, PR, 0, S.Y16, 256, rowg0, nrows);
 
   // ---- FFN layer 0 + ReLU + dropout, pooled over the rows (lane = feature; wave w: features 128 w .. 128 w + 127)
   {
@@ -612,6 +614,24 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
       }
     }
   }
+  if (a.save) {
+    // saved-for-backward tensors, all at the end (no weight stream left to delay): the normalised LayerNorm input goes
+    // through region A (free since the mean-pool pass) so that it leaves as whole rows like the other two tiles
+    char* bufXH = smem;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float* o = u + 16 * t + 4 * g;
+        *reinterpret_cast<u32x2*>(bufXH + l31 * PR + 2 * (64 * w + 32 * t + 8 * g + 4 * h)) = u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+      }
+    if (w == 0 && h == 0 && l31 < nrows) S.rstd[rowg0 + l31] = rstd_keep;
+    __syncthreads();
+    copy_out<5>(bufXH, PR, 0, S.XH16, 256, rowg0, nrows);
+    copy_out<5>(bufO, PR, 0, S.O16, 256, rowg0, nrows);
+    copy_out<5>(bufY, PR, 0, S.Y16, 256, rowg0, nrows);
+  }
   stamp(a.stamps, 3);
 }
 
@@ -635,6 +655,35 @@ __global__ __launch_bounds__(256, 2) void bwd1_kernel(const Bwd1Args a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool kg = (int)blockIdx.x < a.B;
   const int rot = ROT ? (int)(blockIdx.x >> 3) : 0;
+  if ((int)blockIdx.x >= a.B + a.rg_tiles_max) {
+    // writer blocks: materialise dH = mask * d(mean H) / n as the bf16 weight-gradient operand (the tiles above build the same
+    // values on the fly and never store them: a store stream in the middle of their weight stream would stall it).
+    // One wave per row per pass; lane l covers features 8 l .. 8 l + 7: mask byte l of the row's 64.
+    const int wb = (int)blockIdx.x - a.B - a.rg_tiles_max;
+    const int total_rows = a.rows_rg + a.B * a.Nk;
+    for (int r = wb * 4 + (tid >> 6); r < total_rows; r += 4 * a.writer_blocks) {
+      const bool isk = r >= a.rows_rg;
+      const Bwd1Stream& W = a.s[isk ? 1 : 0];
+      const int row = isk ? r - a.rows_rg : r;
+      int sb; float inv;
+      if (isk) { sb = row / a.Nk; inv = 1.0f / (float)a.Nk; }
+      else {
+        int lo = 0, hi = a.B - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.off[mid] <= row) lo = mid; else hi = mid - 1; }
+        sb = lo; inv = a.inv_nr[sb];
+      }
+      const uint32_t word = W.mask[(size_t)row * 16 + (lane >> 2)];
+      const uint32_t bits = word >> (8 * (lane & 3));
+      const float gs = inv * a.drop.scale;
+      const float4 g0 = *reinterpret_cast<const float4*>(W.dHm + (size_t)sb * W.ld_dHm + 8 * lane);
+      const float4 g1 = *reinterpret_cast<const float4*>(W.dHm + (size_t)sb * W.ld_dHm + 8 * lane + 4);
+      auto sel = [&](int k, float g) { return ((bits >> k) & 1u) ? (uint32_t)f2bf(g * gs) : 0u; };
+      const u32x4 fr = u32x4{sel(0, g0.x) | (sel(1, g0.y) << 16), sel(2, g0.z) | (sel(3, g0.w) << 16),
+                             sel(4, g1.x) | (sel(5, g1.y) << 16), sel(6, g1.z) | (sel(7, g1.w) << 16)};
+      *reinterpret_cast<u32x4*>(W.dH16 + (size_t)row * 512 + 8 * lane) = fr;
+    }
+    return;
+  }
   int b; size_t rowg0; int nrows; float inv_n;
   if (kg) {
     b = blockIdx.x; rowg0 = (size_t)b * a.Nk; nrows = a.Nk; inv_n = 1.0f / (float)a.Nk;
@@ -693,7 +742,6 @@ __global__ __launch_bounds__(256, 2) void bwd1_kernel(const Bwd1Args a) {
 #pragma unroll
     for (int d = 0; d < 4; ++d)
       fr[d] = (((bits >> (2 * d)) & 1u) ? (g[d] & 0xFFFFu) : 0u) | (((bits >> (2 * d + 1)) & 1u) ? (g[d] & 0xFFFF0000u) : 0u);
-    if (rok) *reinterpret_cast<u32x4*>(S.dH16 + (rowg0 + l31) * 512 + 16 * ks + 8 * h) = fr;
     return as_frag(fr);
   }, acc1);
   st2.prefetch(reinterpret_cast<const u32x4*>(S.WoT) + (size_t)w * (16 * 2 * 64) + lane, rot);
@@ -760,11 +808,11 @@ __global__ __launch_bounds__(256, 2) void bwd1_kernel(const Bwd1Args a) {
       atomicAdd(S.dbeta + tid, sum);
     }
   }
-  copy_out<5>(bufdU, PR, 0, S.dU16, 256, rowg0, nrows);
   stamp(a.stamps, 2);
   // ---- dO^T = Wo^T-side product: lane = row, wave w: the 64 features of heads 2w, 2w+1
   f32x16 acc2[2] = {zero16(), zero16()};
   st2.run(bufdU + l31 * PR + 16 * h, acc2);
+  copy_out<5>(bufdU, PR, 0, S.dU16, 256, rowg0, nrows);         // (behind the last weight stream of the block)
   if (kg) {
     // dO2 (bf16, the second half's MFMA operand) and delta2[head][j] = sum_f dO2[j][f] * O2[j][f]
 #pragma unroll
@@ -893,20 +941,59 @@ __global__ __launch_bounds__(256, 2) void bwd2_kernel(const Bwd2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x;
+  const int Nk = a.Nk;
+  char* Q2s = smem + X_Q2S; char* dO2s = smem + X_DO2S; float* tabs = reinterpret_cast<float*>(smem + X_TABS);
+  char* bufT = smem + X_BUFT; char* imgs = smem + X_IMGS;
+  int* flag = reinterpret_cast<int*>(smem + X_RED);
+  stamp(a.stamps, 0);
+  const bool early = (int)blockIdx.x < a.B;          // the B early blocks: the part of dG that needs no RG tile of this launch
+  int b;
+  if (early) {
+    // dGpart = dU2 + [dK | dV] . [Wk1; Wv1]  (k steps 16..47 of the [Wq2; Wk1; Wv1] stream), fp32, and the dK | dV columns of the
+    // KG rows' weight-gradient operand.  Counts as one arrival of its sample.
+    b = blockIdx.x;
+    const size_t krow0 = (size_t)b * Nk;
+    Stage<2, 32, true, DEPTH, false> se;
+    se.prefetch(reinterpret_cast<const u32x4*>(a.WcKgT) + (size_t)w * (48 * 2 * 64) + 64 * (16 * 2) + lane, 0);
+    for (int c = tid; c < 32 * 64; c += 256) {
+      const int j = c >> 6, ch = c & 63;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (j < Nk) {
+        const float* src = a.dKV + (krow0 + j) * 512 + 8 * ch;
+        const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+        v = u32x4{pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w)};
+      }
+      *reinterpret_cast<u32x4*>(bufT + j * PQ + 512 + 16 * ch) = v;
+    }
+    __syncthreads();
+    f32x16 acc[2] = {zero16(), zero16()};
+    se.run(bufT + l31 * PQ + 512 + 16 * h, acc);
+    copy_out<6>(bufT, PQ, 512, a.dQKVkg16 + 256, 768, krow0, Nk);
+    if (l31 < Nk) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
+          const u32x2 uv = *reinterpret_cast<const u32x2*>(a.dU2_16 + (krow0 + l31) * 256 + c0);
+          float* dst = a.dGpart + (krow0 + l31) * 256 + c0;                 // (write-through: read by another block of this launch)
+          __hip_atomic_store(dst, acc[t][4 * g] + bf_lo(uv.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(dst + 1, acc[t][4 * g + 1] + bf_hi(uv.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(dst + 2, acc[t][4 * g + 2] + bf_lo(uv.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(dst + 3, acc[t][4 * g + 3] + bf_hi(uv.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+  } else {
+  const int tile = (int)blockIdx.x - a.B;
   if (tile >= a.tile_off[a.B]) return;
   int lo = 0, hi = a.B - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_off[mid] <= tile) lo = mid; else hi = mid - 1; }
-  const int b = lo, Nk = a.Nk;
+  b = lo;
   const int r0t = a.off[b] + 32 * (tile - a.tile_off[b]);
   const size_t rowg0 = r0t;
   const int nrows = min(32, a.off[b + 1] - r0t);
   const bool rok = l31 < nrows;
   const size_t vrow = rowg0 + min(l31, nrows - 1);
-  char* Q2s = smem + X_Q2S; char* dO2s = smem + X_DO2S; float* tabs = reinterpret_cast<float*>(smem + X_TABS);
-  char* bufT = smem + X_BUFT; char* imgs = smem + X_IMGS;
-  int* flag = reinterpret_cast<int*>(smem + X_RED);
-  stamp(a.stamps, 0);
   Stage<2, 48, true, DEPTH, false> sr;
   sr.prefetch(reinterpret_cast<const u32x4*>(a.WcRgT) + (size_t)w * (48 * 2 * 64) + lane, 0);
   // per-sample inputs: the Nk pre-scaled queries, the gradient of their attention output, softmax max / 1/sum, row-dots
@@ -1002,13 +1089,13 @@ __global__ __launch_bounds__(256, 2) void bwd2_kernel(const Bwd2Args a) {
   }
   __syncthreads();                                           // key tile consumed by every wave; dK2 | dV2 tile complete
   stamp(a.stamps, 1);
-  copy_out<6>(bufT, PQ, 512, a.dQKV16 + 256, 768, rowg0, nrows);
 #pragma unroll
   for (int i = 0; i < 4; ++i) { const int id = tid + 256 * i; *reinterpret_cast<u32x4*>(bufT + (id >> 5) * PQ + 16 * (id & 31)) = dqreg[i]; }
   __syncthreads();
   {
     f32x16 acc[2] = {zero16(), zero16()};
     sr.run(bufT + l31 * PQ + 16 * h, acc);
+    copy_out<6>(bufT, PQ, 512, a.dQKV16 + 256, 768, rowg0, nrows);     // (behind the weight stream)
     if (rok) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -1022,50 +1109,48 @@ __global__ __launch_bounds__(256, 2) void bwd2_kernel(const Bwd2Args a) {
     }
   }
   stamp(a.stamps, 2);
-  // ---- arrival: the last tile of the sample takes its KG rows through the same product
+  }
+  // ---- arrival: the last block of the sample (its RG tiles and its early block) finishes the KG rows' product.  What it reads from the other
+  // tiles are the dQ2 sums, fp32 atomics that execute at the memory side (no L2 line to write back), so a tile only has
+  // to have its atomics acknowledged (vmcnt) before its ticket; everything else it reads is the previous launch's.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    flag[0] = __hip_atomic_fetch_add(a.tickets + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (tid == 0) flag[0] = __hip_atomic_fetch_add(a.tickets + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  if (flag[0] != a.tile_off[b + 1] - a.tile_off[b] - 1) return;
+  if (flag[0] != a.tile_off[b + 1] - a.tile_off[b]) return;          // (tiles + the early block)
+  Stage<2, 16, true, DEPTH, false> sg;
+  sg.prefetch(reinterpret_cast<const u32x4*>(a.WcKgT) + (size_t)w * (48 * 2 * 64) + lane, 0);     // k steps 0..15: Wq2
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  Stage<2, 48, true, DEPTH, false> sg;
-  sg.prefetch(reinterpret_cast<const u32x4*>(a.WcKgT) + (size_t)w * (48 * 2 * 64) + lane, 0);
-  // [dQ2 | dK | dV] of the sample's Nk rows: fp32 sums -> bf16 tile (rows >= Nk cleared)
-  for (int c = tid; c < 32 * 96; c += 256) {                 // 96 chunks of 8 columns per row
-    const int j = c / 96, ch = c - 96 * j;
+  // dQ2 of the sample's Nk rows: fp32 sums -> bf16 tile (rows >= Nk cleared)
+  const size_t krow0 = (size_t)b * Nk;
+  for (int c = tid; c < 32 * 32; c += 256) {
+    const int j = c >> 5, ch = c & 31;
     u32x4 v = u32x4{0u, 0u, 0u, 0u};
     if (j < Nk) {
-      const float* src = ch < 32 ? a.dQ2acc + ((size_t)b * Nk + j) * 256 + 8 * ch : a.dKV + ((size_t)b * Nk + j) * 512 + 8 * (ch - 32);
+      const float* src = a.dQ2acc + (krow0 + j) * 256 + 8 * ch;
       const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
       v = u32x4{pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w)};
     }
     *reinterpret_cast<u32x4*>(bufT + j * PQ + 16 * ch) = v;
   }
   __syncthreads();
-  const size_t krow0 = (size_t)b * Nk;
-  copy_out<5>(bufT, PQ, 0, a.dQKVkg16, 768, krow0, Nk);
-  copy_out<6>(bufT, PQ, 512, a.dQKVkg16 + 256, 768, krow0, Nk);
   {
     f32x16 acc[2] = {zero16(), zero16()};
     sg.run(bufT + l31 * PQ + 16 * h, acc);
+    copy_out<5>(bufT, PQ, 0, a.dQKVkg16, 768, krow0, Nk);
     if (l31 < Nk) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
-          const u32x2 uv = *reinterpret_cast<const u32x2*>(a.dU2_16 + (krow0 + l31) * 256 + c0);
+          const float4 pv = *reinterpret_cast<const float4*>(a.dGpart + (krow0 + l31) * 256 + c0);
           *reinterpret_cast<u32x2*>(a.dG16 + (krow0 + l31) * 256 + c0) =
-              u32x2{pack2(acc[t][4 * g] + bf_lo(uv.x), acc[t][4 * g + 1] + bf_hi(uv.x)), pack2(acc[t][4 * g + 2] + bf_lo(uv.y), acc[t][4 * g + 3] + bf_hi(uv.y))};
+              u32x2{pack2(acc[t][4 * g] + pv.x, acc[t][4 * g + 1] + pv.y), pack2(acc[t][4 * g + 2] + pv.z, acc[t][4 * g + 3] + pv.w)};
         }
     }
   }
@@ -1177,7 +1262,9 @@ int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
     return true;
   }();
   (void)attr;
-  const dim3 grid(a.B + a.rg_tiles_max);
+  a.writer_blocks = (a.rows_rg + a.B * a.Nk + 3) / 4;                // one row per wave: a pass is a dependent load -> store chain
+  if (a.writer_blocks > 8192) a.writer_blocks = 8192;
+  const dim3 grid(a.B + a.rg_tiles_max + a.writer_blocks);
   // executed FLOPs per row: dY (512 -> 256), dO (256 -> 256); RG rows: the RG->KG attention backward (5 products of Nk x 256)
   const double rows = (double)a.rows_rg + (double)a.B * a.Nk;
   const int prof = gemm_prof_open(stream, 2.0 * rows * (512.0 * 256.0 + 256.0 * 256.0) + 10.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BWD1);
@@ -1192,7 +1279,7 @@ size_t fused_bwd2_lds() { return X_LDS; }
 int launch_fused_bwd2(Bwd2Args& a, int variant, hipStream_t stream) {
   (void)variant;
   if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q2_16 || !a.dO2_16 || !a.lse2 || !a.delta2 || !a.KV2_16 || !a.dQKV16 ||
-      !a.dU16 || !a.WcRgT || !a.dR16 || !a.dQ2acc || !a.dKV || !a.dU2_16 || !a.WcKgT || !a.dQKVkg16 || !a.dG16 || !a.tickets || !a.off || !a.tile_off)
+      !a.dU16 || !a.WcRgT || !a.dR16 || !a.dQ2acc || !a.dKV || !a.dU2_16 || !a.WcKgT || !a.dQKVkg16 || !a.dG16 || !a.dGpart || !a.tickets || !a.off || !a.tile_off)
     return (int)hipErrorInvalidValue;
   if (!al16(a.dQKV16) || !al16(a.dQKVkg16) || !al16(a.WcRgT) || !al16(a.WcKgT) || !al16(a.dQ2acc) || !al16(a.dKV)) return (int)hipErrorInvalidValue;
   static const bool attr = [] {
@@ -1203,7 +1290,7 @@ int launch_fused_bwd2(Bwd2Args& a, int variant, hipStream_t stream) {
   // executed FLOPs per row: dR / dG (768 -> 256); RG rows: the KG->RG attention backward (5 products of Nk x 256)
   const double rows = (double)a.rows_rg + (double)a.B * a.Nk;
   const int prof = gemm_prof_open(stream, 2.0 * rows * 768.0 * 256.0 + 10.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BWD2);
-  hipLaunchKernelGGL((bwd2_kernel<12, false>), dim3(a.rg_tiles_max), dim3(256), X_LDS, stream, a);
+  hipLaunchKernelGGL((bwd2_kernel<12, false>), dim3(a.B + a.rg_tiles_max), dim3(256), X_LDS, stream, a);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }

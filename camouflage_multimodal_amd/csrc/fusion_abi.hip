@@ -103,7 +103,7 @@ struct Ws {
     // backward: transposed shadows, the bf16 gradients that are weight-gradient operands, per-sample exchange buffers
     us16 *W1T, *W2T, *Wo1T, *Wo2T, *WcRgT, *WcKgT;
     us16 *dH16, *dH2_16, *dU16, *dU2_16, *dQKV16, *dQKVkg16, *dR16, *dG16, *dO2_16;
-    float* delta2;
+    float *delta2, *dGpart;
   } f;
   int* tickets;         // [2][B] arrival counters (forward: KG->RG attention splits; backward: a sample's RG tiles), in the zero block
   float* dQ2acc;        // [TK][H] fp32 sums of the KG->RG query gradient (in the zero block, fused backward)
@@ -183,7 +183,7 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
         f.WcRgT = c.take<us>(3 * H * H); f.WcKgT = c.take<us>(3 * H * H);
         f.dH16 = c.take<us>(Tp * 2 * H); f.dH2_16 = c.take<us>(TKp * 2 * H); f.dU16 = c.take<us>(Tp * H); f.dU2_16 = c.take<us>(TKp * H);
         f.dQKV16 = c.take<us>(Tp * 3 * H); f.dQKVkg16 = c.take<us>(TKp * 3 * H); f.dR16 = c.take<us>(Tp * H); f.dG16 = c.take<us>(TKp * H);
-        f.dO2_16 = c.take<us>(TKp * H); f.delta2 = c.take<float>((size_t)B * 8 * 16);
+        f.dO2_16 = c.take<us>(TKp * H); f.delta2 = c.take<float>((size_t)B * 8 * 16); f.dGpart = c.take<float>(TKp * H);
       }
     }
   } else {
@@ -635,7 +635,7 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   Bwd2Args a2; std::memset(&a2, 0, sizeof(a2));
   a2.Q2_16 = f.Q2_16; a2.dO2_16 = f.dO2_16; a2.lse2 = f.lse2; a2.delta2 = f.delta2; a2.KV2_16 = f.KV2_16; a2.dQKV16 = f.dQKV16;
   a2.dU16 = f.dU16; a2.WcRgT = f.WcRgT; a2.dR16 = f.dR16; a2.dQ2acc = w.dQ2acc; a2.dKV = w.dKV;
-  a2.dU2_16 = f.dU2_16; a2.WcKgT = f.WcKgT; a2.dQKVkg16 = f.dQKVkg16; a2.dG16 = f.dG16;
+  a2.dU2_16 = f.dU2_16; a2.WcKgT = f.WcKgT; a2.dQKVkg16 = f.dQKVkg16; a2.dG16 = f.dG16; a2.dGpart = f.dGpart;
   a2.tickets = w.tickets + B; a2.off = rg_offsets; a2.tile_off = bd.tile_off;
   a2.B = B; a2.Nk = Nk; a2.rows_rg = T; a2.rg_tiles_max = T / 32 + B; a2.qscale = a1.qscale; a2.drop = drop;
   a2.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)3 * g_dbg_stamp_blocks * 8 : nullptr;

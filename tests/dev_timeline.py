@@ -37,6 +37,14 @@ _lib.lib().camo_debug_set_stamps(None, 0)
 st = buf.cpu().numpy().reshape(4, NB, 8)
 for k, name in enumerate(("front", "back", "bwd1", "bwd2") if train else ("front", "back")):
     s = st[k]
+    if name == "back":          # KG->RG attention splits: stamps 4 (split done), 5 (ticket drawn), 6 (combine done, last arriver only)
+        sp = s[(s[:, 0] > 0) & (s[:, 5] > 0)].astype(np.float64)
+        if len(sp):
+            la = sp[sp[:, 6] > 0]
+            print(f"    KG->RG attention: {len(sp)} splits: split {np.median(sp[:, 4] - sp[:, 0]) / 100:.2f} us (max {(sp[:, 4] - sp[:, 0]).max() / 100:.2f}), "
+                  f"drain+ticket {np.median(sp[:, 5] - sp[:, 4]) / 100:.2f} (max {(sp[:, 5] - sp[:, 4]).max() / 100:.2f}); {len(la)} last arrivers: "
+                  f"start->ticket {np.median(la[:, 5] - la[:, 0]) / 100:.2f}, combine {np.median(la[:, 6] - la[:, 5]) / 100:.2f} us; "
+                  f"last ticket drawn at {(sp[:, 5].max() - sp[:, 0].min()) / 100:.2f} us of the kernel")
     act = (s[:, 0] > 0) & (s[:, 3] > 0)          # (blocks that return early leave later stamps empty)
     s = s[act].astype(np.float64)
     t0 = s[:, 0].min()
@@ -45,7 +53,7 @@ for k, name in enumerate(("front", "back", "bwd1", "bwd2") if train else ("front
     idx = np.nonzero(act)[0]
     if name == "back":
         groups = [("KG splits", idx < nkg), ("RG tiles", idx >= nkg)]
-    elif name == "bwd1":
+    elif name in ("bwd1", "bwd2"):
         groups = [("KG blocks", idx < B), ("RG tiles", idx >= B)]
     else:
         groups = [("all tiles", idx >= 0)]
