@@ -49,6 +49,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Sum over the 64 lanes with DPP adds only (no LDS crossbar round trips): a shift-scan inside each row of 16, then the two
+// row broadcasts.  The total is valid in LANE 63 only.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWMASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v = dpp_add<0x111, 0xf>(v);      // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);      // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);      // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of each row holds the row's sum
+  v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -36,6 +36,7 @@ int g_opt_sched16 = -1;
 int g_opt_fused = -1;      // likewise for the fused row-tile schedule (fused_rows.h): 0 = never take it
 unsigned long long* g_dbg_stamps = nullptr;   // testing hook: timeline buffer of the fused kernels ([2][blocks][8] 100 MHz ticks)
 int g_dbg_stamp_blocks = 0;
+int g_opt_tail17 = -1;                        // 0 = never take the one-launch tail (misc.hip, tail_fused_kernel)
 int g_opt_fused_variant = 1;                  // developer A/B of the fused kernels' weight streaming (fused_rows.h)
 int g_opt_fused_save = 0;  // 1 = inference calls of the fused schedule also write what a backward would need (tests read it back)
 
@@ -107,6 +108,7 @@ struct Ws {
   } f;
   int* tickets;         // [2][B] arrival counters (forward: KG->RG attention splits; backward: a sample's RG tiles), in the zero block
   float* dQ2acc;        // [TK][H] fp32 sums of the KG->RG query gradient (in the zero block, fused backward)
+  float* tailsum;       // [B][4H] all-reduce buffers of the one-launch tail (F1 | hidden | dF1) + 4 counter words (in the zero block)
   size_t bytes;
 };
 
@@ -133,13 +135,14 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
     w.means_n = (size_t)B * 6 * H;
     {   // one contiguous block so a single memset clears every atomically-accumulated buffer
       const size_t nzt = ((size_t)2 * B + 3) & ~size_t(3);                   // tickets: padded to 16 bytes
-      const size_t nz = w.means_n + (size_t)B * H + nzt + TK * 2 * H + TK * H;
+      const size_t nz = w.means_n + (size_t)B * H + nzt + TK * 2 * H + TK * H + (size_t)B * 4 * H + 4;
       float* z = c.take<float>(nz);
       w.zero_base = z; w.zero_bytes = nz * sizeof(float);
       w.means = z; w.dfused = z ? z + w.means_n : nullptr;
       w.tickets = z ? reinterpret_cast<int*>(w.dfused + (size_t)B * H) : nullptr;
       w.dKV = z ? w.dfused + (size_t)B * H + nzt : nullptr;
       w.dQ2acc = z ? w.dKV + TK * 2 * H : nullptr;
+      w.tailsum = z ? w.dQ2acc + TK * H : nullptr;
     }
     if (w.means) { w.Ymean = w.means; w.H1mean = w.Ymean + B * H; w.Y2mean = w.H1mean + B * 2 * H; w.H2mean = w.Y2mean + B * H; }
     w.comb = c.take<float>(B * 2 * H); w.F1 = c.take<float>(B * H); w.fused = c.take<float>(B * H);
@@ -506,8 +509,10 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
       pad(f.dU16, t, w.Tp, H); pad(f.dQKV16, t, w.Tp, 3 * H); pad(f.dR16, t, w.Tp, H);
       pad(f.KG16, tk, w.TKp, D); pad(f.G16, tk, w.TKp, H); pad(f.O2_16, tk, w.TKp, H); pad(f.Y2_16, tk, w.TKp, H); pad(f.dH2_16, tk, w.TKp, 2 * H);
       pad(f.dU2_16, tk, w.TKp, H); pad(f.dQKVkg16, tk, w.TKp, 3 * H); pad(f.dG16, tk, w.TKp, H);
+      zero(w.dHm1, (size_t)B * 2 * H * sizeof(float)); zero(w.dHm2, (size_t)B * 2 * H * sizeof(float));   // atomically summed by the one-launch tail
     } else {
       zero(w.zero_base, (size_t)(reinterpret_cast<char*>(w.dKV) - reinterpret_cast<char*>(w.zero_base)));
+      zero(w.tailsum, ((size_t)B * 4 * H + 4) * sizeof(float));
     }
     CK(launch_weight_shadows(sb, st), "weight shadows");
   }
@@ -535,6 +540,8 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
 // ---- node-level backward of the fused row-tile schedule (w.dcomb, w.dHm1, w.dHm2 hold the pooled gradients) ----
 int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* Gr, const int32_t* rg_offsets, const Desc& bd,
                      int B, int T, int Nk, const Ws& w, const DropCfg& drop, hipStream_t st);
+int tail17(const camo_dims_t& d, const float* const* P, float* const* Gr, const Ws& w, int B, float* outs, const FusedLoss* fl,
+           const DropCfg& drop, hipStream_t st);
 
 // ---- node-level backward of the bf16 schedule (w.dcomb, w.dHm1, w.dHm2 hold the pooled gradients) ----
 int backward_nodes16(const camo_dims_t& d, const float* const* P, float* const* Gr, const int32_t* rg_offsets,
@@ -616,6 +623,35 @@ int backward_nodes16(const camo_dims_t& d, const float* const* P, float* const* 
   return 0;
 }
 
+// the per-sample tail of the fused schedule as one launch (misc.hip, tail_fused_kernel); fl == null: forward only
+int tail17(const camo_dims_t& d, const float* const* P, float* const* Gr, const Ws& w, int B, float* outs, const FusedLoss* fl,
+           const DropCfg& drop, hipStream_t st) {
+  const int H = 256;
+  TailFusedArgs a; std::memset(&a, 0, sizeof(a));
+  a.Ymean = w.Ymean; a.H1mean = w.H1mean; a.Y2mean = w.Y2mean; a.H2mean = w.H2mean;
+  a.W13 = P[CAMO_P_F1_W3]; a.b13 = P[CAMO_P_F1_B3]; a.W23 = P[CAMO_P_F2_W3]; a.b23 = P[CAMO_P_F2_B3];
+  a.Wfu0 = P[CAMO_P_FU_W0]; a.bfu0 = P[CAMO_P_FU_B0]; a.Wfu3 = P[CAMO_P_FU_W3]; a.bfu3 = P[CAMO_P_FU_B3];
+  for (int x = 0; x < 4; ++x) {
+    a.Wh0[x] = P[CAMO_P_HEADS + 4 * x]; a.bh0[x] = P[CAMO_P_HEADS + 4 * x + 1]; a.Wh3[x] = P[CAMO_P_HEADS + 4 * x + 2]; a.bh3[x] = P[CAMO_P_HEADS + 4 * x + 3];
+  }
+  if (fl) {
+    a.gW13 = Gr[CAMO_P_F1_W3]; a.gb13 = Gr[CAMO_P_F1_B3]; a.gW23 = Gr[CAMO_P_F2_W3]; a.gb23 = Gr[CAMO_P_F2_B3];
+    a.gWfu0 = Gr[CAMO_P_FU_W0]; a.gbfu0 = Gr[CAMO_P_FU_B0]; a.gWfu3 = Gr[CAMO_P_FU_W3]; a.gbfu3 = Gr[CAMO_P_FU_B3];
+    for (int x = 0; x < 4; ++x) {
+      a.gWh0[x] = Gr[CAMO_P_HEADS + 4 * x]; a.gbh0[x] = Gr[CAMO_P_HEADS + 4 * x + 1]; a.gWh3[x] = Gr[CAMO_P_HEADS + 4 * x + 2]; a.gbh3[x] = Gr[CAMO_P_HEADS + 4 * x + 3];
+    }
+    a.y = reinterpret_cast<const long long*>(fl->y); a.e = fl->e; a.s = fl->s; a.terms = fl->terms; a.pred = fl->pred;
+    a.dcomb = w.dcomb; a.dHm1 = w.dHm1; a.dHm2 = w.dHm2;
+  }
+  a.outs = outs;
+  a.F1sum = w.tailsum; a.hidsum = w.tailsum + (size_t)B * H; a.dF1sum = w.tailsum + (size_t)B * 3 * H;
+  a.counters = reinterpret_cast<unsigned int*>(w.tailsum + (size_t)B * 4 * H);
+  a.B = B; a.C = d.num_classes; a.mode = fl ? 1 : 0; a.drop = drop;
+  a.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)4 * g_dbg_stamp_blocks * 8 : nullptr;
+  CK(launch_tail_fused(a, st), "per-sample tail (one launch)");
+  return 0;
+}
+
 int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* Gr, const int32_t* rg_offsets, const Desc& bd,
                      int B, int T, int Nk, const Ws& w, const DropCfg& drop, hipStream_t st) {
   const int H = 256, D = 128, TK = B * Nk;
@@ -685,7 +721,8 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
                         const void* desc,
                         const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace,
                         size_t workspace_bytes, float* outs, float* attn_rg2kg, float* attn_kg2rg, int32_t training,
-                        uint64_t seed, int32_t precision, int32_t flags, void* stream, const FusedLoss* fl) {
+                        uint64_t seed, int32_t precision, int32_t flags, void* stream, const FusedLoss* fl,
+                        const FusedLoss* fl17 = nullptr /* given: loss + the whole tail backward ride in the one-launch tail */) {
   if (int e = check_dims(dims, B, T, Nk)) return e;
   if (!params || !rg || !rg_offsets || !desc || !kg || !workspace || !outs)
     return fail(CAMO_E_ARG, "null pointer argument");
@@ -761,6 +798,8 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   CK(g.run(), "ffn layer 0");
   }
   // per-sample means of Y and H1d, then the second FFN layer on the means (mean-pool linearity)
+  if (use17 && g_opt_tail17 != 0 && (fl17 || ((flags & CAMO_FWD_INFERENCE) && !fl)) && tail_fused_ok(B, d.num_classes))
+    return tail17(d, P, fl17 ? fl17->head_grads - CAMO_P_HEADS : nullptr, w, B, outs, fl17, drop, st);
   if (use16 || use17) {
     // accumulated by the kernels that produce the pooled tensors
   } else {
@@ -905,6 +944,17 @@ int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* para
   if (!dims || !grads || !y || !e || !s || !outs || !loss_terms) return fail(CAMO_E_ARG, "null pointer argument");
   const int head0 = dims->fusion_type == CAMO_FUSION_LATE ? CAMO_PL_HEADS : CAMO_P_HEADS;
   const bool fuse = heads_loss_ok(B, dims->num_classes);
+  if (g_opt_tail17 != 0 && params && !check_dims(dims, B, T, Nk) && fused17_ok(*dims, params, precision, Nk, max_nr) &&
+      tail_fused_ok(B, dims->num_classes)) {
+    // fused schedule + one-launch tail: node-level forward, [tail forward + loss + tail backward], node-level backward
+    const FusedLoss fl{y, e, s, loss_terms, pred, grads + head0};
+    if (int rc = forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
+                              nullptr, nullptr, training, seed, precision, 0, stream, nullptr, &fl)) return rc;
+    const Ws w = carve(*dims, B, T, Nk, workspace);
+    const Desc bd = desc_carve(B, T, const_cast<void*>(batch_desc));
+    return backward_nodes17(*dims, params, grads, rg_offsets, bd, B, T, Nk, w, make_drop(training, dims->dropout, seed),
+                            static_cast<hipStream_t>(stream));
+  }
   if (fuse) {
     const FusedLoss fl{y, e, s, loss_terms, pred, grads + head0};
     if (int rc = forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
@@ -979,6 +1029,7 @@ int camo_debug_set_option(const char* name, int32_t value) {
   if (std::strcmp(name, "fused") == 0) { g_opt_fused = value; return 0; }
   if (std::strcmp(name, "fused_save") == 0) { g_opt_fused_save = value; return 0; }
   if (std::strcmp(name, "fused_variant") == 0) { g_opt_fused_variant = value; return 0; }
+  if (std::strcmp(name, "tail17") == 0) { g_opt_tail17 = value; return 0; }
   return fail(CAMO_E_ARG, std::string("unknown option ") + name);
 }
 

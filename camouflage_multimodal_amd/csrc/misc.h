@@ -45,3 +45,19 @@ int launch_heads_loss(const float* hid, const HeadsOut& hp, const long long* y, 
 int launch_sumsq(const float* g, size_t n, float* out, hipStream_t stream);
 int launch_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sumsq, float max_norm,
                       float lr, float b1, float b2, float eps, float wd, int step, int zero_grads, hipStream_t stream);
+
+// The whole per-sample tail (pooled FFN second layers, fusion MLP, four heads; with mode 1 also the loss and everything
+// backwards) as ONE launch of 64 co-resident blocks: misc.hip, tail_fused_kernel.  B <= 16, hidden 256.
+struct TailFusedArgs {
+  const float *Ymean, *H1mean, *Y2mean, *H2mean;            // pooled node-level outputs [B][256], [B][512] x 2 streams
+  const float *W13, *b13, *W23, *b23, *Wfu0, *bfu0, *Wfu3, *bfu3; const float* Wh0[4]; const float* bh0[4]; const float* Wh3[4]; const float* bh3[4];
+  float *gW13, *gb13, *gW23, *gb23, *gWfu0, *gbfu0, *gWfu3, *gbfu3; float* gWh0[4]; float* gbh0[4]; float* gWh3[4]; float* gbh3[4];   // += (mode 1)
+  const long long* y; const float* e; const float* s;       // labels (mode 1)
+  float* outs; float* terms; int* pred;                     // [B][2C+2]; mode 1: [B][4], [B] (may be null)
+  float *F1sum, *hidsum, *dF1sum; unsigned int* counters;   // ZEROED exchange buffers [B][256], [B][512], [B][256]; 4 words (3 arrival counters + timeout flag)
+  float *dcomb, *dHm1, *dHm2;                               // mode 1 out: d(mean Z) [B][512]; d(mean H) [B][512] x 2, ZEROED (accumulated with atomics)
+  int B, C, mode; DropCfg drop;
+  unsigned long long* stamps;                               // developer timeline (null in product calls)
+};
+int tail_fused_ok(int B, int C);
+int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream);

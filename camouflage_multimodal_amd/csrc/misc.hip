@@ -482,6 +482,507 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict
   if (lane < nout) atomicAdd(gbx + lane, sd[coff + lane]);
 }
 
+
+// ---------------------------------------------------------------- the whole per-sample tail in ONE launch
+// fusion_model.py:134-139 (pooled FFN second layers, fusion MLP), :208-235 (four heads), the 4-term loss
+// (train_multimodal.py:256-268) and all of it backwards, for B <= 16 samples at hidden 256.
+//
+// As separate launches the tail is ten dependent steps of a few 16x16 tiles each: ~80 us of a 210 us training step at
+// B = 16, almost all of it launch boundaries and cold weight fetches.  Per-CU bandwidth rules out one block per sample
+// (2.4 MB of fp32 weights each).  Here TG = 64 co-resident blocks split every layer's weights between them Megatron
+// style, so that consecutive linear layers need ONE exchange, not two:
+//   block g owns comb columns [8g, 8g+8) (of the 512 = RG | KG pooled features) and fused columns [4g, 4g+4);
+//   L1 (pooled FFN layer) is split by OUTPUT column, L2 (fusion layer 0) by INPUT column -> partial sums of its 256
+//   outputs, all-reduced with fp32 atomics;  L3 (fusion layer 3) by output column, L4 (heads' hidden layers) by input
+//   column -> partial sums of their 512 outputs, all-reduced;  the head output layers and the loss are small enough
+//   to be recomputed by every block.  Backward mirrors it: one all-reduce (d F1), and the last partial sums
+//   (d mean H) are simply complete when the kernel ends.  Every weight gradient element has exactly one writer.
+// An all-reduce = every block's atomics acknowledged, an arrival counter, a BOUNDED spin on it by one lane per block (the
+// grid is 64 blocks of 256 threads: co-resident on any MI355X partition of >= 64 CUs; on timeout the kernel raises
+// counters[3] and finishes with wrong numbers instead of hanging), an agent-scope acquire, then plain loads: float atomics
+// execute at the memory side and leave no line in any L2.
+constexpr int TG = 64;
+__device__ __forceinline__ void tstamp(unsigned long long* stamps, int k) {
+  if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 32 + k] = __builtin_amdgcn_s_memrealtime();
+}
+__device__ __forceinline__ void tail_arrive_wait(unsigned int* counter, unsigned int* timeout) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's atomics are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)TG) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 21)) { __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+constexpr int TF_MAXB = 16;
+constexpr int TF_MAXW = 18;           // 2 * num_classes + 2 (num_classes <= 8)
+constexpr int TF_LDS_FLOATS = 2 * TF_MAXB * 512 + 2 * TF_MAXB * 256 + 2048 + 2048 + 3 * 128 + 64 + 64 + 2 * TF_MAXB * TF_MAXW + TF_MAXW * 129;
+
+// The kernel runs once per step on 64 CUs that have just run other code: every instruction is an instruction-cache miss the
+// first time it executes, so the code is kept SMALL -- loops over the samples stay loops, 4 samples per trip (the LDS images
+// are padded with zero rows to a multiple of 4 samples) so that four independent chains hide the LDS latency; every
+// global read whose address is known early is issued early, and the passes that fetch an all-reduce's result have all
+// their loads in flight together.
+__device__ __forceinline__ void wave_sum4(float (&acc)[4]) {           // totals valid in lane 63
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = wave_sum_lane63(acc[j]);
+}
+
+__global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x, B = a.B, C = a.C, Wd = 2 * C + 2;
+  const int B4 = (B + 3) & ~3;
+  float* R1 = sm;                       // [16][512] pooled FFN activations of this block's stream (kept to the end)
+  float* R2 = R1 + TF_MAXB * 512;       // [16][512] the heads' hidden activations, then (in place) the gradient of their pre-activations
+  float* F1 = R2 + TF_MAXB * 512;       // [16][256] fusion layer 0 activations (after ReLU and dropout)
+  float* DF = F1 + TF_MAXB * 256;       // [16][256] gradient of fusion layer 0's pre-activations
+  float* wA = DF + TF_MAXB * 256;       // [512][4]  this block's columns of the heads' hidden-layer weights
+  float* wB = wA + 2048;                // [256][8]  this block's columns of fusion layer 0's weights
+  float* combS = wB + 2048; float* dcombS = combS + 128; float* ymS = dcombS + 128; float* fusedS = ymS + 128; float* dfusedS = fusedS + 64;
+  float* outsS = dfusedS + 64; float* dpre = outsS + TF_MAXB * TF_MAXW;
+  float* w3s = dpre + TF_MAXB * TF_MAXW;                     // [Wd][129]: output-layer weight rows + bias, in output-column order
+  const bool kgs = g >= 32;                                 // comb columns 256.. are the KG stream's
+  const int c0 = 8 * (g & 31), ccol = (kgs ? 256 : 0) + c0;
+  const float* Hmean = kgs ? a.H2mean : a.H1mean; const float* Ymean = kgs ? a.Y2mean : a.Ymean;
+  const float* W3s = kgs ? a.W23 : a.W13; const float* b3s = kgs ? a.b23 : a.b13;
+  float* gW3s = kgs ? a.gW23 : a.gW13; float* gb3s = kgs ? a.gb23 : a.gb13; float* dHm = kgs ? a.dHm2 : a.dHm1;
+  const bool dodrop = a.drop.p > 0.f;
+  const float dscale = a.drop.scale;
+  auto headW0 = [&](int x) { return x == 0 ? a.Wh0[0] : (x == 1 ? a.Wh0[1] : (x == 2 ? a.Wh0[2] : a.Wh0[3])); };
+  auto headB0 = [&](int x) { return x == 0 ? a.bh0[0] : (x == 1 ? a.bh0[1] : (x == 2 ? a.bh0[2] : a.bh0[3])); };
+  auto headW3 = [&](int x) { return x == 0 ? a.Wh3[0] : (x == 1 ? a.Wh3[1] : (x == 2 ? a.Wh3[2] : a.Wh3[3])); };
+  auto headB3 = [&](int x) { return x == 0 ? a.bh3[0] : (x == 1 ? a.bh3[1] : (x == 2 ? a.bh3[2] : a.bh3[3])); };
+  auto gheadW0 = [&](int x) { return x == 0 ? a.gWh0[0] : (x == 1 ? a.gWh0[1] : (x == 2 ? a.gWh0[2] : a.gWh0[3])); };
+  auto gheadB0 = [&](int x) { return x == 0 ? a.gbh0[0] : (x == 1 ? a.gbh0[1] : (x == 2 ? a.gbh0[2] : a.gbh0[3])); };
+  auto gheadW3 = [&](int x) { return x == 0 ? a.gWh3[0] : (x == 1 ? a.gWh3[1] : (x == 2 ? a.gWh3[2] : a.gWh3[3])); };
+  auto gheadB3 = [&](int x) { return x == 0 ? a.gbh3[0] : (x == 1 ? a.gbh3[1] : (x == 2 ? a.gbh3[2] : a.gbh3[3])); };
+  auto head_of = [&](int o, int& x, int& oo) {              // output column o of [mask C | instance C | edge | score]
+    if (o < C) { x = 0; oo = o; } else if (o < 2 * C) { x = 1; oo = o - C; } else if (o == 2 * C) { x = 2; oo = 0; } else { x = 3; oo = 0; }
+  };
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  tstamp(a.stamps, 0);
+  // ---- every global read that depends on nothing: issued now, one memory round trip for all of them
+  float w1[2][8], w3r[4], w8r[4], w10[2][8];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w1[cc][i] = W3s[(size_t)(c0 + 2 * wave + cc) * 512 + lane + 64 * i];      // L1: rows of this wave's 2 columns
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w3r[i] = a.Wfu3[(size_t)(4 * g + wave) * 256 + lane + 64 * i];              // L3: row of this wave's column
+#pragma unroll
+  for (int c = 0; c < 4; ++c) w8r[c] = a.Wfu3[(size_t)(4 * g + c) * 256 + tid];                           // d F1: rows 4g.., column tid
+  if (a.mode) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w10[kk][c] = W3s[(size_t)(c0 + c) * 512 + tid + 256 * kk];              // d(mean H): column tid (+256)
+  }
+  float4 hv[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) { const int i = tid + 256 * it; hv[it] = i < B * 128 ? reinterpret_cast<const float4*>(Hmean)[i] : z4; }
+  {
+    const float4* p = reinterpret_cast<const float4*>(a.Wfu0 + (size_t)tid * 512 + ccol);
+    reinterpret_cast<float4*>(wB)[2 * tid] = p[0]; reinterpret_cast<float4*>(wB)[2 * tid + 1] = p[1];
+  }
+#pragma unroll
+  for (int mm = 0; mm < 2; ++mm) {
+    const int m = tid + 256 * mm;
+    reinterpret_cast<float4*>(wA)[m] = *reinterpret_cast<const float4*>(headW0(m >> 7) + (size_t)(m & 127) * 256 + 4 * g);
+  }
+  float w3v[10];                                             // (Wd * 129 <= 2322 elements: at most 10 per thread, all in flight)
+#pragma unroll
+  for (int it = 0; it < 10; ++it) {
+    const int p = tid + 256 * it;
+    w3v[it] = 0.f;
+    if (p < Wd * 129) {
+      const int o = p / 129, k = p - 129 * o;
+      int x, oo; head_of(o, x, oo);
+      w3v[it] = k < 128 ? headW3(x)[(size_t)oo * 128 + k] : headB3(x)[oo];
+    }
+  }
+  if (tid < 128) ymS[tid] = tid < B * 8 ? Ymean[(tid >> 3) * 256 + c0 + (tid & 7)] + b3s[c0 + (tid & 7)] : 0.f;
+  const float bias2 = g == 0 ? a.bfu0[tid] : 0.f;
+  const float bias3 = a.bfu3[4 * g + wave];
+  const float bias4a = g == 0 ? headB0(tid >> 7)[tid & 127] : 0.f, bias4b = g == 0 ? headB0(2 + (tid >> 7))[tid & 127] : 0.f;
+  // old values of every gradient this block adds to (mode 1): fetched now, so that no += later waits for its read
+  const int hx = (8 * g) >> 7, hmm0 = (8 * g) & 127, hnout = hx < 2 ? C : 1, hcoff = hx == 0 ? 0 : (hx == 1 ? C : (hx == 2 ? 2 * C : 2 * C + 1));
+  float* dW3h = gheadW3(hx) + (size_t)(tid >> 3) * 128 + hmm0 + (tid & 7);
+  float4* dst0 = reinterpret_cast<float4*>(gheadW0(tid >> 7) + (size_t)(tid & 127) * 256 + 4 * g);
+  float4* dst1 = reinterpret_cast<float4*>(gheadW0(2 + (tid >> 7)) + (size_t)(tid & 127) * 256 + 4 * g);
+  float4* dstfu0 = reinterpret_cast<float4*>(a.gWfu0 + (size_t)tid * 512 + ccol);
+  float oW3h = 0.f, ob3h = 0.f, ob0h = 0.f, obfu3 = 0.f, obfu0 = 0.f, ob3s = 0.f, gwfu3[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 g0 = z4, g1 = z4;
+  if (a.mode) {
+    if (tid < hnout * 8) oW3h = *dW3h;
+    if (g == 0 && tid >= 128 && tid < 128 + Wd) { int xx, oo; head_of(tid - 128, xx, oo); ob3h = gheadB3(xx)[oo]; }
+    g0 = *dst0; g1 = *dst1;
+    if (tid < 8) { ob0h = gheadB0((8 * g + tid) >> 7)[(8 * g + tid) & 127]; ob3s = gb3s[c0 + tid]; }
+    if (tid < 4) { obfu3 = a.gbfu3[4 * g + tid]; obfu0 = a.gbfu0[4 * g + tid]; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gwfu3[c] = a.gWfu3[(size_t)(4 * g + c) * 256 + tid];
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) { const int i = tid + 256 * it; if (i < B4 * 128) reinterpret_cast<float4*>(R1)[i] = hv[it]; }
+#pragma unroll
+  for (int it = 0; it < 10; ++it) { const int p = tid + 256 * it; if (p < Wd * 129) w3s[p] = w3v[it]; }
+  __syncthreads();
+  tstamp(a.stamps, 1);
+  // ---- L1 (by output column): comb[b][c] = mean Y + (mean H) . W3^T + b3, c in this block's 8 columns; wave w: columns 2w, 2w+1
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll 1
+    for (int b0 = 0; b0 < B; b0 += 4) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(w1[cc][i], R1[(b0 + j) * 512 + lane + 64 * i], acc[j]);
+      wave_sum4(acc);
+      if (lane == 63) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) combS[(b0 + j) * 8 + 2 * wave + cc] = acc[j] + ymS[(b0 + j) * 8 + 2 * wave + cc];
+      }
+    }
+  }
+  __syncthreads();
+  tstamp(a.stamps, 2);
+  // ---- L2 (by input column): partial sums of fusion layer 0's 256 outputs; thread n owns output n
+  {
+    float w8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w8[c] = wB[tid * 8 + c];
+#pragma unroll 1
+    for (int b0 = 0; b0 < B; b0 += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 ca = reinterpret_cast<const float4*>(combS)[(b0 + j) * 2], cb = reinterpret_cast<const float4*>(combS)[(b0 + j) * 2 + 1];
+        const float acc = bias2 + w8[0] * ca.x + w8[1] * ca.y + w8[2] * ca.z + w8[3] * ca.w + w8[4] * cb.x + w8[5] * cb.y + w8[6] * cb.z + w8[7] * cb.w;
+        if (b0 + j < B) atomicAdd(a.F1sum + (b0 + j) * 256 + tid, acc);
+      }
+    }
+  }
+  tstamp(a.stamps, 3);
+  tail_arrive_wait(a.counters + 0, a.counters + 3);
+  tstamp(a.stamps, 4);
+  {
+    float4 v4[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { const int i = tid + 256 * it; v4[it] = i < B * 64 ? reinterpret_cast<const float4*>(a.F1sum)[i] : z4; }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = tid + 256 * it;
+      if (i < B4 * 64) {
+        float v[4] = {fmaxf(v4[it].x, 0.f), fmaxf(v4[it].y, 0.f), fmaxf(v4[it].z, 0.f), fmaxf(v4[it].w, 0.f)};
+        if (dodrop) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= drop_mult(a.drop, SITE_FUSE, (uint32_t)(4 * i + e));    // (element index b * 256 + n)
+        }
+        reinterpret_cast<float4*>(F1)[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+  __syncthreads();
+  tstamp(a.stamps, 5);
+  // ---- L3 (by output column): fused[b][4g + w], wave w
+#pragma unroll 1
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(w3r[i], F1[(b0 + j) * 256 + lane + 64 * i], acc[j]);
+    wave_sum4(acc);
+    if (lane == 63) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fusedS[(b0 + j) * 4 + wave] = acc[j] + bias3;
+    }
+  }
+  __syncthreads();
+  tstamp(a.stamps, 6);
+  // ---- L4 (by input column): partial sums of the 4 x 128 hidden units of the heads; thread t owns units t and t + 256
+  {
+    const float4 wa0 = reinterpret_cast<const float4*>(wA)[tid], wa1 = reinterpret_cast<const float4*>(wA)[tid + 256];
+#pragma unroll 1
+    for (int b0 = 0; b0 < B; b0 += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 f = reinterpret_cast<const float4*>(fusedS)[b0 + j];
+        if (b0 + j < B) {
+          atomicAdd(a.hidsum + (b0 + j) * 512 + tid, bias4a + wa0.x * f.x + wa0.y * f.y + wa0.z * f.z + wa0.w * f.w);
+          atomicAdd(a.hidsum + (b0 + j) * 512 + tid + 256, bias4b + wa1.x * f.x + wa1.y * f.y + wa1.z * f.z + wa1.w * f.w);
+        }
+      }
+    }
+  }
+  tstamp(a.stamps, 7);
+  tail_arrive_wait(a.counters + 1, a.counters + 3);
+  tstamp(a.stamps, 8);
+  {
+    float4 v4[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) { const int i = tid + 256 * it; v4[it] = i < B * 128 ? reinterpret_cast<const float4*>(a.hidsum)[i] : z4; }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int i = tid + 256 * it;
+      if (i < B4 * 128) {
+        float v[4] = {fmaxf(v4[it].x, 0.f), fmaxf(v4[it].y, 0.f), fmaxf(v4[it].z, 0.f), fmaxf(v4[it].w, 0.f)};
+        if (dodrop) {
+          const int b = i >> 7, m = (4 * i) & 511;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= drop_mult(a.drop, SITE_HEAD0 + (uint32_t)(m >> 7), (uint32_t)(b * 128 + (m & 127) + e));
+        }
+        reinterpret_cast<float4*>(R2)[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+  if (tid < TF_MAXB * TF_MAXW) dpre[tid] = 0.f;            // (rows past B stay zero)
+  if (tid + 256 < TF_MAXB * TF_MAXW) dpre[tid + 256] = 0.f;
+  __syncthreads();
+  tstamp(a.stamps, 9);
+  // ---- head output layers (every block; operands in LDS), loss
+#pragma unroll 1
+  for (int p = tid; p < B * Wd; p += 256) {
+    const int b = p / Wd, o = p - b * Wd;
+    const int x = o < C ? 0 : (o < 2 * C ? 1 : (o == 2 * C ? 2 : 3));
+    const float* wr = w3s + o * 129;
+    const float* hr = R2 + b * 512 + x * 128;
+    float acc0 = wr[128], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll 2
+    for (int k = 0; k < 128; k += 4) {
+      const float4 h4 = *reinterpret_cast<const float4*>(hr + k);
+      acc0 = fmaf(wr[k], h4.x, acc0); acc1 = fmaf(wr[k + 1], h4.y, acc1); acc2 = fmaf(wr[k + 2], h4.z, acc2); acc3 = fmaf(wr[k + 3], h4.w, acc3);
+    }
+    float acc = (acc0 + acc1) + (acc2 + acc3);
+    if (x == 3) acc = 1.0f / (1.0f + __expf(-acc));
+    outsS[b * TF_MAXW + o] = acc;
+    if (g == 0) a.outs[p] = acc;
+  }
+  __syncthreads();
+  tstamp(a.stamps, 10);
+  if (!a.mode) { tstamp(a.stamps, 20); return; }
+  if (tid < B) {
+    float t4[4]; int pr = 0;
+    loss_sample(outsS + tid * TF_MAXW, (int)a.y[tid], a.e[tid], a.s[tid], C, t4, nullptr, dpre + tid * TF_MAXW, &pr);
+    if (g == 0) {
+      a.terms[4 * tid] = t4[0]; a.terms[4 * tid + 1] = t4[1]; a.terms[4 * tid + 2] = t4[2]; a.terms[4 * tid + 3] = t4[3];
+      if (a.pred) a.pred[tid] = pr;
+    }
+  }
+  __syncthreads();
+  tstamp(a.stamps, 11);
+  // ---- backward.  Output-layer gradients: block g writes units [8g, 8g+8), block 0 the biases (they need the hidden activations,
+  // which the next loop overwrites with their gradient)
+  {
+    if (tid < hnout * 8) {
+      const int o = tid >> 3, mi = tid & 7;
+      float acc = oW3h;
+#pragma unroll 1
+      for (int b0 = 0; b0 < B; b0 += 4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = fmaf(dpre[(b0 + j) * TF_MAXW + hcoff + o], R2[(b0 + j) * 512 + 8 * g + mi], acc);
+      *dW3h = acc;
+    }
+    if (g == 0 && tid >= 128 && tid < 128 + Wd) {
+      const int o = tid - 128;
+      int xx, oo; head_of(o, xx, oo);
+      float acc = ob3h;
+#pragma unroll 1
+      for (int b = 0; b < B; ++b) acc += dpre[b * TF_MAXW + o];
+      gheadB3(xx)[oo] = acc;
+    }
+  }
+  __syncthreads();
+  tstamp(a.stamps, 12);
+  // d hidden (every block, all 512 units), in place: thread t owns units t, t + 256 of every sample
+#pragma unroll
+  for (int mm = 0; mm < 2; ++mm) {
+    const int m = tid + 256 * mm, x = m >> 7, ml = m & 127;
+    const int nout = x < 2 ? C : 1, coff = x == 0 ? 0 : (x == 1 ? C : (x == 2 ? 2 * C : 2 * C + 1));
+#pragma unroll 1
+    for (int b0 = 0; b0 < B; b0 += 4) {
+      float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int o = 0; o < nout; ++o) {
+        const float wv = w3s[(coff + o) * 129 + ml];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = fmaf(dpre[(b0 + j) * TF_MAXW + coff + o], wv, d[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float hcur = R2[(b0 + j) * 512 + m]; R2[(b0 + j) * 512 + m] = hcur > 0.f ? d[j] * dscale : 0.f; }
+    }
+  }
+  __syncthreads();
+  tstamp(a.stamps, 13);
+  // ---- d fused for this block's 4 columns (wave w: column w): sum over the 512 hidden units; the hidden-layer weight
+  // gradients of those 4 columns; hidden-layer bias gradients of units [8g, 8g+8)
+  {
+    float wa[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wa[i] = wA[(lane + 64 * i) * 4 + wave];
+#pragma unroll 1
+    for (int b0 = 0; b0 < B; b0 += 4) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(R2[(b0 + j) * 512 + lane + 64 * i], wa[i], acc[j]);
+      wave_sum4(acc);
+      if (lane == 63) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dfusedS[(b0 + j) * 4 + wave] = acc[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 f = reinterpret_cast<const float4*>(fusedS)[b0 + j];
+        const float d0 = R2[(b0 + j) * 512 + tid], d1 = R2[(b0 + j) * 512 + tid + 256];
+        g0.x = fmaf(d0, f.x, g0.x); g0.y = fmaf(d0, f.y, g0.y); g0.z = fmaf(d0, f.z, g0.z); g0.w = fmaf(d0, f.w, g0.w);
+        g1.x = fmaf(d1, f.x, g1.x); g1.y = fmaf(d1, f.y, g1.y); g1.z = fmaf(d1, f.z, g1.z); g1.w = fmaf(d1, f.w, g1.w);
+      }
+    }
+    *dst0 = g0; *dst1 = g1;
+    if (tid < 8) {
+      const int m = 8 * g + tid;
+      float s = ob0h;
+#pragma unroll 1
+      for (int b = 0; b < B; ++b) s += R2[b * 512 + m];
+      gheadB0(m >> 7)[m & 127] = s;
+    }
+  }
+  __syncthreads();
+  tstamp(a.stamps, 14);
+  // ---- partial sums of d F1 (fusion layer 3 by its output rows 4g..4g+3); its weight and bias gradients
+  {
+    float gw[4] = {gwfu3[0], gwfu3[1], gwfu3[2], gwfu3[3]};
+#pragma unroll 1
+    for (int b0 = 0; b0 < B; b0 += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 df = reinterpret_cast<const float4*>(dfusedS)[b0 + j];
+        const float f1 = F1[(b0 + j) * 256 + tid];
+        gw[0] = fmaf(df.x, f1, gw[0]); gw[1] = fmaf(df.y, f1, gw[1]); gw[2] = fmaf(df.z, f1, gw[2]); gw[3] = fmaf(df.w, f1, gw[3]);
+        if (b0 + j < B) atomicAdd(a.dF1sum + (b0 + j) * 256 + tid, df.x * w8r[0] + df.y * w8r[1] + df.z * w8r[2] + df.w * w8r[3]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a.gWfu3[(size_t)(4 * g + c) * 256 + tid] = gw[c];
+    if (tid < 4) {
+      float s = obfu3;
+#pragma unroll 1
+      for (int b = 0; b < B; ++b) s += dfusedS[b * 4 + tid];
+      a.gbfu3[4 * g + tid] = s;
+    }
+  }
+  // (old values of the gradients the last phase adds to: fetched while the all-reduce is in flight)
+  const float4 o0 = dstfu0[0], o1 = dstfu0[1];
+  float gw3[2][8];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) gw3[kk][c] = gW3s[(size_t)(c0 + c) * 512 + tid + 256 * kk];
+  tstamp(a.stamps, 15);
+  tail_arrive_wait(a.counters + 2, a.counters + 3);
+  tstamp(a.stamps, 16);
+  {
+    float4 v4[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { const int i = tid + 256 * it; v4[it] = i < B * 64 ? reinterpret_cast<const float4*>(a.dF1sum)[i] : z4; }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = tid + 256 * it;
+      if (i < B4 * 64) {
+        const float4 f = reinterpret_cast<const float4*>(F1)[i];
+        reinterpret_cast<float4*>(DF)[i] = make_float4(f.x > 0.f ? v4[it].x * dscale : 0.f, f.y > 0.f ? v4[it].y * dscale : 0.f,
+                                                       f.z > 0.f ? v4[it].z * dscale : 0.f, f.w > 0.f ? v4[it].w * dscale : 0.f);
+      }
+    }
+  }
+  __syncthreads();
+  tstamp(a.stamps, 17);
+  // ---- d comb for this block's 8 columns (wave w: columns 2w, 2w+1); fusion layer 0's weight gradients of those columns,
+  // its bias gradients of units [4g, 4g+4)
+#pragma unroll 1
+  for (int cc = 0; cc < 2; ++cc) {
+    const int c = 2 * wave + cc;
+    float wb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wb[i] = wB[(lane + 64 * i) * 8 + c];
+#pragma unroll 1
+    for (int b0 = 0; b0 < B; b0 += 4) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(DF[(b0 + j) * 256 + lane + 64 * i], wb[i], acc[j]);
+      wave_sum4(acc);
+      if (lane == 63) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dcombS[(b0 + j) * 8 + c] = acc[j];
+          if (b0 + j < B) a.dcomb[(b0 + j) * 512 + ccol + c] = acc[j];
+        }
+      }
+    }
+  }
+  tstamp(a.stamps, 18);
+  {
+    float gw[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+#pragma unroll 1
+    for (int b0 = 0; b0 < B; b0 += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = DF[(b0 + j) * 256 + tid];
+        const float4 ca = reinterpret_cast<const float4*>(combS)[(b0 + j) * 2], cb = reinterpret_cast<const float4*>(combS)[(b0 + j) * 2 + 1];
+        gw[0] = fmaf(d, ca.x, gw[0]); gw[1] = fmaf(d, ca.y, gw[1]); gw[2] = fmaf(d, ca.z, gw[2]); gw[3] = fmaf(d, ca.w, gw[3]);
+        gw[4] = fmaf(d, cb.x, gw[4]); gw[5] = fmaf(d, cb.y, gw[5]); gw[6] = fmaf(d, cb.z, gw[6]); gw[7] = fmaf(d, cb.w, gw[7]);
+      }
+    }
+    dstfu0[0] = make_float4(gw[0], gw[1], gw[2], gw[3]); dstfu0[1] = make_float4(gw[4], gw[5], gw[6], gw[7]);
+    if (tid < 4) {
+      float s = obfu0;
+#pragma unroll 1
+      for (int b = 0; b < B; ++b) s += DF[b * 256 + 4 * g + tid];
+      a.gbfu0[4 * g + tid] = s;
+    }
+  }
+  __syncthreads();
+  tstamp(a.stamps, 19);
+  // ---- partial sums of d(mean H) of this block's stream (complete when the kernel ends); the pooled FFN layer's weight gradients
+#pragma unroll 1
+  for (int b0 = 0; b0 < B; b0 += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 da = reinterpret_cast<const float4*>(dcombS)[(b0 + j) * 2], db = reinterpret_cast<const float4*>(dcombS)[(b0 + j) * 2 + 1];
+      const float dc[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const float hm = R1[(b0 + j) * 512 + tid + 256 * kk];
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { acc = fmaf(dc[c], w10[kk][c], acc); gw3[kk][c] = fmaf(dc[c], hm, gw3[kk][c]); }
+        if (b0 + j < B) atomicAdd(dHm + (b0 + j) * 512 + tid + 256 * kk, acc);
+      }
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) gW3s[(size_t)(c0 + c) * 512 + tid + 256 * kk] = gw3[kk][c];
+  if (tid < 8) {
+    float s = ob3s;
+#pragma unroll 1
+    for (int b = 0; b < B; ++b) s += dcombS[b * 8 + tid];
+    gb3s[c0 + tid] = s;
+  }
+  tstamp(a.stamps, 20);
+}
+
 // ---------------------------------------------------------------- optimizer
 constexpr int SUMSQ_BLOCKS = 256;
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ out) {
@@ -678,6 +1179,20 @@ int launch_heads_loss(const float* hid, const HeadsOut& hp, const long long* y, 
   if (!heads_loss_ok(B, C)) return (int)hipErrorInvalidValue;
   const int prof = gemm_prof_open(stream, 0.0, PROF_TAIL);
   hipLaunchKernelGGL(heads_loss_kernel, dim3(B), dim3(256), 0, stream, hid, hp, y, e, s, C, Fh, scale, outs, terms, pred, dhid);
+  gemm_prof_close(prof, stream);
+  return (int)hipGetLastError();
+}
+
+int tail_fused_ok(int B, int C) { return B >= 1 && B <= TF_MAXB && C >= 1 && 2 * C + 2 <= TF_MAXW; }
+int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream) {
+  if (!tail_fused_ok(a.B, a.C)) return (int)hipErrorInvalidValue;
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS_FLOATS * 4);
+    return true;
+  }();
+  (void)attr;
+  const int prof = gemm_prof_open(stream, 0.0, PROF_TAIL);
+  hipLaunchKernelGGL(tail_fused_kernel, dim3(TG), dim3(256), TF_LDS_FLOATS * 4, stream, a);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }

@@ -199,6 +199,8 @@ int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int3
 /* camo_debug_set_option: lets a test run two schedules of the same call in one process.
  *   "sched16": -1 (default) choose from the configuration, 0 never take the bf16-resident schedule;
  *   "fused":   -1 (default) choose from the configuration, 0 never take the fused row-tile schedule;
+ *   "tail17":  -1 (default) the per-sample tail runs as one launch where the fused schedule does (B <= 16), 0 never;
+ *   "fused_variant": developer A/B of the fused kernels' weight streaming (0, 1 = default, 2);
  *   "fused_save": 1 makes inference calls of the fused schedule also write the tensors a backward would read
  *              (names for camo_debug_ws_offset: R16 G16 Q16 Q2_16 KV16 KV2_16 O16 O2_16 Y16 Y2_16 XH16 XH2_16 rstd1 rstd2
  *              mask1 mask2 lse2 X16 Wqkv_rg W1s Ymean H1mean Y2mean H2mean). */

@@ -21,7 +21,7 @@ _lib.lib().camo_debug_set_option(b"fused_variant", variant)
 nkg = B * ((max(nrs) + 63) // 64)
 buf = torch.zeros(2 * NB * 8, dtype=torch.int64, device="cuda")
 train = len(sys.argv) > 3 and sys.argv[3] == "train"
-buf = torch.zeros(4 * NB * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(5 * NB * 8, dtype=torch.int64, device="cuda")
 if train:
     model.train()
     y, e, s_ = (torch.from_numpy(x).cuda() for x in make_batches(1, B, 0)[0][3:])
@@ -34,7 +34,20 @@ _lib.lib().camo_debug_set_stamps(buf.data_ptr(), NB)
 step()
 torch.cuda.synchronize()
 _lib.lib().camo_debug_set_stamps(None, 0)
-st = buf.cpu().numpy().reshape(4, NB, 8)
+st = buf.cpu().numpy().reshape(5, NB, 8)
+if train:
+    t = st[4].reshape(-1)[:64 * 32].reshape(64, 32).astype(np.float64)
+    if t[:, 0].min() > 0:
+        t0 = t[:, 0].min()
+        names = {0: "start", 1: "staged", 2: "L1 done", 3: "L2 issued", 4: "AR1 done", 5: "F1 staged", 6: "L3 done", 7: "L4 issued", 8: "AR2 done",
+                 9: "hid staged", 10: "head outputs", 11: "loss", 12: "output-layer grads", 13: "d hidden", 14: "d fused + hidden-layer grads",
+                 15: "d F1 issued", 16: "AR3 done", 17: "dF staged", 18: "d comb", 19: "fusion layer 0 grads", 20: "end"}
+        print("--- tail (one launch): stamp (median / max over the 64 blocks, us from first block start; delta to previous)")
+        prev = 0.0
+        for k in range(21):
+            med = np.median(t[:, k] - t0) / 100
+            print(f"   {names[k]:30s} {med:7.2f} / {(t[:, k] - t0).max() / 100:7.2f}   +{med - prev:5.2f}")
+            prev = med
 for k, name in enumerate(("front", "back", "bwd1", "bwd2") if train else ("front", "back")):
     s = st[k]
     if name == "back":          # KG->RG attention splits: stamps 4 (split done), 5 (ticket drawn), 6 (combine done, last arriver only)

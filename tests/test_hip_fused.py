@@ -26,7 +26,7 @@ def _opt(name, value):
 @pytest.fixture
 def fused_opts():
     yield _opt
-    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1)
+    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1)
 
 
 def bf16_round(x):
@@ -241,3 +241,42 @@ def test_fused_backward_stage_by_stage(training, kg_real, fused_opts):
     assert total < max(5e-2, 1.5 * total16), (total, total16)
     gn = np.sqrt(den)
     assert all(r < max(0.12, 2.5 * total16) for r, n, _ in rels if n > 1e-3 * gn), rels[:6]
+
+
+@pytest.mark.parametrize("training,B", [(False, 9), (True, 16), (True, 1)])
+def test_one_launch_tail_matches_separate_launches(training, B, kg_real, fused_opts):
+    """The per-sample tail as ONE launch of 64 co-resident blocks (misc.hip, tail_fused_kernel: split weights, three in-kernel
+    all-reduces) against the ten separate launches it replaces, on the same fused node-level kernels: outputs, loss terms,
+    predictions and every parameter gradient.  Both tails compute in exact fp32; they differ in summation order only."""
+    cfg = OP.full_cfg()
+    m = make_model(cfg, 4, "bf16")
+    m.train(training)
+    eng = m._engine
+    nrs = (NRS + [300, 77, 512, 40, 333, 9, 128])[:B]
+    rg = np.concatenate([OP.make_rg(n, 128, seed=170 + i) for i, n in enumerate(nrs)])
+    kg = np.stack([kg_real] * B)
+    y, e, s = OP.make_labels(B, seed=15)
+    batch = eng.make_batch(torch.from_numpy(rg).cuda(), nrs, torch.from_numpy(kg).cuda())
+    res = []
+    for mode in (-1, 0):
+        fused_opts("tail17", mode)
+        ws = eng.workspace(batch, private=True)
+        ws.zero_()
+        g = eng.ensure_flat_grads(attach=True)
+        g.zero_()
+        outs, terms, pred = eng.train_raw(batch, ws, torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s), training, 99, eng._gtab)
+        torch.cuda.synchronize()
+        res.append((t2n(outs), t2n(terms), t2n(pred), {k: t2n(p.grad).copy() for k, p in m.named_parameters()}))
+        o_inf, _ = eng.forward_raw(batch, eng.workspace(batch, private=True), training, 99, inference=True)
+        assert_close(t2n(o_inf), t2n(outs), 1e-6, 1e-5, "inference forward (one-launch tail, forward only) vs the training call")
+    fused_opts("tail17", -1)
+    (oa, ta, pa, ga), (ob, tb, pb, gb) = res
+    assert_close(oa, ob, 2e-6, 1e-5, "outputs")
+    assert_close(ta, tb, 2e-6, 1e-5, "loss terms")
+    assert np.array_equal(pa, pb)
+    for k in ga:
+        scale = max(float(np.abs(gb[k]).max()), 1e-8)
+        # node-level gradients pass through bf16 operands: a 1-ulp fp32 difference in d(mean H) can flip a bf16 rounding
+        # (tail tensors: fp32 sums in another order -- a gradient that is a small difference of large terms moves by ~1e-4 of itself)
+        tol = 3e-4 if (k.startswith(("mask_head", "instance_head", "edge_head", "score_head")) or "fusion_layer" in k or ".3." in k) else 4e-3
+        assert float(np.abs(ga[k] - gb[k]).max()) <= tol * scale + 2e-7, (k, float(np.abs(ga[k] - gb[k]).max()), scale)
