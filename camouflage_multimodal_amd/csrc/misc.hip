@@ -576,14 +576,6 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
     for (int i = 0; i < 8; ++i) w1[cc][i] = W3s[(size_t)(c0 + 2 * wave + cc) * 512 + lane + 64 * i];      // L1: rows of this wave's 2 columns
 #pragma unroll
   for (int i = 0; i < 4; ++i) w3r[i] = a.Wfu3[(size_t)(4 * g + wave) * 256 + lane + 64 * i];              // L3: row of this wave's column
-#pragma unroll
-  for (int c = 0; c < 4; ++c) w8r[c] = a.Wfu3[(size_t)(4 * g + c) * 256 + tid];                           // d F1: rows 4g.., column tid
-  if (a.mode) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) w10[kk][c] = W3s[(size_t)(c0 + c) * 512 + tid + 256 * kk];              // d(mean H): column tid (+256)
-  }
   float4 hv[8];
 #pragma unroll
   for (int it = 0; it < 8; ++it) { const int i = tid + 256 * it; hv[it] = i < B * 128 ? reinterpret_cast<const float4*>(Hmean)[i] : z4; }
@@ -611,7 +603,6 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
   const float bias2 = g == 0 ? a.bfu0[tid] : 0.f;
   const float bias3 = a.bfu3[4 * g + wave];
   const float bias4a = g == 0 ? headB0(tid >> 7)[tid & 127] : 0.f, bias4b = g == 0 ? headB0(2 + (tid >> 7))[tid & 127] : 0.f;
-  // old values of every gradient this block adds to (mode 1): fetched now, so that no += later waits for its read
   const int hx = (8 * g) >> 7, hmm0 = (8 * g) & 127, hnout = hx < 2 ? C : 1, hcoff = hx == 0 ? 0 : (hx == 1 ? C : (hx == 2 ? 2 * C : 2 * C + 1));
   float* dW3h = gheadW3(hx) + (size_t)(tid >> 3) * 128 + hmm0 + (tid & 7);
   float4* dst0 = reinterpret_cast<float4*>(gheadW0(tid >> 7) + (size_t)(tid & 127) * 256 + 4 * g);
@@ -619,15 +610,6 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
   float4* dstfu0 = reinterpret_cast<float4*>(a.gWfu0 + (size_t)tid * 512 + ccol);
   float oW3h = 0.f, ob3h = 0.f, ob0h = 0.f, obfu3 = 0.f, obfu0 = 0.f, ob3s = 0.f, gwfu3[4] = {0.f, 0.f, 0.f, 0.f};
   float4 g0 = z4, g1 = z4;
-  if (a.mode) {
-    if (tid < hnout * 8) oW3h = *dW3h;
-    if (g == 0 && tid >= 128 && tid < 128 + Wd) { int xx, oo; head_of(tid - 128, xx, oo); ob3h = gheadB3(xx)[oo]; }
-    g0 = *dst0; g1 = *dst1;
-    if (tid < 8) { ob0h = gheadB0((8 * g + tid) >> 7)[(8 * g + tid) & 127]; ob3s = gb3s[c0 + tid]; }
-    if (tid < 4) { obfu3 = a.gbfu3[4 * g + tid]; obfu0 = a.gbfu0[4 * g + tid]; }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) gwfu3[c] = a.gWfu3[(size_t)(4 * g + c) * 256 + tid];
-  }
 #pragma unroll
   for (int it = 0; it < 8; ++it) { const int i = tid + 256 * it; if (i < B4 * 128) reinterpret_cast<float4*>(R1)[i] = hv[it]; }
 #pragma unroll
@@ -667,6 +649,25 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
         if (b0 + j < B) atomicAdd(a.F1sum + (b0 + j) * 256 + tid, acc);
       }
     }
+  }
+  // operands of the backward and the old values of every gradient this block adds to: fetched while the all-reduce is in
+  // flight, so that no += later waits for its read
+  if (a.mode) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w8r[c] = a.Wfu3[(size_t)(4 * g + c) * 256 + tid];                         // d F1: rows 4g.., column tid
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w10[kk][c] = W3s[(size_t)(c0 + c) * 512 + tid + 256 * kk];              // d(mean H): column tid (+256)
+  }
+  if (a.mode) {
+    if (tid < hnout * 8) oW3h = *dW3h;
+    if (g == 0 && tid >= 128 && tid < 128 + Wd) { int xx, oo; head_of(tid - 128, xx, oo); ob3h = gheadB3(xx)[oo]; }
+    g0 = *dst0; g1 = *dst1;
+    if (tid < 8) { ob0h = gheadB0((8 * g + tid) >> 7)[(8 * g + tid) & 127]; ob3s = gb3s[c0 + tid]; }
+    if (tid < 4) { obfu3 = a.gbfu3[4 * g + tid]; obfu0 = a.gbfu0[4 * g + tid]; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gwfu3[c] = a.gWfu3[(size_t)(4 * g + c) * 256 + tid];
   }
   tstamp(a.stamps, 3);
   tail_arrive_wait(a.counters + 0, a.counters + 3);
