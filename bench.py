@@ -133,6 +133,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event roofline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward / batch-sweep / f32 legs (single-GPU runs only)")
+    ap.add_argument("--allreduce", default="bucketed", choices=["bucketed", "single"],
+                    help="gradient all-reduce for --gpus N > 1: two buckets, the first overlapped with the node-level backward "
+                         "(default), or one flat all-reduce after it")
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus N > 1 (nccl = RCCL; gloo lets a "
                     "one-GPU box rehearse the multi-rank path with every rank on the same device)")
     args = ap.parse_args()
@@ -140,7 +143,7 @@ def main():
     import torch
     import torch.distributed as dist
     from camouflage_multimodal_amd import NativeTrainer, build_multimodal_model, _lib
-    from camouflage_multimodal_amd.ddp import GradAllReducer, broadcast_parameters
+    from camouflage_multimodal_amd.ddp import BucketedGradAllReducer, GradAllReducer, broadcast_parameters
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -163,7 +166,7 @@ def main():
     model = build_multimodal_model({}).to(dev).set_precision(args.precision).train()   # reference defaults, dropout 0.3
     if world > 1:
         broadcast_parameters(model._engine.flat_params)
-    trainer = NativeTrainer(model, lr=5e-4, weight_decay=1e-4, grad_allreduce=GradAllReducer() if world > 1 else None)
+    trainer = NativeTrainer(model, lr=5e-4, weight_decay=1e-4, grad_allreduce=(BucketedGradAllReducer() if args.allreduce == "bucketed" else GradAllReducer()) if world > 1 else None)
 
     host = make_batches(8, args.batch, rank)
     batches = [(torch.from_numpy(rg).to(dev), nrs, torch.from_numpy(kg).to(dev), torch.from_numpy(y).to(dev),
@@ -328,7 +331,7 @@ def main():
                                    "model, packed variable-Nr minibatch (Nr ~ real 303..530 histogram, mean %.0f), "
                                    "Nk=13 real KG rows, train mode dropout 0.3, random-init weights" % nr_mean,
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "rg_dim": 128, "hidden_dim": 256,
-                       "num_heads": 8, "parallelism": f"dp{world}",
+                       "num_heads": 8, "parallelism": f"dp{world}", "grad_allreduce": (args.allreduce if world > 1 else None),
                        "precision": "bf16 MFMA operands, fp32 accumulate/optimizer" if args.precision == "bf16"
                                     else "fp32 (f32-input MFMA)"},
         }

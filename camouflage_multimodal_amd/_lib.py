@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcamo_fusion.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 FWD_INFERENCE = 1
 FLAG_ATTN_MAPS = 2
 SUMSQ_FLOATS = 257
@@ -79,7 +79,7 @@ def lib():
     L.camo_clip_adamw.argtypes = [vp, vp, vp, vp, sz, vp, f32, f32, f32, f32, f32, f32, i32, i32, vp]
     L.camo_forward_loss_backward.restype = C.c_int
     L.camo_forward_loss_backward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz,
-                                             vp, vp, vp, vp, vp, vp, i32, C.c_uint64, i32, vp]
+                                             vp, vp, vp, vp, vp, vp, i32, C.c_uint64, i32, vp, vp]
     L.camo_rg_workspace_bytes.restype = sz
     L.camo_rg_workspace_bytes.argtypes = [C.POINTER(CamoRgDims), i32]
     L.camo_rg_build_csr.restype = C.c_int

@@ -827,6 +827,16 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
                       attn_rg2kg, attn_kg2rg, training, seed, precision, flags, stream, nullptr);
 }
 
+// camo_forward_loss_backward's optional event: recorded on the stream as soon as the gradients of the per-sample tail (pooled
+// FFN layers, fusion layer, heads: parameters CAMO_P_F2_W3 .. end of the table, and CAMO_P_F1_W3/B3) are final, so that a
+// data-parallel caller can start reducing that part of the flat buffer while the node-level backward runs.
+static thread_local hipEvent_t t_tail_event = nullptr;
+static int record_tail_event(hipStream_t st) {
+  if (!t_tail_event) return 0;
+  const hipEvent_t ev = t_tail_event; t_tail_event = nullptr;
+  return (int)hipEventRecord(ev, st);
+}
+
 static int backward_impl(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
                          const int32_t* rg_offsets, const void* desc, const float* kg, int32_t B,
                          int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes, const float* outs,
@@ -881,6 +891,7 @@ static int backward_impl(const camo_dims_t* dims, const float* const* params, fl
   gt.tn(w.dcomb, 2 * H, w.H1mean, 2 * H, Gr[CAMO_P_F1_W3], 2 * H, Gr[CAMO_P_F1_B3], H, 2 * H, B);
   gt.tn(w.dcomb + H, 2 * H, w.H2mean, 2 * H, Gr[CAMO_P_F2_W3], 2 * H, Gr[CAMO_P_F2_B3], H, 2 * H, B);
   CK(gt.run(), "ffn layer 3 bwd (pooled)");
+  CK(record_tail_event(st), "tail event");
   if (!(flags & CAMO_FLAG_ATTN_MAPS) && fused17_ok(d, P, precision, Nk, max_nr))
     return backward_nodes17(d, P, Gr, rg_offsets, bd, B, T, Nk, w, drop, st);
   if (sched16_ok(d, P, precision, T, Nk, max_nr))
@@ -936,12 +947,31 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
                        d_outs, d_outs_pre_activation, training, seed, precision, flags, stream, false);
 }
 
+static int forward_loss_backward_impl(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
+                               const int32_t* rg_offsets, const void* batch_desc, const float* kg,
+                               int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes,
+                               const int64_t* y, const float* e, const float* s, float* outs, float* loss_terms, int32_t* pred,
+                               int32_t training, uint64_t seed, int32_t precision, void* stream);
+
 int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
                                const int32_t* rg_offsets, const void* batch_desc, const float* kg,
                                int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes,
                                const int64_t* y, const float* e, const float* s, float* outs, float* loss_terms, int32_t* pred,
-                               int32_t training, uint64_t seed, int32_t precision, void* stream) {
+                               int32_t training, uint64_t seed, int32_t precision, void* tail_event, void* stream) {
   if (!dims || !grads || !y || !e || !s || !outs || !loss_terms) return fail(CAMO_E_ARG, "null pointer argument");
+  t_tail_event = static_cast<hipEvent_t>(tail_event);
+  const int rc = forward_loss_backward_impl(dims, params, grads, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace,
+                                            workspace_bytes, y, e, s, outs, loss_terms, pred, training, seed, precision, stream);
+  if (rc == 0) { CK(record_tail_event(static_cast<hipStream_t>(stream)), "tail event"); }   // (schedules without an early point)
+  t_tail_event = nullptr;
+  return rc;
+}
+
+static int forward_loss_backward_impl(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
+                               const int32_t* rg_offsets, const void* batch_desc, const float* kg,
+                               int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes,
+                               const int64_t* y, const float* e, const float* s, float* outs, float* loss_terms, int32_t* pred,
+                               int32_t training, uint64_t seed, int32_t precision, void* stream) {
   const int head0 = dims->fusion_type == CAMO_FUSION_LATE ? CAMO_PL_HEADS : CAMO_P_HEADS;
   const bool fuse = heads_loss_ok(B, dims->num_classes);
   if (g_opt_tail17 != 0 && params && !check_dims(dims, B, T, Nk) && fused17_ok(*dims, params, precision, Nk, max_nr) &&
@@ -952,6 +982,7 @@ int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* para
                               nullptr, nullptr, training, seed, precision, 0, stream, nullptr, &fl)) return rc;
     const Ws w = carve(*dims, B, T, Nk, workspace);
     const Desc bd = desc_carve(B, T, const_cast<void*>(batch_desc));
+    CK(record_tail_event(static_cast<hipStream_t>(stream)), "tail event");
     return backward_nodes17(*dims, params, grads, rg_offsets, bd, B, T, Nk, w, make_drop(training, dims->dropout, seed),
                             static_cast<hipStream_t>(stream));
   }

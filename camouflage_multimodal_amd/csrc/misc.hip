@@ -525,20 +525,26 @@ constexpr int TF_MAXB = 16;
 constexpr int TF_MAXW = 18;           // 2 * num_classes + 2 (num_classes <= 8)
 constexpr int TF_LDS_FLOATS = 2 * TF_MAXB * 512 + 2 * TF_MAXB * 256 + 2048 + 2048 + 3 * 128 + 64 + 64 + 2 * TF_MAXB * TF_MAXW + TF_MAXW * 129;
 
-// The kernel runs once per step on 64 CUs that have just run other code: every instruction is an instruction-cache miss the
-// first time it executes, so the code is kept SMALL -- loops over the samples stay loops, 4 samples per trip (the LDS images
-// are padded with zero rows to a multiple of 4 samples) so that four independent chains hide the LDS latency; every
-// global read whose address is known early is issued early, and the passes that fetch an all-reduce's result have all
-// their loads in flight together.
+// The kernel runs once per step on 64 CUs that have just run other code, one block per CU: what it costs is latency, not
+// throughput.  So: 1024 threads -- four "quarters" of 256 threads, quarter q walking samples 4q..4q+3 through every
+// per-sample phase (four independent chains per thread hide the LDS latency, four waves per SIMD hide each other's), and
+// the sums over the batch (weight gradients) split by output column between the quarters instead; every global read whose
+// address is known early is issued early (one memory round trip at the start, a second one hidden behind the first
+// all-reduce), and the passes that fetch an all-reduce's result have all their loads in flight together.  The LDS images
+// are padded with zero rows to a multiple of 4 samples.
 __device__ __forceinline__ void wave_sum4(float (&acc)[4]) {           // totals valid in lane 63
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = wave_sum_lane63(acc[j]);
 }
 
-__global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) {
+constexpr int TF_THREADS = 1024;
+
+__global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x, B = a.B, C = a.C, Wd = 2 * C + 2;
-  const int B4 = (B + 3) & ~3;
+  const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x, B = a.B, C = a.C, Wd = 2 * C + 2;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 8), t = tid & 255, wv = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+  const int b0 = 4 * q, B4 = (B + 3) & ~3;
+  const bool active = b0 < B;                               // (wave-uniform)
   float* R1 = sm;                       // [16][512] pooled FFN activations of this block's stream (kept to the end)
   float* R2 = R1 + TF_MAXB * 512;       // [16][512] the heads' hidden activations, then (in place) the gradient of their pre-activations
   float* F1 = R2 + TF_MAXB * 512;       // [16][256] fusion layer 0 activations (after ReLU and dropout)
@@ -568,30 +574,28 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
   };
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   tstamp(a.stamps, 0);
-  // ---- every global read that depends on nothing: issued now, one memory round trip for all of them
-  float w1[2][8], w3r[4], w8r[4], w10[2][8];
+  // ---- every global read of the forward that depends on nothing: issued now, one memory round trip for all of them
+  float w1[2][8], w3r[4];
 #pragma unroll
   for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) w1[cc][i] = W3s[(size_t)(c0 + 2 * wave + cc) * 512 + lane + 64 * i];      // L1: rows of this wave's 2 columns
+    for (int i = 0; i < 8; ++i) w1[cc][i] = W3s[(size_t)(c0 + 2 * wv + cc) * 512 + lane + 64 * i];        // L1: rows of this wave's 2 columns
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w3r[i] = a.Wfu3[(size_t)(4 * g + wave) * 256 + lane + 64 * i];              // L3: row of this wave's column
-  float4 hv[8];
+  for (int i = 0; i < 4; ++i) w3r[i] = a.Wfu3[(size_t)(4 * g + wv) * 256 + lane + 64 * i];                // L3: row of this wave's column
+  float4 hv[2];
 #pragma unroll
-  for (int it = 0; it < 8; ++it) { const int i = tid + 256 * it; hv[it] = i < B * 128 ? reinterpret_cast<const float4*>(Hmean)[i] : z4; }
-  {
-    const float4* p = reinterpret_cast<const float4*>(a.Wfu0 + (size_t)tid * 512 + ccol);
-    reinterpret_cast<float4*>(wB)[2 * tid] = p[0]; reinterpret_cast<float4*>(wB)[2 * tid + 1] = p[1];
-  }
-#pragma unroll
-  for (int mm = 0; mm < 2; ++mm) {
-    const int m = tid + 256 * mm;
+  for (int it = 0; it < 2; ++it) { const int i = tid + TF_THREADS * it; hv[it] = i < B * 128 ? reinterpret_cast<const float4*>(Hmean)[i] : z4; }
+  if (q == 0) {
+    const float4* p = reinterpret_cast<const float4*>(a.Wfu0 + (size_t)t * 512 + ccol);
+    reinterpret_cast<float4*>(wB)[2 * t] = p[0]; reinterpret_cast<float4*>(wB)[2 * t + 1] = p[1];
+  } else if (q < 3) {
+    const int m = tid - 256;
     reinterpret_cast<float4*>(wA)[m] = *reinterpret_cast<const float4*>(headW0(m >> 7) + (size_t)(m & 127) * 256 + 4 * g);
   }
-  float w3v[10];                                             // (Wd * 129 <= 2322 elements: at most 10 per thread, all in flight)
+  float w3v[3];                                              // (Wd * 129 <= 2322 elements: at most 3 per thread)
 #pragma unroll
-  for (int it = 0; it < 10; ++it) {
-    const int p = tid + 256 * it;
+  for (int it = 0; it < 3; ++it) {
+    const int p = tid + TF_THREADS * it;
     w3v[it] = 0.f;
     if (p < Wd * 129) {
       const int o = p / 129, k = p - 129 * o;
@@ -600,27 +604,47 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
     }
   }
   if (tid < 128) ymS[tid] = tid < B * 8 ? Ymean[(tid >> 3) * 256 + c0 + (tid & 7)] + b3s[c0 + (tid & 7)] : 0.f;
-  const float bias2 = g == 0 ? a.bfu0[tid] : 0.f;
-  const float bias3 = a.bfu3[4 * g + wave];
-  const float bias4a = g == 0 ? headB0(tid >> 7)[tid & 127] : 0.f, bias4b = g == 0 ? headB0(2 + (tid >> 7))[tid & 127] : 0.f;
+  const float bias2 = g == 0 ? a.bfu0[t] : 0.f;
+  const float bias3 = a.bfu3[4 * g + wv];
+  const float bias4a = g == 0 ? headB0(t >> 7)[t & 127] : 0.f, bias4b = g == 0 ? headB0(2 + (t >> 7))[t & 127] : 0.f;
+  // operands of the backward and the old values of every gradient this block adds to: issued behind the forward's
+  // reads (loads return in order: the forward never waits for these), so that no += later waits for its read.  The sums over the batch are split between the quarters by column:
+  //   hidden-layer weights [512 m][4 c]: m = t + 256 (q & 1), columns 2 (q >> 1), +1;  fusion layer 3 [256 n][4 c]: column q;
+  //   fusion layer 0 [256 n][8 c]: columns 2q, 2q + 1;  pooled FFN layer [512 k][8 c]: k = t + 256 (q & 1), columns 4 (q >> 1)..+3
+  const int qm = t + 256 * (q & 1), qh = q >> 1;
   const int hx = (8 * g) >> 7, hmm0 = (8 * g) & 127, hnout = hx < 2 ? C : 1, hcoff = hx == 0 ? 0 : (hx == 1 ? C : (hx == 2 ? 2 * C : 2 * C + 1));
   float* dW3h = gheadW3(hx) + (size_t)(tid >> 3) * 128 + hmm0 + (tid & 7);
-  float4* dst0 = reinterpret_cast<float4*>(gheadW0(tid >> 7) + (size_t)(tid & 127) * 256 + 4 * g);
-  float4* dst1 = reinterpret_cast<float4*>(gheadW0(2 + (tid >> 7)) + (size_t)(tid & 127) * 256 + 4 * g);
-  float4* dstfu0 = reinterpret_cast<float4*>(a.gWfu0 + (size_t)tid * 512 + ccol);
-  float oW3h = 0.f, ob3h = 0.f, ob0h = 0.f, obfu3 = 0.f, obfu0 = 0.f, ob3s = 0.f, gwfu3[4] = {0.f, 0.f, 0.f, 0.f};
-  float4 g0 = z4, g1 = z4;
+  float2* dstW0 = reinterpret_cast<float2*>(gheadW0(qm >> 7) + (size_t)(qm & 127) * 256 + 4 * g + 2 * qh);
+  float* dstfu3 = a.gWfu3 + (size_t)(4 * g + q) * 256 + t;
+  float2* dstfu0 = reinterpret_cast<float2*>(a.gWfu0 + (size_t)t * 512 + ccol + 2 * q);
+  float w8r[4], w10[2][8];
+  float oW3h = 0.f, ob3h = 0.f, ob0h = 0.f, obfu3 = 0.f, obfu0 = 0.f, ob3s = 0.f, ofu3 = 0.f, ogw3[4] = {0.f, 0.f, 0.f, 0.f};
+  float2 oW0 = make_float2(0.f, 0.f), ofu0 = make_float2(0.f, 0.f);
+  if (a.mode) {
 #pragma unroll
-  for (int it = 0; it < 8; ++it) { const int i = tid + 256 * it; if (i < B4 * 128) reinterpret_cast<float4*>(R1)[i] = hv[it]; }
+    for (int c = 0; c < 4; ++c) w8r[c] = a.Wfu3[(size_t)(4 * g + c) * 256 + t];                           // d F1: rows 4g.., column t
 #pragma unroll
-  for (int it = 0; it < 10; ++it) { const int p = tid + 256 * it; if (p < Wd * 129) w3s[p] = w3v[it]; }
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w10[kk][c] = W3s[(size_t)(c0 + c) * 512 + t + 256 * kk];                // d(mean H): column t (+256)
+    if (tid < hnout * 8) oW3h = *dW3h;
+    if (g == 0 && tid >= 128 && tid < 128 + Wd) { int xx, oo; head_of(tid - 128, xx, oo); ob3h = gheadB3(xx)[oo]; }
+    oW0 = *dstW0; ofu3 = *dstfu3; ofu0 = *dstfu0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ogw3[c] = gW3s[(size_t)(c0 + 4 * qh + c) * 512 + qm];
+    if (tid < 8) { ob0h = gheadB0((8 * g + tid) >> 7)[(8 * g + tid) & 127]; ob3s = gb3s[c0 + tid]; }
+    if (tid < 4) { obfu3 = a.gbfu3[4 * g + tid]; obfu0 = a.gbfu0[4 * g + tid]; }
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) { const int i = tid + TF_THREADS * it; if (i < B4 * 128) reinterpret_cast<float4*>(R1)[i] = hv[it]; }
+#pragma unroll
+  for (int it = 0; it < 3; ++it) { const int p = tid + TF_THREADS * it; if (p < Wd * 129) w3s[p] = w3v[it]; }
   __syncthreads();
   tstamp(a.stamps, 1);
-  // ---- L1 (by output column): comb[b][c] = mean Y + (mean H) . W3^T + b3, c in this block's 8 columns; wave w: columns 2w, 2w+1
+  // ---- L1 (by output column): comb[b][c] = mean Y + (mean H) . W3^T + b3, c in this block's 8 columns; wave wv: columns 2wv, 2wv+1
+  if (active) {
 #pragma unroll
-  for (int cc = 0; cc < 2; ++cc) {
-#pragma unroll 1
-    for (int b0 = 0; b0 < B; b0 += 4) {
+    for (int cc = 0; cc < 2; ++cc) {
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -629,71 +653,42 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
       wave_sum4(acc);
       if (lane == 63) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) combS[(b0 + j) * 8 + 2 * wave + cc] = acc[j] + ymS[(b0 + j) * 8 + 2 * wave + cc];
+        for (int j = 0; j < 4; ++j) combS[(b0 + j) * 8 + 2 * wv + cc] = acc[j] + ymS[(b0 + j) * 8 + 2 * wv + cc];
       }
     }
   }
   __syncthreads();
   tstamp(a.stamps, 2);
-  // ---- L2 (by input column): partial sums of fusion layer 0's 256 outputs; thread n owns output n
-  {
+  // ---- L2 (by input column): partial sums of fusion layer 0's 256 outputs; thread t owns output t
+  if (active) {
     float w8[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) w8[c] = wB[tid * 8 + c];
-#pragma unroll 1
-    for (int b0 = 0; b0 < B; b0 += 4) {
+    for (int c = 0; c < 8; ++c) w8[c] = wB[t * 8 + c];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 ca = reinterpret_cast<const float4*>(combS)[(b0 + j) * 2], cb = reinterpret_cast<const float4*>(combS)[(b0 + j) * 2 + 1];
-        const float acc = bias2 + w8[0] * ca.x + w8[1] * ca.y + w8[2] * ca.z + w8[3] * ca.w + w8[4] * cb.x + w8[5] * cb.y + w8[6] * cb.z + w8[7] * cb.w;
-        if (b0 + j < B) atomicAdd(a.F1sum + (b0 + j) * 256 + tid, acc);
-      }
+    for (int j = 0; j < 4; ++j) {
+      const float4 ca = reinterpret_cast<const float4*>(combS)[(b0 + j) * 2], cb = reinterpret_cast<const float4*>(combS)[(b0 + j) * 2 + 1];
+      const float acc = bias2 + w8[0] * ca.x + w8[1] * ca.y + w8[2] * ca.z + w8[3] * ca.w + w8[4] * cb.x + w8[5] * cb.y + w8[6] * cb.z + w8[7] * cb.w;
+      if (b0 + j < B) atomicAdd(a.F1sum + (b0 + j) * 256 + t, acc);
     }
-  }
-  // operands of the backward and the old values of every gradient this block adds to: fetched while the all-reduce is in
-  // flight, so that no += later waits for its read
-  if (a.mode) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) w8r[c] = a.Wfu3[(size_t)(4 * g + c) * 256 + tid];                         // d F1: rows 4g.., column tid
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) w10[kk][c] = W3s[(size_t)(c0 + c) * 512 + tid + 256 * kk];              // d(mean H): column tid (+256)
-  }
-  if (a.mode) {
-    if (tid < hnout * 8) oW3h = *dW3h;
-    if (g == 0 && tid >= 128 && tid < 128 + Wd) { int xx, oo; head_of(tid - 128, xx, oo); ob3h = gheadB3(xx)[oo]; }
-    g0 = *dst0; g1 = *dst1;
-    if (tid < 8) { ob0h = gheadB0((8 * g + tid) >> 7)[(8 * g + tid) & 127]; ob3s = gb3s[c0 + tid]; }
-    if (tid < 4) { obfu3 = a.gbfu3[4 * g + tid]; obfu0 = a.gbfu0[4 * g + tid]; }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) gwfu3[c] = a.gWfu3[(size_t)(4 * g + c) * 256 + tid];
   }
   tstamp(a.stamps, 3);
   tail_arrive_wait(a.counters + 0, a.counters + 3);
   tstamp(a.stamps, 4);
   {
-    float4 v4[4];
+    const float4 v4 = tid < B * 64 ? reinterpret_cast<const float4*>(a.F1sum)[tid] : z4;
+    if (tid < B4 * 64) {
+      float v[4] = {fmaxf(v4.x, 0.f), fmaxf(v4.y, 0.f), fmaxf(v4.z, 0.f), fmaxf(v4.w, 0.f)};
+      if (dodrop) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) { const int i = tid + 256 * it; v4[it] = i < B * 64 ? reinterpret_cast<const float4*>(a.F1sum)[i] : z4; }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int i = tid + 256 * it;
-      if (i < B4 * 64) {
-        float v[4] = {fmaxf(v4[it].x, 0.f), fmaxf(v4[it].y, 0.f), fmaxf(v4[it].z, 0.f), fmaxf(v4[it].w, 0.f)};
-        if (dodrop) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= drop_mult(a.drop, SITE_FUSE, (uint32_t)(4 * i + e));    // (element index b * 256 + n)
-        }
-        reinterpret_cast<float4*>(F1)[i] = make_float4(v[0], v[1], v[2], v[3]);
+        for (int e = 0; e < 4; ++e) v[e] *= drop_mult(a.drop, SITE_FUSE, (uint32_t)(4 * tid + e));        // (element index b * 256 + n)
       }
+      reinterpret_cast<float4*>(F1)[tid] = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
   __syncthreads();
   tstamp(a.stamps, 5);
-  // ---- L3 (by output column): fused[b][4g + w], wave w
-#pragma unroll 1
-  for (int b0 = 0; b0 < B; b0 += 4) {
+  // ---- L3 (by output column): fused[b][4g + wv], wave wv
+  if (active) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -702,23 +697,20 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
     wave_sum4(acc);
     if (lane == 63) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fusedS[(b0 + j) * 4 + wave] = acc[j] + bias3;
+      for (int j = 0; j < 4; ++j) fusedS[(b0 + j) * 4 + wv] = acc[j] + bias3;
     }
   }
   __syncthreads();
   tstamp(a.stamps, 6);
   // ---- L4 (by input column): partial sums of the 4 x 128 hidden units of the heads; thread t owns units t and t + 256
-  {
-    const float4 wa0 = reinterpret_cast<const float4*>(wA)[tid], wa1 = reinterpret_cast<const float4*>(wA)[tid + 256];
-#pragma unroll 1
-    for (int b0 = 0; b0 < B; b0 += 4) {
+  if (active) {
+    const float4 wa0 = reinterpret_cast<const float4*>(wA)[t], wa1 = reinterpret_cast<const float4*>(wA)[t + 256];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 f = reinterpret_cast<const float4*>(fusedS)[b0 + j];
-        if (b0 + j < B) {
-          atomicAdd(a.hidsum + (b0 + j) * 512 + tid, bias4a + wa0.x * f.x + wa0.y * f.y + wa0.z * f.z + wa0.w * f.w);
-          atomicAdd(a.hidsum + (b0 + j) * 512 + tid + 256, bias4b + wa1.x * f.x + wa1.y * f.y + wa1.z * f.z + wa1.w * f.w);
-        }
+    for (int j = 0; j < 4; ++j) {
+      const float4 f = reinterpret_cast<const float4*>(fusedS)[b0 + j];
+      if (b0 + j < B) {
+        atomicAdd(a.hidsum + (b0 + j) * 512 + t, bias4a + wa0.x * f.x + wa0.y * f.y + wa0.z * f.z + wa0.w * f.w);
+        atomicAdd(a.hidsum + (b0 + j) * 512 + t + 256, bias4b + wa1.x * f.x + wa1.y * f.y + wa1.z * f.z + wa1.w * f.w);
       }
     }
   }
@@ -726,12 +718,12 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
   tail_arrive_wait(a.counters + 1, a.counters + 3);
   tstamp(a.stamps, 8);
   {
-    float4 v4[8];
+    float4 v4[2];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) { const int i = tid + 256 * it; v4[it] = i < B * 128 ? reinterpret_cast<const float4*>(a.hidsum)[i] : z4; }
+    for (int it = 0; it < 2; ++it) { const int i = tid + TF_THREADS * it; v4[it] = i < B * 128 ? reinterpret_cast<const float4*>(a.hidsum)[i] : z4; }
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int i = tid + 256 * it;
+    for (int it = 0; it < 2; ++it) {
+      const int i = tid + TF_THREADS * it;
       if (i < B4 * 128) {
         float v[4] = {fmaxf(v4[it].x, 0.f), fmaxf(v4[it].y, 0.f), fmaxf(v4[it].z, 0.f), fmaxf(v4[it].w, 0.f)};
         if (dodrop) {
@@ -744,13 +736,11 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
     }
   }
   if (tid < TF_MAXB * TF_MAXW) dpre[tid] = 0.f;            // (rows past B stay zero)
-  if (tid + 256 < TF_MAXB * TF_MAXW) dpre[tid + 256] = 0.f;
   __syncthreads();
   tstamp(a.stamps, 9);
   // ---- head output layers (every block; operands in LDS), loss
-#pragma unroll 1
-  for (int p = tid; p < B * Wd; p += 256) {
-    const int b = p / Wd, o = p - b * Wd;
+  if (tid < B * Wd) {
+    const int b = tid / Wd, o = tid - b * Wd;
     const int x = o < C ? 0 : (o < 2 * C ? 1 : (o == 2 * C ? 2 : 3));
     const float* wr = w3s + o * 129;
     const float* hr = R2 + b * 512 + x * 128;
@@ -763,7 +753,7 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
     float acc = (acc0 + acc1) + (acc2 + acc3);
     if (x == 3) acc = 1.0f / (1.0f + __expf(-acc));
     outsS[b * TF_MAXW + o] = acc;
-    if (g == 0) a.outs[p] = acc;
+    if (g == 0) a.outs[tid] = acc;
   }
   __syncthreads();
   tstamp(a.stamps, 10);
@@ -780,40 +770,37 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
   tstamp(a.stamps, 11);
   // ---- backward.  Output-layer gradients: block g writes units [8g, 8g+8), block 0 the biases (they need the hidden activations,
   // which the next loop overwrites with their gradient)
-  {
-    if (tid < hnout * 8) {
-      const int o = tid >> 3, mi = tid & 7;
-      float acc = oW3h;
+  if (tid < hnout * 8) {
+    const int o = tid >> 3, mi = tid & 7;
+    float acc = oW3h;
 #pragma unroll 1
-      for (int b0 = 0; b0 < B; b0 += 4)
+    for (int bb = 0; bb < B; bb += 4)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = fmaf(dpre[(b0 + j) * TF_MAXW + hcoff + o], R2[(b0 + j) * 512 + 8 * g + mi], acc);
-      *dW3h = acc;
-    }
-    if (g == 0 && tid >= 128 && tid < 128 + Wd) {
-      const int o = tid - 128;
-      int xx, oo; head_of(o, xx, oo);
-      float acc = ob3h;
+      for (int j = 0; j < 4; ++j) acc = fmaf(dpre[(bb + j) * TF_MAXW + hcoff + o], R2[(bb + j) * 512 + 8 * g + mi], acc);
+    *dW3h = acc;
+  }
+  if (g == 0 && tid >= 128 && tid < 128 + Wd) {
+    const int o = tid - 128;
+    int xx, oo; head_of(o, xx, oo);
+    float acc = ob3h;
 #pragma unroll 1
-      for (int b = 0; b < B; ++b) acc += dpre[b * TF_MAXW + o];
-      gheadB3(xx)[oo] = acc;
-    }
+    for (int b = 0; b < B; ++b) acc += dpre[b * TF_MAXW + o];
+    gheadB3(xx)[oo] = acc;
   }
   __syncthreads();
   tstamp(a.stamps, 12);
-  // d hidden (every block, all 512 units), in place: thread t owns units t, t + 256 of every sample
+  // d hidden (every block, all 512 units), in place: thread t owns units t, t + 256 of its quarter's samples
+  if (active) {
 #pragma unroll
-  for (int mm = 0; mm < 2; ++mm) {
-    const int m = tid + 256 * mm, x = m >> 7, ml = m & 127;
-    const int nout = x < 2 ? C : 1, coff = x == 0 ? 0 : (x == 1 ? C : (x == 2 ? 2 * C : 2 * C + 1));
-#pragma unroll 1
-    for (int b0 = 0; b0 < B; b0 += 4) {
+    for (int mm = 0; mm < 2; ++mm) {
+      const int m = t + 256 * mm, x = m >> 7, ml = m & 127;
+      const int nout = x < 2 ? C : 1, coff = x == 0 ? 0 : (x == 1 ? C : (x == 2 ? 2 * C : 2 * C + 1));
       float d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
       for (int o = 0; o < nout; ++o) {
-        const float wv = w3s[(coff + o) * 129 + ml];
+        const float wv3 = w3s[(coff + o) * 129 + ml];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = fmaf(dpre[(b0 + j) * TF_MAXW + coff + o], wv, d[j]);
+        for (int j = 0; j < 4; ++j) d[j] = fmaf(dpre[(b0 + j) * TF_MAXW + coff + o], wv3, d[j]);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const float hcur = R2[(b0 + j) * 512 + m]; R2[(b0 + j) * 512 + m] = hcur > 0.f ? d[j] * dscale : 0.f; }
@@ -821,33 +808,33 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
   }
   __syncthreads();
   tstamp(a.stamps, 13);
-  // ---- d fused for this block's 4 columns (wave w: column w): sum over the 512 hidden units; the hidden-layer weight
-  // gradients of those 4 columns; hidden-layer bias gradients of units [8g, 8g+8)
+  // ---- d fused for this block's 4 columns (wave wv: column wv): sum over the 512 hidden units; the hidden-layer weight
+  // gradients of those 4 columns (2 per quarter pair); hidden-layer bias gradients of units [8g, 8g+8)
+  if (active) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float wa = wA[(lane + 64 * i) * 4 + wv];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(R2[(b0 + j) * 512 + lane + 64 * i], wa, acc[j]);
+    }
+    wave_sum4(acc);
+    if (lane == 63) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dfusedS[(b0 + j) * 4 + wv] = acc[j];
+    }
+  }
   {
-    float wa[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) wa[i] = wA[(lane + 64 * i) * 4 + wave];
+    float2 gacc = oW0;
 #pragma unroll 1
-    for (int b0 = 0; b0 < B; b0 += 4) {
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(R2[(b0 + j) * 512 + lane + 64 * i], wa[i], acc[j]);
-      wave_sum4(acc);
-      if (lane == 63) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dfusedS[(b0 + j) * 4 + wave] = acc[j];
-      }
+    for (int bb = 0; bb < B; bb += 4)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float4 f = reinterpret_cast<const float4*>(fusedS)[b0 + j];
-        const float d0 = R2[(b0 + j) * 512 + tid], d1 = R2[(b0 + j) * 512 + tid + 256];
-        g0.x = fmaf(d0, f.x, g0.x); g0.y = fmaf(d0, f.y, g0.y); g0.z = fmaf(d0, f.z, g0.z); g0.w = fmaf(d0, f.w, g0.w);
-        g1.x = fmaf(d1, f.x, g1.x); g1.y = fmaf(d1, f.y, g1.y); g1.z = fmaf(d1, f.z, g1.z); g1.w = fmaf(d1, f.w, g1.w);
+        const float d = R2[(bb + j) * 512 + qm];
+        const float2 f = reinterpret_cast<const float2*>(fusedS)[(bb + j) * 2 + qh];
+        gacc.x = fmaf(d, f.x, gacc.x); gacc.y = fmaf(d, f.y, gacc.y);
       }
-    }
-    *dst0 = g0; *dst1 = g1;
+    *dstW0 = gacc;
     if (tid < 8) {
       const int m = 8 * g + tid;
       float s = ob0h;
@@ -859,20 +846,20 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
   __syncthreads();
   tstamp(a.stamps, 14);
   // ---- partial sums of d F1 (fusion layer 3 by its output rows 4g..4g+3); its weight and bias gradients
-  {
-    float gw[4] = {gwfu3[0], gwfu3[1], gwfu3[2], gwfu3[3]};
-#pragma unroll 1
-    for (int b0 = 0; b0 < B; b0 += 4) {
+  if (active) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 df = reinterpret_cast<const float4*>(dfusedS)[b0 + j];
-        const float f1 = F1[(b0 + j) * 256 + tid];
-        gw[0] = fmaf(df.x, f1, gw[0]); gw[1] = fmaf(df.y, f1, gw[1]); gw[2] = fmaf(df.z, f1, gw[2]); gw[3] = fmaf(df.w, f1, gw[3]);
-        if (b0 + j < B) atomicAdd(a.dF1sum + (b0 + j) * 256 + tid, df.x * w8r[0] + df.y * w8r[1] + df.z * w8r[2] + df.w * w8r[3]);
-      }
+    for (int j = 0; j < 4; ++j) {
+      const float4 df = reinterpret_cast<const float4*>(dfusedS)[b0 + j];
+      if (b0 + j < B) atomicAdd(a.dF1sum + (b0 + j) * 256 + t, df.x * w8r[0] + df.y * w8r[1] + df.z * w8r[2] + df.w * w8r[3]);
     }
+  }
+  {
+    float gw = ofu3;
+#pragma unroll 1
+    for (int bb = 0; bb < B; bb += 4)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a.gWfu3[(size_t)(4 * g + c) * 256 + tid] = gw[c];
+      for (int j = 0; j < 4; ++j) gw = fmaf(dfusedS[(bb + j) * 4 + q], F1[(bb + j) * 256 + t], gw);
+    *dstfu3 = gw;
     if (tid < 4) {
       float s = obfu3;
 #pragma unroll 1
@@ -880,47 +867,32 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
       a.gbfu3[4 * g + tid] = s;
     }
   }
-  // (old values of the gradients the last phase adds to: fetched while the all-reduce is in flight)
-  const float4 o0 = dstfu0[0], o1 = dstfu0[1];
-  float gw3[2][8];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) gw3[kk][c] = gW3s[(size_t)(c0 + c) * 512 + tid + 256 * kk];
   tstamp(a.stamps, 15);
   tail_arrive_wait(a.counters + 2, a.counters + 3);
   tstamp(a.stamps, 16);
   {
-    float4 v4[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) { const int i = tid + 256 * it; v4[it] = i < B * 64 ? reinterpret_cast<const float4*>(a.dF1sum)[i] : z4; }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int i = tid + 256 * it;
-      if (i < B4 * 64) {
-        const float4 f = reinterpret_cast<const float4*>(F1)[i];
-        reinterpret_cast<float4*>(DF)[i] = make_float4(f.x > 0.f ? v4[it].x * dscale : 0.f, f.y > 0.f ? v4[it].y * dscale : 0.f,
-                                                       f.z > 0.f ? v4[it].z * dscale : 0.f, f.w > 0.f ? v4[it].w * dscale : 0.f);
-      }
+    const float4 v4 = tid < B * 64 ? reinterpret_cast<const float4*>(a.dF1sum)[tid] : z4;
+    if (tid < B4 * 64) {
+      const float4 f = reinterpret_cast<const float4*>(F1)[tid];
+      reinterpret_cast<float4*>(DF)[tid] = make_float4(f.x > 0.f ? v4.x * dscale : 0.f, f.y > 0.f ? v4.y * dscale : 0.f,
+                                                       f.z > 0.f ? v4.z * dscale : 0.f, f.w > 0.f ? v4.w * dscale : 0.f);
     }
   }
   __syncthreads();
   tstamp(a.stamps, 17);
-  // ---- d comb for this block's 8 columns (wave w: columns 2w, 2w+1); fusion layer 0's weight gradients of those columns,
+  // ---- d comb for this block's 8 columns (wave wv: columns 2wv, 2wv+1); fusion layer 0's weight gradients of those columns,
   // its bias gradients of units [4g, 4g+4)
-#pragma unroll 1
-  for (int cc = 0; cc < 2; ++cc) {
-    const int c = 2 * wave + cc;
-    float wb[4];
+  if (active) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wb[i] = wB[(lane + 64 * i) * 8 + c];
-#pragma unroll 1
-    for (int b0 = 0; b0 < B; b0 += 4) {
+    for (int cc = 0; cc < 2; ++cc) {
+      const int c = 2 * wv + cc;
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        const float wb = wB[(lane + 64 * i) * 8 + c];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(DF[(b0 + j) * 256 + lane + 64 * i], wb[i], acc[j]);
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(DF[(b0 + j) * 256 + lane + 64 * i], wb, acc[j]);
+      }
       wave_sum4(acc);
       if (lane == 63) {
 #pragma unroll
@@ -933,18 +905,16 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
   }
   tstamp(a.stamps, 18);
   {
-    float gw[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+    float2 gw = ofu0;
 #pragma unroll 1
-    for (int b0 = 0; b0 < B; b0 += 4) {
+    for (int bb = 0; bb < B; bb += 4)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float d = DF[(b0 + j) * 256 + tid];
-        const float4 ca = reinterpret_cast<const float4*>(combS)[(b0 + j) * 2], cb = reinterpret_cast<const float4*>(combS)[(b0 + j) * 2 + 1];
-        gw[0] = fmaf(d, ca.x, gw[0]); gw[1] = fmaf(d, ca.y, gw[1]); gw[2] = fmaf(d, ca.z, gw[2]); gw[3] = fmaf(d, ca.w, gw[3]);
-        gw[4] = fmaf(d, cb.x, gw[4]); gw[5] = fmaf(d, cb.y, gw[5]); gw[6] = fmaf(d, cb.z, gw[6]); gw[7] = fmaf(d, cb.w, gw[7]);
+        const float d = DF[(bb + j) * 256 + t];
+        const float2 cv = reinterpret_cast<const float2*>(combS)[(bb + j) * 4 + q];
+        gw.x = fmaf(d, cv.x, gw.x); gw.y = fmaf(d, cv.y, gw.y);
       }
-    }
-    dstfu0[0] = make_float4(gw[0], gw[1], gw[2], gw[3]); dstfu0[1] = make_float4(gw[4], gw[5], gw[6], gw[7]);
+    *dstfu0 = gw;
     if (tid < 4) {
       float s = obfu0;
 #pragma unroll 1
@@ -955,26 +925,31 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailFusedArgs a) 
   __syncthreads();
   tstamp(a.stamps, 19);
   // ---- partial sums of d(mean H) of this block's stream (complete when the kernel ends); the pooled FFN layer's weight gradients
-#pragma unroll 1
-  for (int b0 = 0; b0 < B; b0 += 4) {
+  if (active) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 da = reinterpret_cast<const float4*>(dcombS)[(b0 + j) * 2], db = reinterpret_cast<const float4*>(dcombS)[(b0 + j) * 2 + 1];
-      const float dc[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const float hm = R1[(b0 + j) * 512 + tid + 256 * kk];
-        float acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { acc = fmaf(dc[c], w10[kk][c], acc); gw3[kk][c] = fmaf(dc[c], hm, gw3[kk][c]); }
-        if (b0 + j < B) atomicAdd(dHm + (b0 + j) * 512 + tid + 256 * kk, acc);
+        const float acc = da.x * w10[kk][0] + da.y * w10[kk][1] + da.z * w10[kk][2] + da.w * w10[kk][3] +
+                          db.x * w10[kk][4] + db.y * w10[kk][5] + db.z * w10[kk][6] + db.w * w10[kk][7];
+        if (b0 + j < B) atomicAdd(dHm + (b0 + j) * 512 + t + 256 * kk, acc);
       }
     }
   }
+  {
+    float gw[4] = {ogw3[0], ogw3[1], ogw3[2], ogw3[3]};
+#pragma unroll 1
+    for (int bb = 0; bb < B; bb += 4)
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
+      for (int j = 0; j < 4; ++j) {
+        const float4 dc = reinterpret_cast<const float4*>(dcombS)[(bb + j) * 2 + qh];
+        const float hm = R1[(bb + j) * 512 + qm];
+        gw[0] = fmaf(dc.x, hm, gw[0]); gw[1] = fmaf(dc.y, hm, gw[1]); gw[2] = fmaf(dc.z, hm, gw[2]); gw[3] = fmaf(dc.w, hm, gw[3]);
+      }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) gW3s[(size_t)(c0 + c) * 512 + tid + 256 * kk] = gw3[kk][c];
+    for (int c = 0; c < 4; ++c) gW3s[(size_t)(c0 + 4 * qh + c) * 512 + qm] = gw[c];
+  }
   if (tid < 8) {
     float s = ob3s;
 #pragma unroll 1
@@ -1193,7 +1168,7 @@ int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream) {
   }();
   (void)attr;
   const int prof = gemm_prof_open(stream, 0.0, PROF_TAIL);
-  hipLaunchKernelGGL(tail_fused_kernel, dim3(TG), dim3(256), TF_LDS_FLOATS * 4, stream, a);
+  hipLaunchKernelGGL(tail_fused_kernel, dim3(TG), dim3(TF_THREADS), TF_LDS_FLOATS * 4, stream, a);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }

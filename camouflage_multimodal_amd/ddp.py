@@ -1,6 +1,8 @@
 """Single-node data parallelism for the fusion trainer: one process per GPU, parameters
-replicated, ONE all-reduce of the flat fp32 gradient buffer per optimizer step (RCCL over xGMI
-when the process group's backend is ``nccl``; ``gloo`` on CPU in the tests).
+replicated, the flat fp32 gradient buffer all-reduced once per optimizer step -- in one piece
+(``GradAllReducer``) or in two buckets, the first overlapped with the node-level backward
+(``BucketedGradAllReducer``) -- over RCCL/xGMI when the process group's backend is ``nccl``;
+``gloo`` on CPU in the tests.
 
 Semantics (the reference itself is single-process): the reference's gradients are the
 SUM over the samples of a minibatch, clipped once (train_multimodal.py:238-279).  A global
@@ -28,6 +30,52 @@ class GradAllReducer:
     def __call__(self, flat_grads: torch.Tensor):
         if self.world > 1:
             dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+        return flat_grads
+
+
+class BucketedGradAllReducer(GradAllReducer):
+    """Two buckets instead of one, the first overlapped with the node-level backward.
+
+    The gradients of the per-sample tail (pooled KG FFN layer, fusion layer, heads: ``engine.tail_grad_offset()`` .. end of
+    the flat buffer, ~1/3 of it) are final before the four node-level backward launches start.  The native training call
+    records an event at that point (``camo_forward_loss_backward(tail_event=...)``); bucket A's all-reduce is issued on a
+    side stream behind that event and runs beside the backward kernels, bucket B (everything in front of the offset) is
+    issued behind the whole call.  Both land before the clip: ``wait()`` orders the launch stream behind them.  The sum
+    is the same as the single all-reduce's (a different partition of the same element-wise SUM)."""
+    overlapped = True
+
+    def __init__(self, group=None):
+        super().__init__(group)
+        self._event = None
+        self._side = None
+
+    def tail_event(self, device):
+        """Raw hipEvent_t handle for the training call, or None without a GPU / with a single rank."""
+        if self.world <= 1 or torch.device(device).type != "cuda":
+            return None
+        if self._event is None:
+            with torch.cuda.device(device):
+                self._event = torch.cuda.Event()
+                self._event.record()                         # (the handle exists once the event has been recorded)
+                self._side = torch.cuda.Stream(device)
+        h = self._event.cuda_event
+        return int(getattr(h, "value", h) or 0) or None
+
+    def __call__(self, flat_grads: torch.Tensor, split=None):
+        if self.world <= 1:
+            return flat_grads
+        if not split or split >= flat_grads.numel():
+            return super().__call__(flat_grads)
+        head, tail = flat_grads[:split], flat_grads[split:]
+        if flat_grads.is_cuda and self._event is not None:
+            self._side.wait_event(self._event)
+            with torch.cuda.stream(self._side):
+                wa = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            wb = dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            wa.wait(); wb.wait()
+        else:
+            dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group)
         return flat_grads
 
 

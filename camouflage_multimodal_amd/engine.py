@@ -148,6 +148,14 @@ class FusionEngine:
                     p.grad = self.flat_grads[o:o + n].view(shape)
         return self.flat_grads
 
+    def tail_grad_offset(self):
+        """Offset (in floats) of the first gradient of the per-sample tail's contiguous run in the flat buffer --
+        ``fusion.ffn_kg.3.weight`` (CAMO_P_F2_W3) .. end -- or None when the model has no such run (late fusion)."""
+        for i, name, o, n, shape in self._layout:
+            if name == "fusion.ffn_kg.3.weight":
+                return o
+        return None
+
     def _grad_table(self, gflat):
         tab = (C.c_void_p * len(self.slots))()
         for i, name, o, n, shape in self._layout:
@@ -259,9 +267,11 @@ class FusionEngine:
                                           _lib.FLAG_ATTN_MAPS if had_attention else 0, _stream_ptr(self.device))
         _lib.check(rc, "camo_backward")
 
-    def train_raw(self, batch, ws, mask_label, edge_label, score_label, training, seed, gtab):
+    def train_raw(self, batch, ws, mask_label, edge_label, score_label, training, seed, gtab, tail_event=None):
         """The native training call (camo_forward_loss_backward): forward, the reference's 4-term loss and backward into
-        the flat gradient buffer in one library call.  Returns (outs [B, 2C+2], loss_terms [B, 4], pred int32 [B])."""
+        the flat gradient buffer in one library call.  Returns (outs [B, 2C+2], loss_terms [B, 4], pred int32 [B]).
+        ``tail_event``: raw hipEvent_t handle (int) recorded when the per-sample tail's gradients are final
+        (``tail_grad_offset()`` .. end of the flat buffer): the hook for overlapping the data-parallel all-reduce."""
         mod = self.module()
         dev = batch.rg.device
         check_labels(mask_label, self.dims.num_classes)
@@ -275,7 +285,8 @@ class FusionEngine:
             rc = _lib.lib().camo_forward_loss_backward(
                 C.byref(self.dims), self._ptab, gtab, _ptr(batch.rg), _ptr(batch.offsets), _ptr(batch.desc),
                 _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(y), _ptr(e), _ptr(s),
-                _ptr(outs), _ptr(terms), _ptr(pred), int(bool(training)), seed, _PREC[mod.precision], _stream_ptr(self.device))
+                _ptr(outs), _ptr(terms), _ptr(pred), int(bool(training)), seed, _PREC[mod.precision],
+                C.c_void_p(tail_event) if tail_event else None, _stream_ptr(self.device))
         _lib.check(rc, "camo_forward_loss_backward")
         return outs, terms, pred
 

@@ -192,13 +192,17 @@ class NativeTrainer:
         g = eng.ensure_flat_grads(attach=False)
         if self.keep_grads or not self._grads_clean:
             g.zero_()                                       # optimizer.zero_grad() per minibatch [:239]
+        ar, ev, split = self.grad_allreduce, None, None
+        if self.fused_call and ar is not None and getattr(ar, "overlapped", False):
+            split = eng.tail_grad_offset()
+            ev = ar.tail_event(eng.device) if split else None
         if self.fused_call:
-            _, terms, pred = eng.train_raw(batch, ws, mask_label, edge_label, score_label, training, seed, eng._gtab)
+            _, terms, pred = eng.train_raw(batch, ws, mask_label, edge_label, score_label, training, seed, eng._gtab, tail_event=ev)
         else:
             outs, _ = eng.forward_raw(batch, ws, training, seed)
             terms, d_pre, pred = multitask_loss(outs, mask_label, edge_label, score_label, self.num_classes, pre_activation=True)
             eng.backward_raw(batch, ws, outs, d_pre, training, seed, eng._gtab, pre_activation=True)
-        self.opt.step(allreduce=self.grad_allreduce, zero_grads=not self.keep_grads)
+        self.opt.step(allreduce=(lambda g: ar(g, split=split)) if ev else ar, zero_grads=not self.keep_grads)
         self._grads_clean = not self.keep_grads
         return terms, pred
 

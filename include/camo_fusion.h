@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CAMO_ABI_VERSION 4
+#define CAMO_ABI_VERSION 5
 
 enum {
   CAMO_OK = 0,
@@ -173,12 +173,18 @@ int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sum
  * same results, fewer launches (the head output layer, the loss and that layer's backward run as one kernel).
  * Writes outs [B, 2C+2], loss_terms [B, 4], pred [B] (may be null) and ACCUMULATES into grads like
  * camo_backward.  Stands behind the body of the per-minibatch loop of train_epoch_fixed
- * (train_multimodal.py:245-270) for one packed minibatch. */
+ * (train_multimodal.py:245-270) for one packed minibatch.
+ * tail_event (hipEvent_t, may be null): recorded on `stream` as soon as the gradients of the per-sample tail are final
+ *   -- parameters CAMO_P_F2_W3 .. the end of the table (pooled KG FFN layer, fusion layer, the four heads; one
+ *   contiguous run when the gradients live in one flat buffer in table order) and CAMO_P_F1_W3/B3 -- i.e. before the
+ *   node-level backward launches.  A data-parallel caller starts the all-reduce of that run behind the event and the
+ *   rest behind the call (ddp.py: BucketedGradAllReducer).  Every schedule records it (at the end when it has no
+ *   earlier point: late fusion). */
 int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
                                const int32_t* rg_offsets, const void* batch_desc, const float* kg,
                                int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes,
                                const int64_t* y, const float* e, const float* s, float* outs, float* loss_terms, int32_t* pred,
-                               int32_t training, uint64_t seed, int32_t precision, void* stream);
+                               int32_t training, uint64_t seed, int32_t precision, void* tail_event, void* stream);
 
 /* ---- testing hooks ---------------------------------------------------------
  * Not part of the operator surface; used by tests/ to check kernels in isolation.

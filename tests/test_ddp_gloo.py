@@ -128,3 +128,35 @@ def test_mean_instead_of_sum_would_differ():
     n_sum = FO.clip_grad_norm({k: v.copy() for k, v in g.items()}, 1.0)
     n_mean = FO.clip_grad_norm({k: v / 2 for k, v in g.items()}, 1.0)
     assert n_sum > 1.0 and abs(n_mean - n_sum / 2) < 1e-6 * n_sum   # the clip sees a different norm => different update
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from camouflage_multimodal_amd.ddp import BucketedGradAllReducer, GradAllReducer
+        g = torch.Generator().manual_seed(7 + rank)
+        flat = torch.randn(1000, generator=g)
+        a, b, c = flat.clone(), flat.clone(), flat.clone()
+        GradAllReducer()(a)
+        red = BucketedGradAllReducer()
+        assert red.tail_event("cpu") is None              # no GPU: no event, the two buckets are reduced one after the other
+        red(b, split=640)
+        red(c, split=None)                                 # no split point (late fusion): one piece
+        q.put((rank, a.numpy(), b.numpy(), c.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_all_reduce_is_the_same_sum():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    for rank, a, b, c in res:
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert np.array_equal(res[0][1], res[1][1])
