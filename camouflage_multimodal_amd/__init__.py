@@ -18,9 +18,10 @@ from .train_multimodal import (NativeTrainer, SmartMultimodalDataset, calculate_
                                extract_label_from_mask, fit, pack_samples, train_epoch_fixed, train_multimodal_fixed,
                                validate_fixed)
 
-from .region_graph import RegionGraphGNN, build_target_csr  # noqa: F401,E402
+from .region_graph import (RegionGraphData, RegionGraphGNN, build_target_csr, create_region_graph,  # noqa: F401,E402
+                           create_region_graph_from_segments)
 
-__all__ = ["RegionGraphGNN", "build_target_csr", "build_multimodal_model", "MultimodalCamouflageDetector", "CrossAttentionFusion", "LateFusion",
+__all__ = ["RegionGraphGNN", "RegionGraphData", "create_region_graph", "create_region_graph_from_segments", "build_target_csr", "build_multimodal_model", "MultimodalCamouflageDetector", "CrossAttentionFusion", "LateFusion",
            "AggressiveFocalLoss", "multitask_loss", "FusedClipAdamW", "cosine_warm_restarts_lr", "NativeTrainer",
            "calculate_f1_score", "collate_fn", "fit", "pack_samples", "train_epoch_fixed", "validate_fixed",
            "EmbeddingMatcher", "DeviceResidentDataset", "SmartMultimodalDataset", "extract_label_from_mask", "train_multimodal_fixed", "load_multimodal_model", "build_ordered_kg_tensor",

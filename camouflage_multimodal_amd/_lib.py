@@ -28,6 +28,9 @@ SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_
 
 # every symbol include/camo_rg_gnn.h declares
 RG_SYMBOLS = ("camo_rg_workspace_bytes", "camo_rg_node_embeddings", "camo_rg_build_csr")
+# every symbol include/camo_rg_features.h declares
+RGF_SYMBOLS = ("camo_rg_graph_workspace_bytes", "camo_rg_region_graph")
+RG_MAX_LABELS = 4096
 RG_NPARAMS = 28
 
 
@@ -86,6 +89,10 @@ def lib():
     L.camo_rg_build_csr.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.camo_rg_node_embeddings.restype = C.c_int
     L.camo_rg_node_embeddings.argtypes = [C.POINTER(CamoRgDims), vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, vp]
+    L.camo_rg_graph_workspace_bytes.restype = sz
+    L.camo_rg_graph_workspace_bytes.argtypes = [i32]
+    L.camo_rg_region_graph.restype = C.c_int
+    L.camo_rg_region_graph.argtypes = [vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, vp, vp, i32, vp, vp]
     L.camo_debug_gemm.restype = C.c_int
     L.camo_debug_gemm.argtypes = [vp, i32, vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]
     L.camo_debug_gemm16.restype = C.c_int

@@ -25,7 +25,9 @@
 #include "gemm16.h"
 #include "misc.h"
 #include "rg_gnn.h"
+#include "rg_features.h"
 #include "../../include/camo_rg_gnn.h"
+#include "../../include/camo_rg_features.h"
 
 namespace {
 
@@ -1175,6 +1177,26 @@ int camo_rg_node_embeddings(const camo_rg_dims_t* dims, const float* const* para
   // fc_shared + relu (:121)
   g.nt(cur, C, P[CAMO_RG_FC_W], C, P[CAMO_RG_FC_B], out, C, N, C, C, GF_RELU);
   CK(g.run(), "fc_shared");
+  return 0;
+}
+
+size_t camo_rg_graph_workspace_bytes(int32_t n_labels) {
+  if (n_labels < 1 || n_labels > CAMO_RG_MAX_LABELS) return 0;
+  return rg_graph_carve(n_labels, nullptr).bytes;
+}
+
+int camo_rg_region_graph(const float* image, const int32_t* segments, const uint8_t* canny, int32_t H, int32_t W, int32_t n_labels,
+                         void* workspace, size_t workspace_bytes, float* x, int32_t* region_map, int64_t* edge_index,
+                         float* edge_attr, int32_t edge_capacity, int32_t* counts, void* stream) {
+  if (!image || !segments || !canny || !workspace || !x || !region_map || !edge_index || !edge_attr || !counts)
+    return fail(CAMO_E_ARG, "null pointer argument");
+  if (H < 1 || W < 1 || (long long)H * W > (1ll << 26)) return fail(CAMO_E_ARG, "image size out of range");
+  if (n_labels < 1 || n_labels > CAMO_RG_MAX_LABELS) return fail(CAMO_E_ARG, "n_labels must be in [1, 4096]");
+  if (edge_capacity < 2) return fail(CAMO_E_ARG, "edge_capacity must be >= 2");
+  const RgGraphWs ws = rg_graph_carve(n_labels, workspace);
+  if (workspace_bytes < ws.bytes) return fail(CAMO_E_WORKSPACE, "workspace smaller than camo_rg_graph_workspace_bytes()");
+  CK(launch_region_graph(image, segments, canny, H, W, n_labels, ws, x, region_map, reinterpret_cast<long long*>(edge_index), edge_attr,
+                         edge_capacity, counts, static_cast<hipStream_t>(stream)), "region graph");
   return 0;
 }
 }  // extern "C"

@@ -1,4 +1,4 @@
-"""Region-Graph GNN embedding path on MI355X.
+"""Region-Graph construction and GNN embedding path on MI355X.
 
 ``RegionGraphGNN`` keeps the reference module's name, constructor and ``state_dict`` keys
 (models/region_graph/extract_rg_embeddings.py:27-52), so ``best_model.pth`` loads with ``strict=True``
@@ -54,6 +54,76 @@ def build_target_csr(num_nodes, edge_index, edge_weight=None):
     rowptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=dev)
     rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=num_nodes), 0)
     return rowptr.to(torch.int32), src[order].to(torch.int32).contiguous(), w[order].contiguous()
+
+
+class RegionGraphData:
+    """What the reference's ``create_region_graph`` returns as a torch_geometric ``Data`` (extract_rg_embeddings.py:239-243):
+    ``x`` [n, 15], ``edge_index`` [2, E] int64, ``edge_attr`` [E, 1]; duck-typed for ``extract_node_embeddings``."""
+
+    def __init__(self, x, edge_index, edge_attr):
+        self.x, self.edge_index, self.edge_attr = x, edge_index, edge_attr
+
+    def to(self, device):
+        return RegionGraphData(self.x.to(device), self.edge_index.to(device), self.edge_attr.to(device))
+
+    cpu = lambda self: self.to("cpu")  # noqa: E731
+
+
+def create_region_graph_from_segments(image, segments, edges_canny, device="cuda", edge_capacity=None):
+    """The body of ``create_region_graph`` (extract_rg_embeddings.py:146-246) between its skimage calls, on the device
+    (``camo_rg_region_graph``, include/camo_rg_features.h): ``image`` [H, W, 3] float in [0, 1], ``segments`` [H, W] integer
+    superpixel labels (what ``slic`` returned, :144), ``edges_canny`` [H, W] bool (what ``canny`` returned, :152) ->
+    (RegionGraphData on the device, region_map int32 [labels] = new index of each label or -1).  Regions are renumbered in
+    increasing label order with empty labels dropped; edges come sorted by (i, j) with each followed by its reverse (the
+    reference's order is networkx's iteration order: a permutation).  PARITY UNPINNED, see the header."""
+    dev = torch.device(device)
+    img = torch.as_tensor(image).to(device=dev, dtype=torch.float32).contiguous()
+    seg = torch.as_tensor(segments).to(device=dev, dtype=torch.int32).contiguous()
+    can = torch.as_tensor(edges_canny).to(device=dev).to(torch.uint8).contiguous()
+    _lib.require_device(img, "image")
+    if img.dim() != 3 or img.shape[2] != 3 or seg.shape != img.shape[:2] or can.shape != img.shape[:2]:
+        raise ValueError(f"need image [H, W, 3], segments [H, W], edges_canny [H, W]; got {tuple(img.shape)}, {tuple(seg.shape)}, {tuple(can.shape)}")
+    H, W = seg.shape
+    lo, hi = int(seg.min()), int(seg.max())
+    if lo < 0 or hi >= _lib.RG_MAX_LABELS:
+        raise ValueError(f"segment labels must lie in [0, {_lib.RG_MAX_LABELS}), got [{lo}, {hi}]")
+    n_labels = hi + 1
+    cap = int(edge_capacity) if edge_capacity else 16 * n_labels        # (a planar adjacency has < 3 n pairs; 8-connectivity adds corner contacts)
+    L = _lib.lib()
+    while True:
+        ws = torch.empty(L.camo_rg_graph_workspace_bytes(n_labels), dtype=torch.uint8, device=dev)
+        x = torch.empty(n_labels, 15, dtype=torch.float32, device=dev)
+        rmap = torch.empty(n_labels, dtype=torch.int32, device=dev)
+        ei = torch.empty(2, cap, dtype=torch.int64, device=dev)
+        ea = torch.empty(cap, dtype=torch.float32, device=dev)
+        counts = torch.zeros(2, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.camo_rg_region_graph(_ptr(img), _ptr(seg), _ptr(can), H, W, n_labels, _ptr(ws), ws.numel(), _ptr(x), _ptr(rmap),
+                                        _ptr(ei), _ptr(ea), cap, _ptr(counts), _stream_ptr(dev))
+        _lib.check(rc, "camo_rg_region_graph")
+        n, e = (int(v) for v in counts.tolist())                         # (the one synchronisation: the sizes of what was built)
+        if e <= cap:
+            break
+        cap = e                                                          # the library reported the capacity needed: once more
+    return RegionGraphData(x[:n], ei[:, :e], ea[:e].unsqueeze(1)), rmap
+
+
+def create_region_graph(image, n_segments=500, device="cuda"):
+    """``create_region_graph(image, n_segments)`` of the reference (extract_rg_embeddings.py:138): slic and canny are
+    skimage's and stay on the host when skimage is installed; everything after them runs on the device.  Returns
+    (RegionGraphData, segments)."""
+    try:
+        from skimage import feature
+        from skimage.segmentation import slic
+    except ImportError as err:
+        raise _lib.CamoError("create_region_graph needs scikit-image for slic / canny (models/region_graph/extract_rg_embeddings.py:144,152); "
+                             "pass their results to create_region_graph_from_segments instead") from err
+    import numpy as np
+    image = np.asarray(image)
+    segments = slic((image * 255).astype(np.uint8), n_segments=n_segments, compactness=10, sigma=1)       # :143-144
+    gray = np.dot(image[..., :3], [0.2989, 0.5870, 0.1140])                                               # :151
+    data, _ = create_region_graph_from_segments(image, segments, feature.canny(gray, sigma=2), device)  # :152
+    return data, segments
 
 
 class _GATParams(nn.Module):
@@ -142,6 +212,18 @@ class RegionGraphGNN(nn.Module):
                                        _ptr(ws), ws.numel(), _ptr(out), _stream_ptr())
         _lib.check(rc, "camo_rg_node_embeddings")
         return out
+
+    def extract_graph_embedding(self, data):
+        """[num_graphs, hidden]: mean of the node embeddings per graph (global_mean_pool, extract_rg_embeddings.py:124-135).
+        Not an input of the fusion model (the reference only stores it next to the node embeddings); the pooling is index
+        plumbing on the device."""
+        emb = self.extract_node_embeddings(data)
+        batch = getattr(data, "batch", None)
+        if batch is None:
+            return emb.mean(dim=0, keepdim=True)
+        g = int(batch.max().item()) + 1
+        out = torch.zeros(g, emb.shape[1], dtype=emb.dtype, device=emb.device).index_add_(0, batch.long(), emb)
+        return out / torch.bincount(batch.long(), minlength=g).clamp(min=1).unsqueeze(1).to(emb.dtype)
 
     def forward(self, data):
         raise _lib.CamoError("RegionGraphGNN.forward (node-classification heads, used only to train the RG model) is outside "

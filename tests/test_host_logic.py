@@ -32,6 +32,12 @@ def test_shared_library_exports_every_declared_symbol():
     for s in declared2:
         assert hasattr(L, s), s
     assert f"CAMO_RG_NPARAMS" in hdr2 and _lib.RG_NPARAMS == 28
+    hdr3 = open(os.path.join(ROOT, "include", "camo_rg_features.h")).read()
+    declared3 = set(re.findall(r"\b(camo_[a-z_0-9]+)\s*\(", hdr3)) - {"camo_last_error"}
+    assert declared3 == set(_lib.RGF_SYMBOLS), declared3 ^ set(_lib.RGF_SYMBOLS)
+    for s in declared3:
+        assert hasattr(L, s), s
+    assert f"#define CAMO_RG_MAX_LABELS {_lib.RG_MAX_LABELS}" in hdr3
 
 
 def test_argument_validation_without_a_gpu():
