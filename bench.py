@@ -325,6 +325,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",
             "data": "synthetic",
+            "health": {"tail_timeouts": _lib.tail_timeouts(),
+                       "note": "arrival waits of the one-launch tail kernel that gave up during this process (0 = every step valid)"},
             "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "timed_seconds": round(sum(blocks), 3),
                        "reported": "median block", "min_ms_per_step": round(min(blocks) / args.steps * 1e3, 4),
                        "max_ms_per_step": round(max(blocks) / args.steps * 1e3, 4)},

@@ -23,7 +23,7 @@ NPARAMS_CROSS, NPARAMS_LATE = 44, 22
 # every symbol include/camo_fusion.h declares
 SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_batch_desc_bytes", "camo_prepare_batch", "camo_forward", "camo_backward", "camo_forward_loss_backward",
            "camo_loss", "camo_grad_sumsq", "camo_clip_adamw", "camo_debug_gemm", "camo_debug_gemm16", "camo_debug_ws_offset",
-           "camo_debug_set_option", "camo_debug_set_stamps", "camo_prof_begin", "camo_prof_end", "camo_prof_kind")
+           "camo_debug_set_option", "camo_debug_set_stamps", "camo_prof_begin", "camo_prof_end", "camo_prof_kind", "camo_tail_timeouts")
 
 
 # every symbol include/camo_rg_gnn.h declares
@@ -89,6 +89,8 @@ def lib():
     L.camo_rg_build_csr.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.camo_rg_node_embeddings.restype = C.c_int
     L.camo_rg_node_embeddings.argtypes = [C.POINTER(CamoRgDims), vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, vp]
+    L.camo_tail_timeouts.restype = C.c_int
+    L.camo_tail_timeouts.argtypes = [vp]
     L.camo_rg_graph_workspace_bytes.restype = sz
     L.camo_rg_graph_workspace_bytes.argtypes = [i32]
     L.camo_rg_region_graph.restype = C.c_int
@@ -127,3 +129,11 @@ def require_device(t, name):
     if not t.is_cuda:
         raise CamoError(f"{name} is on {t.device}: the fusion path runs as HIP kernels on an MI355X and has no CPU "
                         "fallback (move the model and its inputs to 'cuda').")
+
+
+def tail_timeouts():
+    """Number of arrival waits of the one-launch tail kernel that gave up since the library was loaded (synchronous; see
+    camo_tail_timeouts in include/camo_fusion.h).  Anything but 0 means a training step produced wrong results."""
+    n = C.c_uint32(0)
+    check(lib().camo_tail_timeouts(C.byref(n)), "camo_tail_timeouts")
+    return int(n.value)

@@ -1076,6 +1076,14 @@ int camo_prof_begin(int32_t max_launches) {
   return 0;
 }
 
+int camo_tail_timeouts(uint32_t* count) {
+  if (!count) return fail(CAMO_E_ARG, "null pointer argument");
+  unsigned int n = 0;
+  CK(tail_timeouts(&n), "tail timeouts");
+  *count = n;
+  return 0;
+}
+
 int camo_prof_kind(int32_t kind, double* ms, int32_t* launches, double* flops) {
   int n = 0;
   CK(gemm_prof_kind(kind, ms, &n, flops), "prof kind");

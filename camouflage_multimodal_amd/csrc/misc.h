@@ -61,3 +61,4 @@ struct TailFusedArgs {
 };
 int tail_fused_ok(int B, int C);
 int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream);
+int tail_timeouts(unsigned int* out);

@@ -502,6 +502,10 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict
 // counters[3] and finishes with wrong numbers instead of hanging), an agent-scope acquire, then plain loads: float atomics
 // execute at the memory side and leave no line in any L2.
 constexpr int TG = 64;
+// sticky health counter: arrival waits of the one-launch tail that gave up (a block of the launch never arrived within the
+// spin bound -- it cannot happen while the launch's 64 blocks are co-resident, i.e. one process per GPU; a step that hit it
+// has wrong results).  Read by camo_tail_timeouts().
+__device__ unsigned int g_tail_timeouts = 0;
 __device__ __forceinline__ void tstamp(unsigned long long* stamps, int k) {
   if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 32 + k] = __builtin_amdgcn_s_memrealtime();
 }
@@ -513,7 +517,11 @@ __device__ __forceinline__ void tail_arrive_wait(unsigned int* counter, unsigned
     unsigned int spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)TG) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 21)) { __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (++spins > (1u << 21)) {
+        __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&g_tail_timeouts, 1u);
+        break;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1171,6 +1179,10 @@ int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(tail_fused_kernel, dim3(TG), dim3(TF_THREADS), TF_LDS_FLOATS * 4, stream, a);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
+}
+
+int tail_timeouts(unsigned int* out) {          // synchronous (hipMemcpyFromSymbol): health check, not part of a step
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_timeouts), sizeof(unsigned int));
 }
 
 int launch_sumsq(const float* g, size_t n, float* out, hipStream_t stream) {

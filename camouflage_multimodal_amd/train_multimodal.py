@@ -24,6 +24,7 @@ from collections import Counter
 import numpy as np
 import torch
 
+from . import _lib
 from .fusion_model import build_multimodal_model
 from .losses import multitask_loss
 from .optim import FusedClipAdamW
@@ -282,6 +283,9 @@ def fit(config, train_loader, val_loader, device="cuda", grad_allreduce=None, lo
         loader = train_loader(epoch) if callable(train_loader) else train_loader
         tl, tf1 = train_epoch_fixed(model, loader, trainer, device, epoch + 1)
         vl, vf1, a0, a1 = validate_fixed(model, val_loader, device)
+        if _lib.tail_timeouts():
+            raise _lib.CamoError("the one-launch tail kernel timed out waiting for its own blocks (GPU shared with another process?): "
+                                 "this epoch's results are invalid")
         trainer.opt.set_epoch(epoch + 1)                     # scheduler.step() [:439]: a checkpoint carries the NEXT epoch's lr
         for k, v in (("train_loss", tl), ("val_loss", vl), ("train_f1_class_0", tf1["f1_class_0"]),
                      ("train_f1_class_1", tf1["f1_class_1"]), ("train_f1_avg", tf1["f1_avg"]),

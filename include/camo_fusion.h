@@ -228,6 +228,13 @@ int camo_prof_end(double* gemm_ms, int32_t* gemm_launches, double* gemm_flops);
  * (camo_prof_end's own outputs are the totals over all kinds.) */
 int camo_prof_kind(int32_t kind, double* ms, int32_t* launches, double* flops);
 
+/* Health check of the one-launch per-sample tail (the only kernel of the library whose blocks wait for each other: three
+ * all-reduces among its 64 co-resident blocks, each wait bounded).  *count = number of waits that gave up since the
+ * library was loaded; 0 in any run with one process per GPU.  A non-zero count means a step produced wrong results (the
+ * GPU was shared with another process that kept the launch's blocks from being co-resident).  SYNCHRONOUS (reads a device
+ * counter): call it between epochs, not inside a step.  train_multimodal.fit does, and raises. */
+int camo_tail_timeouts(uint32_t* count);
+
 #ifdef __cplusplus
 }
 #endif

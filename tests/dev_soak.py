@@ -1,9 +1,9 @@
-"""Developer aid: a few hundred optimizer steps on repeated synthetic batches (loss must fall, parameters stay finite),\nat B = 128 and B = 16.  python tests/dev_soak.py"""
+"""Developer aid: optimizer steps on repeated synthetic batches (loss must fall, parameters stay finite): 40 at B = 128 and\n20 000 at B = 16 (the one-launch tail with its in-kernel all-reduces); reports the tail kernel's timeout counter.\n  python tests/dev_soak.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
-from camouflage_multimodal_amd import NativeTrainer, build_multimodal_model
+from camouflage_multimodal_amd import NativeTrainer, _lib, build_multimodal_model
 dev = torch.device("cuda", 0)
 for B in (128, 16):
     torch.manual_seed(0)
@@ -12,7 +12,7 @@ for B in (128, 16):
     host = bench.make_batches(4, B, 0)
     bt = [(torch.from_numpy(rg).to(dev), nrs, torch.from_numpy(kg).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(e).to(dev), torch.from_numpy(s).to(dev)) for rg, nrs, kg, y, e, s in host]
     losses = []
-    steps = 400 if B == 16 else 40
+    steps = 20000 if B == 16 else 40
     for i in range(steps):
         terms, pred = tr.step(*bt[i % 4])
         if i % (steps // 8) == 0 or i == steps - 1:
@@ -24,3 +24,4 @@ for B in (128, 16):
     for i in range(50): tr.step(*bt[i % 4])
     torch.cuda.synchronize()
     print(f"   {B * 50 / (time.perf_counter() - t0):.0f} images/s at B={B}")
+print(f"tail-kernel waits that gave up in this process: {_lib.tail_timeouts()} (must be 0)")

@@ -184,3 +184,10 @@ def test_predict_post_processing_and_batch_results(tmp_path, kg_real):
     assert len(res) == 2 and set(res[0]) == {"image", "prediction", "pred_label", "camo_prob", "not_camo_prob", "score"}
     assert res[0]["image"] == "img0.jpg" and res[0]["prediction"] in ("Camouflaged", "Not Camouflaged")
     assert abs(res[0]["camo_prob"] + res[0]["not_camo_prob"] - 1) < 1e-6
+
+
+def test_tail_kernel_never_times_out_in_this_process():
+    """The one-launch tail's bounded waits (three all-reduces among 64 co-resident blocks) must never give up when the
+    process has the GPU's CUs to itself; the counter is sticky, so this covers every fused training step the tests above ran."""
+    from camouflage_multimodal_amd import _lib
+    assert _lib.tail_timeouts() == 0
