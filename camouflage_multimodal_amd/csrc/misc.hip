@@ -357,11 +357,17 @@ __global__ void head_out_grad_kernel(const float* __restrict__ outs, const float
 // per sample: 3*focal(mask,y) + CE(inst,y) + .5*BCEWithLogits(edge,e) + .3*MSE(score,s)
 // (train_multimodal.py:29-57, 256-268), each at batch size 1.
 // o: the sample's 2C+2 outputs (score column post-sigmoid).  d_outs / d_pre rows may be null; they must not alias o.
+// FAST: hardware exp / log / reciprocal (v_exp_f32, v_log_f32, v_rcp_f32: ~1 ulp each) instead of the correctly rounded library
+// calls -- a third of the instructions; used by the one-launch tail, where sixteen lanes run this on every block's critical path.
+template <bool FAST = false>
 __device__ __forceinline__ void loss_sample(const float* __restrict__ o, int yb, float eb, float sb, int C,
                                             float* __restrict__ terms4, float* __restrict__ d_outs, float* __restrict__ d_pre,
                                             int* __restrict__ pred) {
   const int W = 2 * C + 2;
   const float sc = o[W - 1];
+  auto ex = [](float x) { return FAST ? __expf(x) : expf(x); };
+  auto lg = [](float x) { return FAST ? __logf(x) : logf(x); };
+  auto rc = [](float x) { return FAST ? __frcp_rn(x) : 1.0f / x; };
   auto put = [&](int k, float val) {        // gradient w.r.t. output k; d_pre: score column w.r.t. the pre-sigmoid value
     if (d_outs) d_outs[k] = val;
     if (d_pre) d_pre[k] = (k == W - 1) ? val * sc * (1.0f - sc) : val;
@@ -375,17 +381,18 @@ __device__ __forceinline__ void loss_sample(const float* __restrict__ o, int yb,
     float mx = -INFINITY; int am = 0;
     for (int k = 0; k < C; ++k) if (o[k] > mx) { mx = o[k]; am = k; }
     float z = 0.f;
-    for (int k = 0; k < C; ++k) z += expf(o[k] - mx);
+    for (int k = 0; k < C; ++k) z += ex(o[k] - mx);
+    const float iz = rc(z);
     // ce from the log-sum-exp (finite when pt underflows, like torch's log_softmax); the gradient is written
     // without the division by pt:  d l / d logit_k = at * (-3 om^2 ce pt - om^3) * (delta_ky - p_k)
-    const float ce = -(o[yb] - mx - logf(z));
-    const float pt = expf(o[yb] - mx) / z;
+    const float ce = -(o[yb] - mx - lg(z));
+    const float pt = FAST ? ex(o[yb] - mx) * iz : expf(o[yb] - mx) / z;
     const float at = yb == 1 ? 0.75f : 0.25f;
     const float om = 1.0f - pt;
     terms4[0] = 3.0f * at * om * om * om * ce + poison;
     const float dl = at * (-3.0f * om * om * ce * pt - om * om * om);
     for (int k = 0; k < C; ++k) {
-      const float pk = expf(o[k] - mx) / z;
+      const float pk = FAST ? ex(o[k] - mx) * iz : expf(o[k] - mx) / z;
       put(k, 3.0f * dl * ((k == yb ? 1.0f : 0.0f) - pk) + poison);
     }
     if (pred) *pred = am;
@@ -396,15 +403,16 @@ __device__ __forceinline__ void loss_sample(const float* __restrict__ o, int yb,
     float mx = -INFINITY;
     for (int k = 0; k < C; ++k) mx = fmaxf(mx, oi[k]);
     float z = 0.f;
-    for (int k = 0; k < C; ++k) z += expf(oi[k] - mx);
-    terms4[1] = -(oi[yb] - mx - logf(z));
-    for (int k = 0; k < C; ++k) put(C + k, expf(oi[k] - mx) / z - (k == yb ? 1.0f : 0.0f));
+    for (int k = 0; k < C; ++k) z += ex(oi[k] - mx);
+    const float iz = rc(z);
+    terms4[1] = -(oi[yb] - mx - lg(z));
+    for (int k = 0; k < C; ++k) put(C + k, (FAST ? ex(oi[k] - mx) * iz : expf(oi[k] - mx) / z) - (k == yb ? 1.0f : 0.0f));
   }
   // BCE with logits on edge
   {
     const float x = o[2 * C], t = eb;
-    terms4[2] = 0.5f * (fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))));
-    put(2 * C, 0.5f * (1.0f / (1.0f + expf(-x)) - t));
+    terms4[2] = 0.5f * (fmaxf(x, 0.f) - x * t + (FAST ? __logf(1.0f + __expf(-fabsf(x))) : log1pf(expf(-fabsf(x)))));
+    put(2 * C, 0.5f * ((FAST ? rc(1.0f + ex(-x)) : 1.0f / (1.0f + expf(-x))) - t));
   }
   // MSE on the (post-sigmoid) score
   {
@@ -531,7 +539,8 @@ __device__ __forceinline__ void tail_arrive_wait(unsigned int* counter, unsigned
 
 constexpr int TF_MAXB = 16;
 constexpr int TF_MAXW = 18;           // 2 * num_classes + 2 (num_classes <= 8)
-constexpr int TF_LDS_FLOATS = 2 * TF_MAXB * 512 + 2 * TF_MAXB * 256 + 2048 + 2048 + 3 * 128 + 64 + 64 + 2 * TF_MAXB * TF_MAXW + TF_MAXW * 129;
+constexpr int TF_LDS_FLOATS = 2 * TF_MAXB * 512 + 2 * TF_MAXB * 256 + 2048 + 2048 + 3 * 128 + 64 + 64 + 2 * TF_MAXB * TF_MAXW + TF_MAXW * 129 + 2 +
+                             8 * 512 + 4 * 256;      // (148 KB)
 
 // The kernel runs once per step on 64 CUs that have just run other code, one block per CU: what it costs is latency, not
 // throughput.  So: 1024 threads -- four "quarters" of 256 threads, quarter q walking samples 4q..4q+3 through every
@@ -562,6 +571,8 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
   float* combS = wB + 2048; float* dcombS = combS + 128; float* ymS = dcombS + 128; float* fusedS = ymS + 128; float* dfusedS = fusedS + 64;
   float* outsS = dfusedS + 64; float* dpre = outsS + TF_MAXB * TF_MAXW;
   float* w3s = dpre + TF_MAXB * TF_MAXW;                     // [Wd][129]: output-layer weight rows + bias, in output-column order
+  float* W3L = w3s + ((TF_MAXW * 129 + 3) & ~3);             // [8][512] this block's rows of its stream's pooled FFN layer (L1, and d(mean H))
+  float* WfL = W3L + 8 * 512;                                // [4][256] this block's rows of fusion layer 3 (L3, and d F1)
   const bool kgs = g >= 32;                                 // comb columns 256.. are the KG stream's
   const int c0 = 8 * (g & 31), ccol = (kgs ? 256 : 0) + c0;
   const float* Hmean = kgs ? a.H2mean : a.H1mean; const float* Ymean = kgs ? a.Y2mean : a.Ymean;
@@ -583,13 +594,9 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   tstamp(a.stamps, 0);
   // ---- every global read of the forward that depends on nothing: issued now, one memory round trip for all of them
-  float w1[2][8], w3r[4];
-#pragma unroll
-  for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) w1[cc][i] = W3s[(size_t)(c0 + 2 * wv + cc) * 512 + lane + 64 * i];        // L1: rows of this wave's 2 columns
-#pragma unroll
-  for (int i = 0; i < 4; ++i) w3r[i] = a.Wfu3[(size_t)(4 * g + wv) * 256 + lane + 64 * i];                // L3: row of this wave's column
+  // (weight rows go through LDS: one 16-byte load per thread instead of 40 dword loads that four quarters would repeat)
+  const float4 w3l = *reinterpret_cast<const float4*>(W3s + (size_t)(c0 + (tid >> 7)) * 512 + 4 * (tid & 127));
+  const float4 wfl = tid < 256 ? *reinterpret_cast<const float4*>(a.Wfu3 + (size_t)(4 * g + (tid >> 6)) * 256 + 4 * (tid & 63)) : z4;
   float4 hv[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) { const int i = tid + TF_THREADS * it; hv[it] = i < B * 128 ? reinterpret_cast<const float4*>(Hmean)[i] : z4; }
@@ -625,16 +632,9 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
   float2* dstW0 = reinterpret_cast<float2*>(gheadW0(qm >> 7) + (size_t)(qm & 127) * 256 + 4 * g + 2 * qh);
   float* dstfu3 = a.gWfu3 + (size_t)(4 * g + q) * 256 + t;
   float2* dstfu0 = reinterpret_cast<float2*>(a.gWfu0 + (size_t)t * 512 + ccol + 2 * q);
-  float w8r[4], w10[2][8];
   float oW3h = 0.f, ob3h = 0.f, ob0h = 0.f, obfu3 = 0.f, obfu0 = 0.f, ob3s = 0.f, ofu3 = 0.f, ogw3[4] = {0.f, 0.f, 0.f, 0.f};
   float2 oW0 = make_float2(0.f, 0.f), ofu0 = make_float2(0.f, 0.f);
   if (a.mode) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) w8r[c] = a.Wfu3[(size_t)(4 * g + c) * 256 + t];                           // d F1: rows 4g.., column t
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) w10[kk][c] = W3s[(size_t)(c0 + c) * 512 + t + 256 * kk];                // d(mean H): column t (+256)
     if (tid < hnout * 8) oW3h = *dW3h;
     if (g == 0 && tid >= 128 && tid < 128 + Wd) { int xx, oo; head_of(tid - 128, xx, oo); ob3h = gheadB3(xx)[oo]; }
     oW0 = *dstW0; ofu3 = *dstfu3; ofu0 = *dstfu0;
@@ -647,6 +647,8 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
   for (int it = 0; it < 2; ++it) { const int i = tid + TF_THREADS * it; if (i < B4 * 128) reinterpret_cast<float4*>(R1)[i] = hv[it]; }
 #pragma unroll
   for (int it = 0; it < 3; ++it) { const int p = tid + TF_THREADS * it; if (p < Wd * 129) w3s[p] = w3v[it]; }
+  reinterpret_cast<float4*>(W3L)[tid] = w3l;
+  if (tid < 256) reinterpret_cast<float4*>(WfL)[tid] = wfl;
   __syncthreads();
   tstamp(a.stamps, 1);
   // ---- L1 (by output column): comb[b][c] = mean Y + (mean H) . W3^T + b3, c in this block's 8 columns; wave wv: columns 2wv, 2wv+1
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(w1[cc][i], R1[(b0 + j) * 512 + lane + 64 * i], acc[j]);
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(W3L[(2 * wv + cc) * 512 + lane + 64 * i], R1[(b0 + j) * 512 + lane + 64 * i], acc[j]);
       wave_sum4(acc);
       if (lane == 63) {
 #pragma unroll
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = fmaf(w3r[i], F1[(b0 + j) * 256 + lane + 64 * i], acc[j]);
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(WfL[wv * 256 + lane + 64 * i], F1[(b0 + j) * 256 + lane + 64 * i], acc[j]);
     wave_sum4(acc);
     if (lane == 63) {
 #pragma unroll
@@ -746,29 +748,38 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
   if (tid < TF_MAXB * TF_MAXW) dpre[tid] = 0.f;            // (rows past B stay zero)
   __syncthreads();
   tstamp(a.stamps, 9);
-  // ---- head output layers (every block; operands in LDS), loss
-  if (tid < B * Wd) {
-    const int b = tid / Wd, o = tid - b * Wd;
+  // ---- head output layers (every block; operands in LDS), loss.  Four lanes share an output: lane kq of the quad takes
+  // hidden units 16 it + 4 kq .. + 3
+#pragma unroll 1
+  for (int p = tid >> 2; p < B * Wd; p += TF_THREADS / 4) {
+    const int kq = tid & 3;
+    const int b = p / Wd, o = p - b * Wd;
     const int x = o < C ? 0 : (o < 2 * C ? 1 : (o == 2 * C ? 2 : 3));
-    const float* wr = w3s + o * 129;
-    const float* hr = R2 + b * 512 + x * 128;
-    float acc0 = wr[128], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-#pragma unroll 2
-    for (int k = 0; k < 128; k += 4) {
-      const float4 h4 = *reinterpret_cast<const float4*>(hr + k);
-      acc0 = fmaf(wr[k], h4.x, acc0); acc1 = fmaf(wr[k + 1], h4.y, acc1); acc2 = fmaf(wr[k + 2], h4.z, acc2); acc3 = fmaf(wr[k + 3], h4.w, acc3);
+    const float* wr = w3s + o * 129 + 4 * kq;
+    const float* hr = R2 + b * 512 + x * 128 + 4 * kq;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const float4 h4 = *reinterpret_cast<const float4*>(hr + 16 * it);
+      acc0 = fmaf(wr[16 * it], h4.x, acc0); acc1 = fmaf(wr[16 * it + 1], h4.y, acc1);
+      acc2 = fmaf(wr[16 * it + 2], h4.z, acc2); acc3 = fmaf(wr[16 * it + 3], h4.w, acc3);
     }
     float acc = (acc0 + acc1) + (acc2 + acc3);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += w3s[o * 129 + 128];
     if (x == 3) acc = 1.0f / (1.0f + __expf(-acc));
-    outsS[b * TF_MAXW + o] = acc;
-    if (g == 0) a.outs[tid] = acc;
+    if (kq == 0) {
+      outsS[b * TF_MAXW + o] = acc;
+      if (g == 0) a.outs[p] = acc;
+    }
   }
   __syncthreads();
   tstamp(a.stamps, 10);
   if (!a.mode) { tstamp(a.stamps, 20); return; }
   if (tid < B) {
     float t4[4]; int pr = 0;
-    loss_sample(outsS + tid * TF_MAXW, (int)a.y[tid], a.e[tid], a.s[tid], C, t4, nullptr, dpre + tid * TF_MAXW, &pr);
+    loss_sample<true>(outsS + tid * TF_MAXW, (int)a.y[tid], a.e[tid], a.s[tid], C, t4, nullptr, dpre + tid * TF_MAXW, &pr);
     if (g == 0) {
       a.terms[4 * tid] = t4[0]; a.terms[4 * tid + 1] = t4[1]; a.terms[4 * tid + 2] = t4[2]; a.terms[4 * tid + 3] = t4[3];
       if (a.pred) a.pred[tid] = pr;
@@ -858,7 +869,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 df = reinterpret_cast<const float4*>(dfusedS)[b0 + j];
-      if (b0 + j < B) atomicAdd(a.dF1sum + (b0 + j) * 256 + t, df.x * w8r[0] + df.y * w8r[1] + df.z * w8r[2] + df.w * w8r[3]);
+      if (b0 + j < B) atomicAdd(a.dF1sum + (b0 + j) * 256 + t, df.x * WfL[t] + df.y * WfL[256 + t] + df.z * WfL[512 + t] + df.w * WfL[768 + t]);
     }
   }
   {
@@ -939,8 +950,9 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
       const float4 da = reinterpret_cast<const float4*>(dcombS)[(b0 + j) * 2], db = reinterpret_cast<const float4*>(dcombS)[(b0 + j) * 2 + 1];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const float acc = da.x * w10[kk][0] + da.y * w10[kk][1] + da.z * w10[kk][2] + da.w * w10[kk][3] +
-                          db.x * w10[kk][4] + db.y * w10[kk][5] + db.z * w10[kk][6] + db.w * w10[kk][7];
+        const float* wc = W3L + t + 256 * kk;
+        const float acc = da.x * wc[0] + da.y * wc[512] + da.z * wc[1024] + da.w * wc[1536] +
+                          db.x * wc[2048] + db.y * wc[2560] + db.z * wc[3072] + db.w * wc[3584];
         if (b0 + j < B) atomicAdd(dHm + (b0 + j) * 512 + t + 256 * kk, acc);
       }
     }
