@@ -130,9 +130,10 @@ __global__ __launch_bounds__(256) void shadow_kernel(const ShadowBatch sb, int t
   if (!J.transposed) {
     int i = 0, nn = n;
     while (i + 1 < J.nsrc && nn >= J.rows[i]) { nn -= J.rows[i]; ++i; }
-    const float* p = J.src[i] + (size_t)nn * J.ld[i] + k0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = p[e];
+    // (two 16-byte loads: eight dword loads of 64 different cache lines each kept the address unit busy 4x longer)
+    const float4* p = reinterpret_cast<const float4*>(J.src[i] + (size_t)nn * J.ld[i] + k0);
+    const float4 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
   } else {
     int i = 0, kk = k0;
     while (i + 1 < J.nsrc && kk >= J.rows[i]) { kk -= J.rows[i]; ++i; }      // (source blocks are multiples of 8 rows)
@@ -1171,7 +1172,10 @@ int launch_weight_shadows(ShadowBatch& sb, hipStream_t stream) {
     ShadowJob& J = sb.j[i];
     if ((J.N & 127) || (J.K & 15) || J.nsrc < 1 || J.nsrc > 3 || !J.dst || !al16(J.dst)) return (int)hipErrorInvalidValue;
     int sum = 0;
-    for (int s = 0; s < J.nsrc; ++s) { if (!J.src[s] || (J.rows[s] & 7)) return (int)hipErrorInvalidValue; sum += J.rows[s]; }
+    for (int s = 0; s < J.nsrc; ++s) {
+      if (!J.src[s] || (J.rows[s] & 7) || (!J.transposed && (!al16(J.src[s]) || (J.ld[s] & 3)))) return (int)hipErrorInvalidValue;
+      sum += J.rows[s];
+    }
     if (sum != (J.transposed ? J.K : J.N)) return (int)hipErrorInvalidValue;
     J.chunk_begin = total;
     total += J.N * J.K / 8;
