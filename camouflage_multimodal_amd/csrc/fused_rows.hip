@@ -596,6 +596,8 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
       uint32_t wlo = 0u, whi = 0u;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
+        if (8 * (i >> 2) >= nrows) continue;                // (block-uniform) a register group whose rows are all past the tile's end: the
+                                                            // KG tile has 13 rows, so half of its epilogue -- on the kernel's critical path -- goes
         const int row = acc_row(i, h);
         float v = fmaxf(acc[t][i] + bias, 0.f);
         if (dodrop) v *= drop_mult(a.drop, S.site_ffn, (uint32_t)(rowg0 + row) * 512u + (uint32_t)f);
