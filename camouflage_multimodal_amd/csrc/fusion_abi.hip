@@ -1111,7 +1111,8 @@ int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int3
       {"dO2_16", w.f.dO2_16}, {"delta2", w.f.delta2}, {"dKV", w.dKV}, {"dQ2acc", w.dQ2acc}, {"Ymean", w.Ymean}, {"H1mean", w.H1mean}, {"Y2mean", w.Y2mean}, {"H2mean", w.H2mean},
       {"R", w.R}, {"G", w.G}, {"Q", w.Q}, {"KV2", w.KV2}, {"KV", w.KV}, {"Q2", w.Q2}, {"P", w.P}, {"P2", w.P2},
       {"O", w.O}, {"O2", w.O2}, {"U", w.U}, {"U2", w.U2}, {"Y", w.Y}, {"Y2", w.Y2}, {"H1", w.H1}, {"H2", w.H2},
-      {"comb", w.comb}, {"fused", w.fused}};
+      {"comb", w.comb}, {"fused", w.fused}, {"F1", w.F1}, {"hid", w.hid}, {"dhid", w.dhid}, {"dfused", w.dfused}, {"dF1", w.dF1},
+      {"dcomb", w.dcomb}, {"dHm1", w.dHm1}, {"dHm2", w.dHm2}};
   for (const auto& e : tab)
     if (std::strcmp(e.n, name) == 0 && e.p) return static_cast<const char*>(e.p) - base;
   return -1;
