@@ -1179,7 +1179,12 @@ int launch_heads_loss(const float* hid, const HeadsOut& hp, const long long* y, 
   return (int)hipGetLastError();
 }
 
-int tail_fused_ok(int B, int C) { return B >= 1 && B <= TF_MAXB && C >= 1 && 2 * C + 2 <= TF_MAXW; }
+int tail_fused_ok(int B, int C) {
+  // every block of the launch waits for the other 63: all of them must be resident at once, one per CU (1024 threads, 148 KB of
+  // LDS), so the device (or the partition this process sees) must have at least that many CUs
+  static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  return B >= 1 && B <= TF_MAXB && C >= 1 && 2 * C + 2 <= TF_MAXW && cus >= TG;
+}
 int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream) {
   if (!tail_fused_ok(a.B, a.C)) return (int)hipErrorInvalidValue;
   static const bool attr = [] {
