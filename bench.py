@@ -134,9 +134,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event roofline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward / batch-sweep / f32 legs (single-GPU runs only)")
-    ap.add_argument("--allreduce", default="bucketed", choices=["bucketed", "single"],
+    ap.add_argument("--allreduce", default="bucketed", choices=["bucketed", "single", "oneshot"],
                     help="gradient all-reduce for --gpus N > 1: two buckets, the first overlapped with the node-level backward "
-                         "(default), or one flat all-reduce after it")
+                         "(default), one flat all-reduce after it, or all_to_all + local sum + all_gather (one exchange step per direction)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus N > 1 (nccl = RCCL; gloo lets a "
                     "one-GPU box rehearse the multi-rank path with every rank on the same device)")
     args = ap.parse_args()
@@ -144,7 +144,7 @@ def main():
     import torch
     import torch.distributed as dist
     from camouflage_multimodal_amd import NativeTrainer, build_multimodal_model, _lib
-    from camouflage_multimodal_amd.ddp import BucketedGradAllReducer, GradAllReducer, broadcast_parameters
+    from camouflage_multimodal_amd.ddp import BucketedGradAllReducer, GradAllReducer, OneShotGradAllReducer, broadcast_parameters
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -167,7 +167,7 @@ def main():
     model = build_multimodal_model({}).to(dev).set_precision(args.precision).train()   # reference defaults, dropout 0.3
     if world > 1:
         broadcast_parameters(model._engine.flat_params)
-    trainer = NativeTrainer(model, lr=5e-4, weight_decay=1e-4, grad_allreduce=(BucketedGradAllReducer() if args.allreduce == "bucketed" else GradAllReducer()) if world > 1 else None)
+    trainer = NativeTrainer(model, lr=5e-4, weight_decay=1e-4, grad_allreduce={"bucketed": BucketedGradAllReducer, "single": GradAllReducer, "oneshot": OneShotGradAllReducer}[args.allreduce]() if world > 1 else None)
 
     host = make_batches(8, args.batch, rank)
     batches = [(torch.from_numpy(rg).to(dev), nrs, torch.from_numpy(kg).to(dev), torch.from_numpy(y).to(dev),

@@ -79,6 +79,35 @@ class BucketedGradAllReducer(GradAllReducer):
         return flat_grads
 
 
+class OneShotGradAllReducer(GradAllReducer):
+    """The all-reduce as ONE exchange step per direction instead of a ring: reduce-scatter by ``all_to_all`` (every rank sends
+    shard j of its gradients straight to rank j -- on an xGMI node each of the seven peers has its own link, so the seven
+    724 KB shards travel concurrently), a local sum of the ``world`` received shards in rank order (deterministic, identical
+    on every rank after the gather), then ``all_gather``.  SURVEY.md 8e proposes this shape for the 5.8 MB buffer, where a
+    ring's 2 (N - 1) dependent steps are latency-bound.  UNMEASURED (no multi-GPU node was available): kept as an option
+    (``bench.py --allreduce oneshot``), not the default; the CPU gloo test holds it to the plain all-reduce."""
+
+    def __init__(self, group=None):
+        super().__init__(group)
+        self._send = self._recv = None
+
+    def __call__(self, flat_grads: torch.Tensor, split=None):
+        w = self.world
+        if w <= 1:
+            return flat_grads
+        n = flat_grads.numel()
+        shard = ((n + w - 1) // w + 3) // 4 * 4
+        if self._send is None or self._send.numel() != w * shard or self._send.device != flat_grads.device:
+            self._send = torch.zeros(w * shard, dtype=flat_grads.dtype, device=flat_grads.device)
+            self._recv = torch.empty_like(self._send)
+        self._send[:n].copy_(flat_grads)
+        dist.all_to_all_single(self._recv, self._send, group=self.group)          # recv[j] = rank j's copy of MY shard
+        mine = self._recv.view(w, shard).sum(dim=0)                                # ranks 0..w-1 in order: every rank sums alike
+        dist.all_gather_into_tensor(self._send, mine, group=self.group)
+        flat_grads.copy_(self._send[:n])
+        return flat_grads
+
+
 def broadcast_parameters(flat_params: torch.Tensor, src=0, group=None):
     """Make every rank start from rank ``src``'s parameters (one flat broadcast)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -134,16 +134,20 @@ def _bucket_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from camouflage_multimodal_amd.ddp import BucketedGradAllReducer, GradAllReducer
+        from camouflage_multimodal_amd.ddp import BucketedGradAllReducer, GradAllReducer, OneShotGradAllReducer
         g = torch.Generator().manual_seed(7 + rank)
         flat = torch.randn(1000, generator=g)
         a, b, c = flat.clone(), flat.clone(), flat.clone()
+        d = flat[:997].clone()                             # (a length the world size does not divide)
+        one = OneShotGradAllReducer()
+        one(d); one(d_again := flat[:997].clone())
         GradAllReducer()(a)
         red = BucketedGradAllReducer()
         assert red.tail_event("cpu") is None              # no GPU: no event, the two buckets are reduced one after the other
         red(b, split=640)
         red(c, split=None)                                 # no split point (late fusion): one piece
-        q.put((rank, a.numpy(), b.numpy(), c.numpy()))
+        assert torch.equal(d, d_again)
+        q.put((rank, a.numpy(), b.numpy(), c.numpy(), d.numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -157,6 +161,7 @@ def test_bucketed_all_reduce_is_the_same_sum():
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(60); assert p.exitcode == 0
-    for rank, a, b, c in res:
+    for rank, a, b, c, d in res:
         assert np.array_equal(a, b) and np.array_equal(a, c)
-    assert np.array_equal(res[0][1], res[1][1])
+        assert np.allclose(d, a[:997], rtol=0, atol=1e-6)  # all_to_all + local sum + all_gather: the same sum
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][4], res[1][4])
