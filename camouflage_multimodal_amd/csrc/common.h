@@ -17,6 +17,7 @@ struct DropCfg {
   uint32_t seed_lo, seed_hi;
   float p;       // drop probability; 0 => disabled
   float scale;   // 1/(1-p)
+  uint32_t thr;  // keep iff hash >= thr: ceil(p * 2^24) << 8, i.e. exactly "top 24 bits / 2^24 >= p" without the shift, convert and multiply
 };
 
 __host__ __device__ inline DropCfg make_drop(int training, float p, uint64_t seed) {
@@ -25,6 +26,12 @@ __host__ __device__ inline DropCfg make_drop(int training, float p, uint64_t see
   d.seed_hi = (uint32_t)(seed >> 32);
   d.p = (training && p > 0.f) ? p : 0.f;
   d.scale = d.p > 0.f ? 1.0f / (1.0f - d.p) : 1.0f;
+  // u = (x >> 8) / 2^24 >= p  <=>  (x >> 8) >= p * 2^24 (exact in double)  <=>  x >= ceil(p * 2^24) << 8  (the low 8 bits of x cannot
+  // lift x >> 8 over an integer bound)
+  const double t = (double)d.p * 16777216.0;
+  unsigned long long t24 = (unsigned long long)t;
+  if ((double)t24 < t) ++t24;
+  d.thr = t24 >= 16777216ull ? 0xFFFFFFFFu : (uint32_t)(t24 << 8);
   return d;
 }
 
@@ -40,8 +47,7 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
 // cycles per element and showed up as microseconds in every epilogue that draws a mask).
 __device__ __forceinline__ float drop_mult(const DropCfg& d, uint32_t site, uint32_t idx) {
   const uint32_t x = fmix32((idx + (site * 0x85EBCA77u + d.seed_lo)) ^ d.seed_hi);
-  const float u = (float)(x >> 8) * (1.0f / 16777216.0f);
-  return u >= d.p ? d.scale : 0.0f;
+  return x >= d.thr ? d.scale : 0.0f;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

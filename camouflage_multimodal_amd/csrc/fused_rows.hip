@@ -20,6 +20,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -350,6 +351,7 @@ __device__ __forceinline__ void attn_kg_split(const BackArgs& a, char* smem, int
     }
   mx[0] = fmaxf(mx[0], __shfl_xor(mx[0], 32, 64));
   mx[1] = fmaxf(mx[1], __shfl_xor(mx[1], 32, 64));
+  stamp(a.stamps, 1);
   f32x16 Z[2] = {zero16(), zero16()};
   float L[2] = {0.f, 0.f};
   const bool dodrop = a.drop.p > 0.f;
@@ -380,6 +382,7 @@ __device__ __forceinline__ void attn_kg_split(const BackArgs& a, char* smem, int
   }
   L[0] += __shfl_xor(L[0], 32, 64);
   L[1] += __shfl_xor(L[1], 32, 64);
+  stamp(a.stamps, 2);
   // partial of this split: Z has the query on its registers (0..7 -> j = acc_row(i, h) < 16) and the feature on the lane
 #pragma unroll
   for (int hd = 0; hd < 2; ++hd) {
@@ -389,8 +392,18 @@ __device__ __forceinline__ void attn_kg_split(const BackArgs& a, char* smem, int
       __hip_atomic_store(part + lane, mx[hd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(part + 16 + lane, L[hd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // Z [16 queries][32 features] goes through this wave's (now idle) value-tile scratch so that it leaves as 16-byte
+    // write-through stores: a dword sc1 store is one fabric write per lane, six times the time per byte
+    float* zt = reinterpret_cast<float*>(Vt);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) __hip_atomic_store(part + 32 + acc_row(i, h) * 32 + l31, Z[hd][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < 8; ++i) zt[acc_row(i, h) * 32 + l31] = Z[hd][i];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int idx = lane + 64 * r;                       // float4 idx of the [16][32] tile
+      const f32x4 v = *reinterpret_cast<const f32x4*>(zt + 4 * idx);
+      float* dst = part + 32 + 4 * idx;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+    }
   }
 }
 
@@ -406,15 +419,18 @@ __device__ __forceinline__ void attn_kg_combine(const BackArgs& a, char* smem, i
   constexpr size_t SS = (size_t)2 * 8 * PART_FLOATS;                          // floats between consecutive splits
   // the first batch of Z loads does not depend on the scale factors: it is issued together with the m / l loads, so the
   // whole combine is (1 + number of further 4-split batches) memory round trips
-  const int hd2 = tid >> 5, f = tid & 31;
-  const float* z0 = part + (size_t)hd2 * PART_FLOATS + 32 + f;
-  float zv[4][16];
+  // a thread owns four (head, query, 4 features) items: item it = tid + 256 it -> head = it_idx >> 7, query = (it_idx >> 3) & 15,
+  // features 4 (it_idx & 7) .. + 3, i.e. one 16-byte load per split and item
+  f32x4 zv[4][4];
   auto load_z = [&](int s0) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float* z = z0 + (size_t)min(s0 + k, nsplit - 1) * SS;
+      const float* z = part + (size_t)min(s0 + k, nsplit - 1) * SS + 32;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) zv[k][j] = z[j * 32];
+      for (int it = 0; it < 4; ++it) {
+        const int idx = tid + 256 * it;
+        zv[k][it] = *reinterpret_cast<const f32x4*>(z + (size_t)(idx >> 7) * PART_FLOATS + 4 * (idx & 127));
+      }
     }
   };
   load_z(0);
@@ -452,22 +468,27 @@ __device__ __forceinline__ void attn_kg_combine(const BackArgs& a, char* smem, i
     if (a.save && a.lse2 && j < Nk) { float* o = a.lse2 + (((size_t)b * 8 + hd) * 16 + j) * 2; o[0] = M; o[1] = L; }
   }
   __syncthreads();
-  const int hd = hd2;
-  float acc[16];
+  f32x4 acc[4];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int it = 0; it < 4; ++it) acc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int s0 = 0; s0 < nsplit; s0 += 4) {
     if (s0 > 0) load_z(s0);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (s0 + k < nsplit) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = fmaf(zv[k][j], sc[(s0 + k) * 128 + hd * 16 + j], acc[j]);
+        for (int it = 0; it < 4; ++it) acc[it] += zv[k][it] * sc[(s0 + k) * 128 + ((tid + 256 * it) >> 3)];     // (index = head * 16 + query)
       }
   }
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (j < Nk) *reinterpret_cast<us16*>(bufO + j * PR + 2 * (32 * hd + f)) = f2bf(acc[j] * invL[hd * 16 + j]);
+  for (int it = 0; it < 4; ++it) {
+    const int idx = tid + 256 * it, hd = idx >> 7, j = (idx >> 3) & 15, f4 = idx & 7;
+    if (j < Nk) {
+      const float il = invL[hd * 16 + j];
+      *reinterpret_cast<u32x2*>(bufO + j * PR + 2 * (32 * hd + 4 * f4)) =
+          u32x2{pack2(acc[it][0] * il, acc[it][1] * il), pack2(acc[it][2] * il, acc[it][3] * il)};
+    }
+  }
 }
 
 template <int DEPTH, bool ROT>

@@ -54,6 +54,10 @@ for k, name in enumerate(("front", "back", "bwd1", "bwd2") if train else ("front
         sp = s[(s[:, 0] > 0) & (s[:, 5] > 0)].astype(np.float64)
         if len(sp):
             la = sp[sp[:, 6] > 0]
+            nl = sp[sp[:, 6] == 0]
+            if len(nl) and (nl[:, 1] > 0).all():
+                print(f"    KG split blocks that are not last arrivers: scores ready {np.median(nl[:, 1] - nl[:, 0]) / 100:.2f} us, exp/PV done "
+                      f"{np.median(nl[:, 2] - nl[:, 0]) / 100:.2f}, partial stored {np.median(nl[:, 4] - nl[:, 0]) / 100:.2f}, ticket {np.median(nl[:, 5] - nl[:, 0]) / 100:.2f}")
             print(f"    KG->RG attention: {len(sp)} splits: split {np.median(sp[:, 4] - sp[:, 0]) / 100:.2f} us (max {(sp[:, 4] - sp[:, 0]).max() / 100:.2f}), "
                   f"drain+ticket {np.median(sp[:, 5] - sp[:, 4]) / 100:.2f} (max {(sp[:, 5] - sp[:, 4]).max() / 100:.2f}); {len(la)} last arrivers: "
                   f"start->ticket {np.median(la[:, 5] - la[:, 0]) / 100:.2f}, combine {np.median(la[:, 6] - la[:, 5]) / 100:.2f} us; "
