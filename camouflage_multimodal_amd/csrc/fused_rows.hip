@@ -677,7 +677,10 @@ __global__ __launch_bounds__(256, 2) void bwd1_kernel(const Bwd1Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool kg = (int)blockIdx.x < a.B;
+  // grid order: RG tiles, then the B KG blocks, then the writer blocks.  B + tiles exceeds the CU count by a few blocks at the
+  // benchmark size, and the blocks that have to share a CU start ~2.3 us late in this kernel: they had better be the KG
+  // blocks (15 us) than RG tiles (18-22 us), which then ended the kernel
+  const bool kg = (int)blockIdx.x >= a.rg_tiles_max && (int)blockIdx.x < a.rg_tiles_max + a.B;
   const int rot = ROT ? (int)(blockIdx.x >> 3) : 0;
   if ((int)blockIdx.x >= a.B + a.rg_tiles_max) {
     // writer blocks: materialise dH = mask * d(mean H) / n as the bf16 weight-gradient operand (the tiles above build the same
@@ -710,9 +713,9 @@ __global__ __launch_bounds__(256, 2) void bwd1_kernel(const Bwd1Args a) {
   }
   int b; size_t rowg0; int nrows; float inv_n;
   if (kg) {
-    b = blockIdx.x; rowg0 = (size_t)b * a.Nk; nrows = a.Nk; inv_n = 1.0f / (float)a.Nk;
+    b = (int)blockIdx.x - a.rg_tiles_max; rowg0 = (size_t)b * a.Nk; nrows = a.Nk; inv_n = 1.0f / (float)a.Nk;
   } else {
-    const int tile = (int)blockIdx.x - a.B;
+    const int tile = (int)blockIdx.x;
     if (tile >= a.tile_off[a.B]) return;
     int lo = 0, hi = a.B - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_off[mid] <= tile) lo = mid; else hi = mid - 1; }
