@@ -48,6 +48,7 @@ struct BackArgs {
   const us16* Q16; const us16* KV16;           // RG queries [T][256]; KG keys|values [B*Nk][512]
   const us16* Q2_16; const us16* KV2_16;       // KG queries [B*Nk][256]; RG keys|values [T][512]
   const int* off; const int* tile_off; const float* inv_nr;
+  const int4* tile_desc;                       // per 32-row RG tile {sample, first packed row, rows, 1 / Nr as bits}; sample = -1 past the last tile
   float* lse2;                                 // [B][8][16][2]: max and sum of the KG->RG softmax (saved for backward)
   float* part; int* tickets; int max_splits;   // KG->RG attention runs as ceil(Nr / 64) split blocks per sample (max_splits = the
                                                // largest count: grid sizing): partials [rg_tiles_max][8][FUSED_PART_FLOATS] indexed by
@@ -72,7 +73,7 @@ struct Bwd1Args {
   const us16* Q16; const us16* KV16;           // RG queries (pre-scaled) [T][256]; KG keys|values [B*Nk][512]
   us16* dQKV16; float* dKV;                    // out: dQ into columns 0..255 of [T][768]; dK|dV [B*Nk][512] += (atomics, zeroed by the caller)
   const us16* O2_16; us16* dO2_16; float* delta2;   // KG: attention output in, its gradient out [B*Nk][256], row-dots out [B][8][16]
-  const int* off; const int* tile_off; const float* inv_nr;
+  const int* off; const int* tile_off; const float* inv_nr; const int4* tile_desc;
   int B, Nk, rg_tiles_max, rows_rg; float qscale; DropCfg drop; unsigned long long* stamps;
   int writer_blocks;                           // (filled by the launcher)
 };
@@ -91,7 +92,7 @@ struct Bwd2Args {
   const us16* dU2_16; const us16* WcKgT; us16* dQKVkg16; us16* dG16;              // KG rows: [B*Nk][768] out (weight-gradient operand), [B*Nk][256] out
   float* dGpart;                               // [B*Nk][256] fp32 scratch: the part of dG an early block computes while the RG tiles run
   int* tickets;                                // [B] zeroed arrival counters (one per sample)
-  const int* off; const int* tile_off;
+  const int* off; const int* tile_off; const int4* tile_desc;
   int B, Nk, rg_tiles_max, rows_rg; float qscale; DropCfg drop; unsigned long long* stamps;
 };
 int launch_fused_bwd2(Bwd2Args& a, int variant, hipStream_t stream);

@@ -535,13 +535,11 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
     stamp(a.stamps, 6);
     rowg0 = (size_t)b * a.Nk; nrows = a.Nk; inv_n = 1.0f / (float)a.Nk;
   } else {
-    const int tile = (int)blockIdx.x - nkg;
-    if (tile >= a.tile_off[a.B]) return;
-    int lo = 0, hi = a.B - 1;                                              // sample of this tile: tile_off[b] <= tile < tile_off[b+1]
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_off[mid] <= tile) lo = mid; else hi = mid - 1; }
-    b = lo;
-    const int r0 = a.off[b] + 32 * (tile - a.tile_off[b]);
-    rowg0 = r0; nrows = min(32, a.off[b + 1] - r0); inv_n = a.inv_nr[b];
+    // one 16-byte load of the batch descriptor's tile table {sample, first row, rows, 1 / Nr} (a binary search of tile_off here was
+    // five dependent global loads: 1.5-2 us before a tile's first useful instruction)
+    const int4 td = a.tile_desc[(int)blockIdx.x - nkg];
+    if (td.x < 0) return;
+    b = td.x; rowg0 = td.y; nrows = td.z; inv_n = __int_as_float(td.w);
     attn_rg_tile(a, smem, b, rowg0, nrows, w, lane);
   }
   __syncthreads();
@@ -715,13 +713,9 @@ __global__ __launch_bounds__(256, 2) void bwd1_kernel(const Bwd1Args a) {
   if (kg) {
     b = (int)blockIdx.x - a.rg_tiles_max; rowg0 = (size_t)b * a.Nk; nrows = a.Nk; inv_n = 1.0f / (float)a.Nk;
   } else {
-    const int tile = (int)blockIdx.x;
-    if (tile >= a.tile_off[a.B]) return;
-    int lo = 0, hi = a.B - 1;
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_off[mid] <= tile) lo = mid; else hi = mid - 1; }
-    b = lo;
-    const int r0 = a.off[b] + 32 * (tile - a.tile_off[b]);
-    rowg0 = r0; nrows = min(32, a.off[b + 1] - r0); inv_n = a.inv_nr[b];
+    const int4 td = a.tile_desc[blockIdx.x];
+    if (td.x < 0) return;
+    b = td.x; rowg0 = td.y; nrows = td.z; inv_n = __int_as_float(td.w);
   }
   const Bwd1Stream& S = a.s[kg ? 1 : 0];
   us16* gtab = reinterpret_cast<us16*>(smem + W_GTAB);
@@ -1011,14 +1005,11 @@ __global__ __launch_bounds__(256, 2) void bwd2_kernel(const Bwd2Args a) {
         }
     }
   } else {
-  const int tile = (int)blockIdx.x - a.B;
-  if (tile >= a.tile_off[a.B]) return;
-  int lo = 0, hi = a.B - 1;
-  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.tile_off[mid] <= tile) lo = mid; else hi = mid - 1; }
-  b = lo;
-  const int r0t = a.off[b] + 32 * (tile - a.tile_off[b]);
-  const size_t rowg0 = r0t;
-  const int nrows = min(32, a.off[b + 1] - r0t);
+  const int4 td = a.tile_desc[(int)blockIdx.x - a.B];
+  if (td.x < 0) return;
+  b = td.x;
+  const size_t rowg0 = td.y;
+  const int nrows = td.z;
   const bool rok = l31 < nrows;
   const size_t vrow = rowg0 + min(l31, nrows - 1);
   Stage<2, 48, true, DEPTH, false> sr;
@@ -1246,7 +1237,7 @@ int launch_fused_front(FrontArgs& a, int variant, hipStream_t stream) {
 }
 
 int launch_fused_back(BackArgs& a, int variant, hipStream_t stream) {
-  if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q16 || !a.KV16 || !a.Q2_16 || !a.KV2_16 || !a.off || !a.tile_off || !a.inv_nr ||
+  if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q16 || !a.KV16 || !a.Q2_16 || !a.KV2_16 || !a.off || !a.tile_off || !a.tile_desc || !a.inv_nr ||
       !a.part || !a.tickets || a.max_splits < 1 || a.max_splits > FUSED_MAX_SPLITS)
     return (int)hipErrorInvalidValue;
   for (int i = 0; i < 2; ++i) {
@@ -1277,7 +1268,7 @@ size_t fused_bwd1_lds() { return W_LDS; }
 
 int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
   if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q16 || !a.KV16 || !a.dQKV16 || !a.dKV || !a.O2_16 || !a.dO2_16 || !a.delta2 ||
-      !a.off || !a.tile_off || !a.inv_nr)
+      !a.off || !a.tile_off || !a.tile_desc || !a.inv_nr)
     return (int)hipErrorInvalidValue;
   for (int i = 0; i < 2; ++i) {
     const Bwd1Stream& S = a.s[i];
@@ -1309,7 +1300,7 @@ size_t fused_bwd2_lds() { return X_LDS; }
 int launch_fused_bwd2(Bwd2Args& a, int variant, hipStream_t stream) {
   (void)variant;
   if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q2_16 || !a.dO2_16 || !a.lse2 || !a.delta2 || !a.KV2_16 || !a.dQKV16 ||
-      !a.dU16 || !a.WcRgT || !a.dR16 || !a.dQ2acc || !a.dKV || !a.dU2_16 || !a.WcKgT || !a.dQKVkg16 || !a.dG16 || !a.dGpart || !a.tickets || !a.off || !a.tile_off)
+      !a.dU16 || !a.WcRgT || !a.dR16 || !a.dQ2acc || !a.dKV || !a.dU2_16 || !a.WcKgT || !a.dQKVkg16 || !a.dG16 || !a.dGpart || !a.tickets || !a.off || !a.tile_off || !a.tile_desc)
     return (int)hipErrorInvalidValue;
   if (!al16(a.dQKV16) || !al16(a.dQKVkg16) || !al16(a.WcRgT) || !al16(a.WcKgT) || !al16(a.dQ2acc) || !al16(a.dKV)) return (int)hipErrorInvalidValue;
   static const bool attr = [] {

@@ -66,11 +66,12 @@ struct Carver {
 };
 
 // The batch descriptor (camo_prepare_batch): [ row -> sample map | 1 / Nr | first 32-row tile of every sample ]
-struct Desc { int* row_sample; float* inv_nr; int* tile_off; size_t bytes; };
+struct Desc { int* row_sample; float* inv_nr; int* tile_off; int4* tile_desc; size_t bytes; };
 Desc desc_carve(int B, int T, void* base) {
   Desc d{};
   Carver c(base);
   d.row_sample = c.take<int>((size_t)T); d.inv_nr = c.take<float>((size_t)B); d.tile_off = c.take<int>((size_t)B + 1);
+  d.tile_desc = c.take<int4>((size_t)T / 32 + B);       // one entry per block of the fused kernels' RG tile range
   c.off = (c.off + 255) & ~size_t(255);
   d.bytes = c.off;
   return d;
@@ -530,7 +531,7 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   ba.s[1] = BackStream{f.Wo2, P[CAMO_P_A2_OUT_B], f.W2, P[CAMO_P_F2_B0], P[CAMO_P_LN2_W], P[CAMO_P_LN2_B], f.G16,
                        f.O2_16, f.Y2_16, f.XH2_16, f.rstd2, f.mask2, w.Y2mean, w.H2mean, SITE_FFN_KG};
   ba.Q16 = f.Q16; ba.KV16 = f.KV16; ba.Q2_16 = f.Q2_16; ba.KV2_16 = f.KV2_16;
-  ba.off = rg_offsets; ba.tile_off = bd.tile_off; ba.inv_nr = bd.inv_nr; ba.lse2 = f.lse2;
+  ba.off = rg_offsets; ba.tile_off = bd.tile_off; ba.tile_desc = bd.tile_desc; ba.inv_nr = bd.inv_nr; ba.lse2 = f.lse2;
   ba.B = B; ba.Nk = Nk; ba.rows_rg = T; ba.rg_tiles_max = T / 32 + B;          // >= sum of ceil(Nr / 32); surplus blocks exit at once
   ba.part = f.part; ba.tickets = w.tickets; ba.max_splits = (max_nr + 63) / 64;
   ba.drop = drop; ba.save = save ? 1 : 0;
@@ -666,7 +667,7 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
                        Gr[CAMO_P_LN2_W], Gr[CAMO_P_LN2_B]};
   a1.Q16 = f.Q16; a1.KV16 = f.KV16; a1.dQKV16 = f.dQKV16; a1.dKV = w.dKV;
   a1.O2_16 = f.O2_16; a1.dO2_16 = f.dO2_16; a1.delta2 = f.delta2;
-  a1.off = rg_offsets; a1.tile_off = bd.tile_off; a1.inv_nr = bd.inv_nr;
+  a1.off = rg_offsets; a1.tile_off = bd.tile_off; a1.tile_desc = bd.tile_desc; a1.inv_nr = bd.inv_nr;
   a1.B = B; a1.Nk = Nk; a1.rows_rg = T; a1.rg_tiles_max = T / 32 + B; a1.qscale = 1.0f / sqrtf(32.0f); a1.drop = drop;
   a1.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)2 * g_dbg_stamp_blocks * 8 : nullptr;
   CK(launch_fused_bwd1(a1, g_opt_fused_variant, st), "fused backward, first half");
@@ -674,7 +675,7 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   a2.Q2_16 = f.Q2_16; a2.dO2_16 = f.dO2_16; a2.lse2 = f.lse2; a2.delta2 = f.delta2; a2.KV2_16 = f.KV2_16; a2.dQKV16 = f.dQKV16;
   a2.dU16 = f.dU16; a2.WcRgT = f.WcRgT; a2.dR16 = f.dR16; a2.dQ2acc = w.dQ2acc; a2.dKV = w.dKV;
   a2.dU2_16 = f.dU2_16; a2.WcKgT = f.WcKgT; a2.dQKVkg16 = f.dQKVkg16; a2.dG16 = f.dG16; a2.dGpart = f.dGpart;
-  a2.tickets = w.tickets + B; a2.off = rg_offsets; a2.tile_off = bd.tile_off;
+  a2.tickets = w.tickets + B; a2.off = rg_offsets; a2.tile_off = bd.tile_off; a2.tile_desc = bd.tile_desc;
   a2.B = B; a2.Nk = Nk; a2.rows_rg = T; a2.rg_tiles_max = T / 32 + B; a2.qscale = a1.qscale; a2.drop = drop;
   a2.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)3 * g_dbg_stamp_blocks * 8 : nullptr;
   CK(launch_fused_bwd2(a2, g_opt_fused_variant, st), "fused backward, second half");
@@ -715,7 +716,7 @@ int camo_prepare_batch(const int32_t* rg_offsets, int32_t B, int32_t T, int32_t 
   if (!rg_offsets || !desc || B < 1 || T < B || max_nr < 1 || max_nr > T) return fail(CAMO_E_ARG, "bad prepare_batch arguments");
   const Desc d = desc_carve(B, T, desc);
   if (desc_bytes < d.bytes) return fail(CAMO_E_WORKSPACE, "descriptor buffer smaller than camo_batch_desc_bytes()");
-  CK(launch_rowmap(rg_offsets, d.row_sample, d.inv_nr, d.tile_off, B, max_nr, static_cast<hipStream_t>(stream)), "rowmap");
+  CK(launch_rowmap(rg_offsets, d.row_sample, d.inv_nr, d.tile_off, d.tile_desc, B, T / 32 + B, max_nr, static_cast<hipStream_t>(stream)), "rowmap");
   return 0;
 }
 

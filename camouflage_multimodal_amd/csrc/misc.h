@@ -28,7 +28,7 @@ struct PrepBatch { PrepJob j[PREP_MAXJ]; int n; };
 int launch_prep(PrepBatch& pb, hipStream_t stream);
 
 int ln_supported(int H);
-int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int* tile_off, int B, int max_nr, hipStream_t stream);
+int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int* tile_off, int4* tile_desc, int B, int ntile_max, int max_nr, hipStream_t stream);
 int launch_ln_fwd(const LnSeg& s0, const LnSeg& s1, int H, hipStream_t stream);
 int launch_ln_bwd(const LnBwdSeg& s0, const LnBwdSeg& s1, int H, hipStream_t stream);
 int launch_seg_mean(const SegMean* segs, int nseg, int B, int max_rows, hipStream_t stream);

@@ -36,6 +36,22 @@ __global__ __launch_bounds__(256) void tileoff_kernel(const int* __restrict__ of
   for (int b = b0; b < b1; ++b) { tile_off[b] = acc; acc += (offs[b + 1] - offs[b] + 31) >> 5; }
 }
 
+// per 32-row tile of the fused kernels: {sample, first packed row, rows in the tile, 1 / Nr}; sample = -1 for the unused tail
+// of the table (the launches size their tile range by the bound T / 32 + B)
+__global__ __launch_bounds__(256) void tiledesc_kernel(const int* __restrict__ offs, const int* __restrict__ tile_off, int4* __restrict__ tile_desc,
+                                                       int B, int ntile_max) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntile_max) return;
+  int4 d = make_int4(-1, 0, 0, 0);
+  if (t < tile_off[B]) {
+    int lo = 0, hi = B - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= t) lo = mid; else hi = mid - 1; }
+    const int r0 = offs[lo] + 32 * (t - tile_off[lo]), nr = offs[lo + 1] - offs[lo];
+    d = make_int4(lo, r0, min(32, offs[lo + 1] - r0), __float_as_int(1.0f / (float)nr));
+  }
+  tile_desc[t] = d;
+}
+
 // ---------------------------------------------------------------- LayerNorm forward
 // y = (u - mean) * rstd * gamma + beta, eps 1e-5 (nn.LayerNorm default, fusion_model.py:49-50)
 // A wave owns LNF_R consecutive rows.  Optional fused mean pool (S.mean): the wave keeps per-lane column sums
@@ -1100,9 +1116,10 @@ int launch_prep(PrepBatch& pb, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int* tile_off, int B, int max_nr, hipStream_t stream) {
+int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int* tile_off, int4* tile_desc, int B, int ntile_max, int max_nr, hipStream_t stream) {
   hipLaunchKernelGGL(rowmap_kernel, dim3((max_nr + 255) / 256, B), dim3(256), 0, stream, offs, row_sample, inv_nr);
   hipLaunchKernelGGL(tileoff_kernel, dim3(1), dim3(256), 0, stream, offs, tile_off, B);
+  hipLaunchKernelGGL(tiledesc_kernel, dim3((ntile_max + 255) / 256), dim3(256), 0, stream, offs, tile_off, tile_desc, B, ntile_max);
   return (int)hipGetLastError();
 }
 

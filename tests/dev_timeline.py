@@ -65,10 +65,10 @@ for k, name in enumerate(("front", "back", "bwd1", "bwd2") if train else ("front
     act = (s[:, 0] > 0) & (s[:, 3] > 0)          # (blocks that return early leave later stamps empty)
     s = s[act].astype(np.float64)
     t0 = s[:, 0].min()
-    if name == "bwd1":
+    if name in ("bwd1", "bwd2", "back", "front"):
         st0 = st[k][:, 0].astype(np.float64); ok = st0 > 0
         ids = np.nonzero(ok)[0]; late = ids[np.argsort(-st0[ok])[:14]]
-        print("    bwd1 latest starters (block id: start us):", ", ".join(f"{i}: {(st0[i] - st0[ok].min()) / 100:.2f}" for i in sorted(late)))
+        print(f"    {name} latest starters (block id: start us):", ", ".join(f"{i}: {(st0[i] - st0[ok].min()) / 100:.2f}" for i in sorted(late)))
     print(f"--- {name} (variant {variant}): {act.sum()} blocks, kernel span {(s[:, 3].max() - t0) / 100:.2f} us; first block starts at 0, last starts at {(s[:, 0].max() - t0) / 100:.2f} us")
     ph = np.diff(s[:, :4], axis=1) / 100.0
     idx = np.nonzero(act)[0]
