@@ -609,19 +609,22 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
   };
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   tstamp(a.stamps, 0);
-  // ---- every global read of the forward that depends on nothing: issued now, one memory round trip for all of them
+  // ---- every global read of the forward that depends on nothing: issued now, one memory round trip for all of them; what
+  // the first layer needs comes first (loads return in order), the rest lands while that layer runs
   // (weight rows go through LDS: one 16-byte load per thread instead of 40 dword loads that four quarters would repeat)
   const float4 w3l = *reinterpret_cast<const float4*>(W3s + (size_t)(c0 + (tid >> 7)) * 512 + 4 * (tid & 127));
-  const float4 wfl = tid < 256 ? *reinterpret_cast<const float4*>(a.Wfu3 + (size_t)(4 * g + (tid >> 6)) * 256 + 4 * (tid & 63)) : z4;
   float4 hv[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) { const int i = tid + TF_THREADS * it; hv[it] = i < B * 128 ? reinterpret_cast<const float4*>(Hmean)[i] : z4; }
+  const float ymv = tid < B * 8 ? Ymean[(tid >> 3) * 256 + c0 + (tid & 7)] + b3s[c0 + (tid & 7)] : 0.f;
+  const float4 wfl = tid < 256 ? *reinterpret_cast<const float4*>(a.Wfu3 + (size_t)(4 * g + (tid >> 6)) * 256 + 4 * (tid & 63)) : z4;
+  float4 wb0 = z4, wb1 = z4, wav = z4;
   if (q == 0) {
     const float4* p = reinterpret_cast<const float4*>(a.Wfu0 + (size_t)t * 512 + ccol);
-    reinterpret_cast<float4*>(wB)[2 * t] = p[0]; reinterpret_cast<float4*>(wB)[2 * t + 1] = p[1];
+    wb0 = p[0]; wb1 = p[1];
   } else if (q < 3) {
     const int m = tid - 256;
-    reinterpret_cast<float4*>(wA)[m] = *reinterpret_cast<const float4*>(headW0(m >> 7) + (size_t)(m & 127) * 256 + 4 * g);
+    wav = *reinterpret_cast<const float4*>(headW0(m >> 7) + (size_t)(m & 127) * 256 + 4 * g);
   }
   float w3v[3];                                              // (Wd * 129 <= 2322 elements: at most 3 per thread)
 #pragma unroll
@@ -634,7 +637,6 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
       w3v[it] = k < 128 ? headW3(x)[(size_t)oo * 128 + k] : headB3(x)[oo];
     }
   }
-  if (tid < 128) ymS[tid] = tid < B * 8 ? Ymean[(tid >> 3) * 256 + c0 + (tid & 7)] + b3s[c0 + (tid & 7)] : 0.f;
   const float bias2 = g == 0 ? a.bfu0[t] : 0.f;
   const float bias3 = a.bfu3[4 * g + wv];
   const float bias4a = g == 0 ? headB0(t >> 7)[t & 127] : 0.f, bias4b = g == 0 ? headB0(2 + (t >> 7))[t & 127] : 0.f;
@@ -661,10 +663,8 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
   }
 #pragma unroll
   for (int it = 0; it < 2; ++it) { const int i = tid + TF_THREADS * it; if (i < B4 * 128) reinterpret_cast<float4*>(R1)[i] = hv[it]; }
-#pragma unroll
-  for (int it = 0; it < 3; ++it) { const int p = tid + TF_THREADS * it; if (p < Wd * 129) w3s[p] = w3v[it]; }
   reinterpret_cast<float4*>(W3L)[tid] = w3l;
-  if (tid < 256) reinterpret_cast<float4*>(WfL)[tid] = wfl;
+  if (tid < 128) ymS[tid] = ymv;
   __syncthreads();
   tstamp(a.stamps, 1);
   // ---- L1 (by output column): comb[b][c] = mean Y + (mean H) . W3^T + b3, c in this block's 8 columns; wave wv: columns 2wv, 2wv+1
@@ -683,6 +683,12 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
       }
     }
   }
+  // the operands of the later layers have landed meanwhile
+  if (q == 0) { reinterpret_cast<float4*>(wB)[2 * t] = wb0; reinterpret_cast<float4*>(wB)[2 * t + 1] = wb1; }
+  else if (q < 3) reinterpret_cast<float4*>(wA)[tid - 256] = wav;
+#pragma unroll
+  for (int it = 0; it < 3; ++it) { const int p = tid + TF_THREADS * it; if (p < Wd * 129) w3s[p] = w3v[it]; }
+  if (tid < 256) reinterpret_cast<float4*>(WfL)[tid] = wfl;
   __syncthreads();
   tstamp(a.stamps, 2);
   // ---- L2 (by input column): partial sums of fusion layer 0's 256 outputs; thread t owns output t
