@@ -31,7 +31,14 @@ struct FrontStream {
   us16* R16; us16* Q16; us16* KV16;            // [M][256] projection, [M][256] queries (pre-scaled by 1/sqrt(32)), [M][512] keys|values
   int tile_begin;
 };
-struct FrontArgs { FrontStream s[2]; float qscale; int save; unsigned long long* stamps; };
+#define FUSED_FRONT_MAXZ 4
+#define FUSED_BWD1_MAXZ 16
+struct FrontArgs {
+  FrontStream s[2]; float qscale; int save; unsigned long long* stamps;
+  // clears that ride at the end of every block when no shadow launch precedes this one (the step's atomics block, d(mean H)):
+  // 16-byte aligned, sizes multiples of 16; spread over the grid
+  void* zero_ptr[FUSED_FRONT_MAXZ]; unsigned zero_bytes[FUSED_FRONT_MAXZ]; int nzero;
+};
 int launch_fused_front(FrontArgs& a, int variant, hipStream_t stream);   // variant: 0 <depth 12>, 1 <depth 12, rotated k order> (default), 2 <depth 16, rotated>
 
 // ---- forward, back half
@@ -76,6 +83,8 @@ struct Bwd1Args {
   const int* off; const int* tile_off; const float* inv_nr; const int4* tile_desc;
   int B, Nk, rg_tiles_max, rows_rg; float qscale; DropCfg drop; unsigned long long* stamps;
   int writer_blocks;                           // (filled by the launcher)
+  // clears for the weight-gradient launch (pad rows of its operands) when no shadow launch did them: one extra block each
+  void* zero_ptr[FUSED_BWD1_MAXZ]; unsigned zero_bytes[FUSED_BWD1_MAXZ]; int nzero;
 };
 int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream);
 size_t fused_bwd1_lds();

@@ -219,6 +219,11 @@ __global__ __launch_bounds__(256, 2) void front_kernel(const FrontArgs a) {
   copy_out<6>(bufQ, PQ, 512, S.KV16, 512, row0, nrows);
   copy_out<5>(bufR, PR, 0, S.R16, 256, row0, nrows);
   if (a.save) copy_out<4>(bufX, PX, 0, S.X16, 128, row0, nrows);
+  for (int zi = 0; zi < a.nzero; ++zi) {                    // (behind the tile's own stores: nothing of this block waits for them)
+    u32x4* z = static_cast<u32x4*>(a.zero_ptr[zi]);
+    const unsigned n16 = a.zero_bytes[zi] >> 4;
+    for (unsigned i = blockIdx.x * 256 + tid; i < n16; i += gridDim.x * 256) z[i] = u32x4{0u, 0u, 0u, 0u};
+  }
   stamp(a.stamps, 3);
 }
 
@@ -680,6 +685,13 @@ __global__ __launch_bounds__(256, 2) void bwd1_kernel(const Bwd1Args a) {
   // blocks (15 us) than RG tiles (18-22 us), which then ended the kernel
   const bool kg = (int)blockIdx.x >= a.rg_tiles_max && (int)blockIdx.x < a.rg_tiles_max + a.B;
   const int rot = ROT ? (int)(blockIdx.x >> 3) : 0;
+  if ((int)blockIdx.x >= a.B + a.rg_tiles_max + a.writer_blocks) {       // one clearing block per range (see Bwd1Args)
+    const int zi = (int)blockIdx.x - a.B - a.rg_tiles_max - a.writer_blocks;
+    u32x4* z = static_cast<u32x4*>(a.zero_ptr[zi]);
+    const unsigned n16 = a.zero_bytes[zi] >> 4;
+    for (unsigned i = tid; i < n16; i += 256) z[i] = u32x4{0u, 0u, 0u, 0u};
+    return;
+  }
   if ((int)blockIdx.x >= a.B + a.rg_tiles_max) {
     // writer blocks: materialise dH = mask * d(mean H) / n as the bf16 weight-gradient operand (the tiles above build the same
     // values on the fly and never store them: a store stream in the middle of their weight stream would stall it).
@@ -1220,6 +1232,9 @@ int launch_fused_front(FrontArgs& a, int variant, hipStream_t stream) {
     S.tile_begin = total;
     total += (S.M + 31) / 32;
   }
+  if (a.nzero < 0 || a.nzero > FUSED_FRONT_MAXZ) return (int)hipErrorInvalidValue;
+  for (int i = 0; i < a.nzero; ++i)
+    if (!a.zero_ptr[i] || !al16(a.zero_ptr[i]) || (a.zero_bytes[i] & 15)) return (int)hipErrorInvalidValue;
   static const bool attr = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel<12, false>), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel<12, true>), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
@@ -1285,7 +1300,10 @@ int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
   (void)attr;
   a.writer_blocks = (a.rows_rg + a.B * a.Nk + 3) / 4;                // one row per wave: a pass is a dependent load -> store chain
   if (a.writer_blocks > 8192) a.writer_blocks = 8192;
-  const dim3 grid(a.B + a.rg_tiles_max + a.writer_blocks);
+  if (a.nzero < 0 || a.nzero > FUSED_BWD1_MAXZ) return (int)hipErrorInvalidValue;
+  for (int i = 0; i < a.nzero; ++i)
+    if (!a.zero_ptr[i] || !al16(a.zero_ptr[i]) || (a.zero_bytes[i] & 15)) return (int)hipErrorInvalidValue;
+  const dim3 grid(a.B + a.rg_tiles_max + a.writer_blocks + a.nzero);
   // executed FLOPs per row: dY (512 -> 256), dO (256 -> 256); RG rows: the RG->KG attention backward (5 products of Nk x 256)
   const double rows = (double)a.rows_rg + (double)a.B * a.Nk;
   const int prof = gemm_prof_open(stream, 2.0 * rows * (512.0 * 256.0 + 256.0 * 256.0) + 10.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BWD1);

@@ -475,6 +475,35 @@ bool fused17_ok(const camo_dims_t& d, const float* const* P, int precision, int 
          P[CAMO_P_RG_PROJ_W] && P[CAMO_P_KG_PROJ_W];
 }
 
+// camo_forward_loss_backward's optional caller-owned weight shadows (camo_shadow_bytes): the 14 fragment-order bf16 copies the
+// fused kernels stream live there instead of in the per-batch workspace, so that the optimizer call can leave them ready for
+// the next step (camo_clip_adamw_shadows) and the forward need not rebuild them (CAMO_FLAG_SHADOWS_VALID).
+static thread_local void* t_zero_front_ptr[FUSED_FRONT_MAXZ]; static thread_local unsigned t_zero_front_bytes[FUSED_FRONT_MAXZ];
+static thread_local int t_nzero_front = 0;
+static thread_local void* t_zero_bwd1_ptr[FUSED_BWD1_MAXZ]; static thread_local unsigned t_zero_bwd1_bytes[FUSED_BWD1_MAXZ];
+static thread_local int t_nzero_bwd1 = 0;
+static thread_local void* t_shadows = nullptr;
+static thread_local bool t_shadows_valid = false;
+struct ShadowSet { us16 *Wrg, *Wkg, *Wqkv_rg, *Wqkv_kg, *Wo1, *Wo2, *W1, *W2, *W1T, *W2T, *Wo1T, *Wo2T, *WcRgT, *WcKgT; size_t bytes; };
+static ShadowSet shadow_carve(void* base) {
+  ShadowSet x{};
+  Carver c(base);
+  const size_t H = 256, D = 128, HH = H * H;
+  x.Wrg = c.take<us16>(H * D); x.Wkg = c.take<us16>(H * D); x.Wqkv_rg = c.take<us16>(3 * HH); x.Wqkv_kg = c.take<us16>(3 * HH);
+  x.Wo1 = c.take<us16>(HH); x.Wo2 = c.take<us16>(HH); x.W1 = c.take<us16>(2 * HH); x.W2 = c.take<us16>(2 * HH);
+  x.W1T = c.take<us16>(2 * HH); x.W2T = c.take<us16>(2 * HH); x.Wo1T = c.take<us16>(HH); x.Wo2T = c.take<us16>(HH);
+  x.WcRgT = c.take<us16>(3 * HH); x.WcKgT = c.take<us16>(3 * HH);
+  x.bytes = (c.off + 255) & ~size_t(255);
+  return x;
+}
+static void bind_shadows(Ws& w) {                 // (after every carve() of a call that was handed external shadows)
+  if (!t_shadows) return;
+  const ShadowSet x = shadow_carve(t_shadows);
+  Ws::F17& f = w.f;
+  f.Wrg = x.Wrg; f.Wkg = x.Wkg; f.Wqkv_rg = x.Wqkv_rg; f.Wqkv_kg = x.Wqkv_kg; f.Wo1 = x.Wo1; f.Wo2 = x.Wo2; f.W1 = x.W1; f.W2 = x.W2;
+  f.W1T = x.W1T; f.W2T = x.W2T; f.Wo1T = x.Wo1T; f.Wo2T = x.Wo2T; f.WcRgT = x.WcRgT; f.WcKgT = x.WcKgT;
+}
+
 int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg, const int32_t* rg_offsets, const Desc& bd,
                     const float* kg, int B, int T, int Nk, int max_nr, const Ws& w, const DropCfg& drop, bool save, hipStream_t st) {
   const int H = 256, D = 128, TK = B * Nk;
@@ -487,11 +516,14 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
       J.dst = dst; J.N = N; J.K = K; J.transposed = 0; J.nsrc = s1 ? 2 : 1;
       J.src[0] = s0; J.rows[0] = r0; J.ld[0] = K; J.src[1] = s1; J.rows[1] = r1; J.ld[1] = K;
     };
+    const bool build = !t_shadows_valid;        // (valid: camo_clip_adamw_shadows left them ready; only the clears ride in this launch)
+    if (build) {
     job(f.Wrg, H, D, P[CAMO_P_RG_PROJ_W], H); job(f.Wkg, H, D, P[CAMO_P_KG_PROJ_W], H);
     job(f.Wqkv_rg, 3 * H, H, P[CAMO_P_A1_IN_W], H, P[CAMO_P_A2_IN_W] + HH, 2 * H);       // [Wq1; Wk2; Wv2]: what RG rows are projected with
     job(f.Wqkv_kg, 3 * H, H, P[CAMO_P_A2_IN_W], H, P[CAMO_P_A1_IN_W] + HH, 2 * H);       // [Wq2; Wk1; Wv1]
     job(f.Wo1, H, H, P[CAMO_P_A1_OUT_W], H); job(f.Wo2, H, H, P[CAMO_P_A2_OUT_W], H);
     job(f.W1, 2 * H, H, P[CAMO_P_F1_W0], 2 * H); job(f.W2, 2 * H, H, P[CAMO_P_F2_W0], 2 * H);
+    }
     auto zero = [&](void* ptr, size_t bytes) { if (bytes) { sb.zero_ptr[sb.nzero] = ptr; sb.zero_bytes[sb.nzero++] = (bytes + 15) & ~size_t(15); } };
     if (save) {
       // transposed shadows of the backward's dy . W products; K-concatenated where one product serves three in-projections
@@ -500,10 +532,12 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
         J.dst = dst; J.N = N; J.K = K; J.transposed = 1; J.nsrc = s1 ? 2 : 1;
         J.src[0] = s0; J.rows[0] = r0; J.ld[0] = N; J.src[1] = s1; J.rows[1] = r1; J.ld[1] = N;
       };
+      if (build) {
       jobT(f.W1T, H, 2 * H, P[CAMO_P_F1_W0], 2 * H); jobT(f.W2T, H, 2 * H, P[CAMO_P_F2_W0], 2 * H);
       jobT(f.Wo1T, H, H, P[CAMO_P_A1_OUT_W], H); jobT(f.Wo2T, H, H, P[CAMO_P_A2_OUT_W], H);
       jobT(f.WcRgT, H, 3 * H, P[CAMO_P_A1_IN_W], H, P[CAMO_P_A2_IN_W] + HH, 2 * H);      // dR = [dQ | dK2 | dV2] . [Wq1; Wk2; Wv2]
       jobT(f.WcKgT, H, 3 * H, P[CAMO_P_A2_IN_W], H, P[CAMO_P_A1_IN_W] + HH, 2 * H);      // dG = [dQ2 | dK | dV] . [Wq2; Wk1; Wv1]
+      }
       zero(w.zero_base, w.zero_bytes);                       // means, dfused, arrival counters, dK|dV and dQ2 sums
       // pad rows (row count rounded up to 128) of every weight-gradient operand: the contraction runs over whole 64-row tiles
       const size_t t = T, tk = TK;
@@ -517,13 +551,35 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
       zero(w.zero_base, (size_t)(reinterpret_cast<char*>(w.dKV) - reinterpret_cast<char*>(w.zero_base)));
       zero(w.tailsum, ((size_t)B * 4 * H + 4) * sizeof(float));
     }
-    CK(launch_weight_shadows(sb, st), "weight shadows");
+    if (build) {
+      CK(launch_weight_shadows(sb, st), "weight shadows");
+      t_nzero_front = t_nzero_bwd1 = 0;
+    } else {
+      // no shadow launch this step: the clears ride elsewhere -- the atomics block and d(mean H) at the end of the front
+      // kernel's blocks (first use: the back kernel's pooled sums), the operand pad rows in extra blocks of the first backward
+      // kernel (first use: the weight-gradient launch)
+      t_nzero_front = t_nzero_bwd1 = 0;
+      for (int i = 0; i < sb.nzero; ++i) {
+        const bool early = sb.zero_ptr[i] == (void*)w.zero_base || sb.zero_ptr[i] == (void*)w.dHm1 || sb.zero_ptr[i] == (void*)w.dHm2 || sb.zero_ptr[i] == (void*)w.tailsum;
+        if (sb.zero_bytes[i] > 0xFFFFFFF0ull) return fail(CAMO_E_ARG, "clear range too large");
+        if (early) {
+          if (t_nzero_front >= FUSED_FRONT_MAXZ) return fail(CAMO_E_ARG, "too many early clear ranges");
+          t_zero_front_ptr[t_nzero_front] = sb.zero_ptr[i]; t_zero_front_bytes[t_nzero_front++] = (unsigned)sb.zero_bytes[i];
+        } else {
+          if (t_nzero_bwd1 >= FUSED_BWD1_MAXZ) return fail(CAMO_E_ARG, "too many late clear ranges");
+          t_zero_bwd1_ptr[t_nzero_bwd1] = sb.zero_ptr[i]; t_zero_bwd1_bytes[t_nzero_bwd1++] = (unsigned)sb.zero_bytes[i];
+        }
+      }
+    }
   }
   FrontArgs fa; std::memset(&fa, 0, sizeof(fa));
   fa.qscale = 1.0f / sqrtf(32.0f); fa.save = save ? 1 : 0;
   fa.s[0] = FrontStream{rg, T, f.Wrg, P[CAMO_P_RG_PROJ_B], f.Wqkv_rg, P[CAMO_P_A1_IN_B], P[CAMO_P_A2_IN_B] + H, f.X16, f.R16, f.Q16, f.KV2_16, 0};
   fa.s[1] = FrontStream{kg, TK, f.Wkg, P[CAMO_P_KG_PROJ_B], f.Wqkv_kg, P[CAMO_P_A2_IN_B], P[CAMO_P_A1_IN_B] + H, f.KG16, f.G16, f.Q2_16, f.KV16, 0};
   fa.stamps = g_dbg_stamps;
+  fa.nzero = t_nzero_front;
+  for (int i = 0; i < t_nzero_front; ++i) { fa.zero_ptr[i] = t_zero_front_ptr[i]; fa.zero_bytes[i] = t_zero_front_bytes[i]; }
+  t_nzero_front = 0;
   CK(launch_fused_front(fa, g_opt_fused_variant, st), "fused forward, front half");
   BackArgs ba; std::memset(&ba, 0, sizeof(ba));
   ba.s[0] = BackStream{f.Wo1, P[CAMO_P_A1_OUT_B], f.W1, P[CAMO_P_F1_B0], P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], f.R16,
@@ -670,6 +726,9 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   a1.off = rg_offsets; a1.tile_off = bd.tile_off; a1.tile_desc = bd.tile_desc; a1.inv_nr = bd.inv_nr;
   a1.B = B; a1.Nk = Nk; a1.rows_rg = T; a1.rg_tiles_max = T / 32 + B; a1.qscale = 1.0f / sqrtf(32.0f); a1.drop = drop;
   a1.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)2 * g_dbg_stamp_blocks * 8 : nullptr;
+  a1.nzero = t_nzero_bwd1;
+  for (int i = 0; i < t_nzero_bwd1; ++i) { a1.zero_ptr[i] = t_zero_bwd1_ptr[i]; a1.zero_bytes[i] = t_zero_bwd1_bytes[i]; }
+  t_nzero_bwd1 = 0;
   CK(launch_fused_bwd1(a1, g_opt_fused_variant, st), "fused backward, first half");
   Bwd2Args a2; std::memset(&a2, 0, sizeof(a2));
   a2.Q2_16 = f.Q2_16; a2.dO2_16 = f.dO2_16; a2.lse2 = f.lse2; a2.delta2 = f.delta2; a2.KV2_16 = f.KV2_16; a2.dQKV16 = f.dQKV16;
@@ -734,7 +793,8 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   if (max_nr < 1 || max_nr > T) return fail(CAMO_E_ARG, "max_nr out of range");
   if (precision != CAMO_PREC_F32 && precision != CAMO_PREC_BF16) return fail(CAMO_E_ARG, "unknown precision");
   const camo_dims_t& d = *dims;
-  const Ws w = carve(d, B, T, Nk, workspace);
+  Ws w = carve(d, B, T, Nk, workspace);
+  bind_shadows(w);
   if (workspace_bytes < w.bytes) return fail(CAMO_E_WORKSPACE, "workspace smaller than camo_workspace_bytes()");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const DropCfg drop = make_drop(training, d.dropout, seed);
@@ -853,7 +913,8 @@ static int backward_impl(const camo_dims_t* dims, const float* const* params, fl
   if (max_nr < 1 || max_nr > T) return fail(CAMO_E_ARG, "max_nr out of range");
   if (precision != CAMO_PREC_F32 && precision != CAMO_PREC_BF16) return fail(CAMO_E_ARG, "unknown precision");
   const camo_dims_t& d = *dims;
-  const Ws w = carve(d, B, T, Nk, workspace);
+  Ws w = carve(d, B, T, Nk, workspace);
+  bind_shadows(w);
   if (workspace_bytes < w.bytes) return fail(CAMO_E_WORKSPACE, "workspace smaller than camo_workspace_bytes()");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const DropCfg drop = make_drop(training, d.dropout, seed);
@@ -960,11 +1021,19 @@ int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* para
                                const int32_t* rg_offsets, const void* batch_desc, const float* kg,
                                int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes,
                                const int64_t* y, const float* e, const float* s, float* outs, float* loss_terms, int32_t* pred,
-                               int32_t training, uint64_t seed, int32_t precision, void* tail_event, void* stream) {
+                               int32_t training, uint64_t seed, int32_t precision, void* tail_event, void* shadows,
+                               int32_t shadows_valid, void* stream) {
   if (!dims || !grads || !y || !e || !s || !outs || !loss_terms) return fail(CAMO_E_ARG, "null pointer argument");
+  if (shadows_valid && !shadows) return fail(CAMO_E_ARG, "shadows_valid without a shadow buffer");
+  // external shadows are used by the fused schedule only; whether the call takes it is known from its arguments
+  const bool ext = shadows && params && !check_dims(dims, B, T, Nk) && fused17_ok(*dims, params, precision, Nk, max_nr);
+  if (shadows_valid && !ext) return fail(CAMO_E_ARG, "shadows_valid on a call that does not take the fused schedule");
+  if (ext && (reinterpret_cast<uintptr_t>(shadows) & 255)) return fail(CAMO_E_ARG, "the shadow buffer must be 256-byte aligned");
+  t_shadows = ext ? shadows : nullptr; t_shadows_valid = ext && shadows_valid != 0;
   t_tail_event = static_cast<hipEvent_t>(tail_event);
   const int rc = forward_loss_backward_impl(dims, params, grads, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace,
                                             workspace_bytes, y, e, s, outs, loss_terms, pred, training, seed, precision, stream);
+  t_shadows = nullptr; t_shadows_valid = false;
   if (rc == 0) { CK(record_tail_event(static_cast<hipStream_t>(stream)), "tail event"); }   // (schedules without an early point)
   t_tail_event = nullptr;
   return rc;
@@ -983,7 +1052,8 @@ static int forward_loss_backward_impl(const camo_dims_t* dims, const float* cons
     const FusedLoss fl{y, e, s, loss_terms, pred, grads + head0};
     if (int rc = forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
                               nullptr, nullptr, training, seed, precision, 0, stream, nullptr, &fl)) return rc;
-    const Ws w = carve(*dims, B, T, Nk, workspace);
+    Ws w = carve(*dims, B, T, Nk, workspace);
+    bind_shadows(w);
     const Desc bd = desc_carve(B, T, const_cast<void*>(batch_desc));
     CK(record_tail_event(static_cast<hipStream_t>(stream)), "tail event");
     return backward_nodes17(*dims, params, grads, rg_offsets, bd, B, T, Nk, w, make_drop(training, dims->dropout, seed),
@@ -1018,6 +1088,62 @@ int camo_loss(const float* outs, const int64_t* y, const float* e, const float* 
 int camo_grad_sumsq(const float* g, size_t n, float* sumsq, void* stream) {
   if (!g || !sumsq || n == 0) return fail(CAMO_E_ARG, "null pointer or empty buffer");
   CK(launch_sumsq(g, n, sumsq, static_cast<hipStream_t>(stream)), "grad sumsq");
+  return 0;
+}
+
+size_t camo_shadow_bytes(const camo_dims_t* dims) {
+  if (!dims || !fused17_dims(*dims)) return 0;
+  return shadow_carve(nullptr).bytes;
+}
+
+int camo_clip_adamw_shadows(const camo_dims_t* dims, const float* const* params, float* p, float* g, float* m, float* v, size_t n,
+                            float* sumsq, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                            int32_t step, int32_t zero_grads, void* shadows, void* stream) {
+  if (!dims || !params || !p || !g || !m || !v || !sumsq || !shadows || n == 0) return fail(CAMO_E_ARG, "null pointer or empty buffer");
+  if (step < 1) return fail(CAMO_E_ARG, "step is 1-based");
+  if (!fused17_dims(*dims)) return fail(CAMO_E_UNSUPPORTED, "weight shadows exist for the fused schedule's configuration only");
+  if (reinterpret_cast<uintptr_t>(shadows) & 255) return fail(CAMO_E_ARG, "the shadow buffer must be 256-byte aligned");
+  const int H = 256, D = 128;
+  const size_t HH = (size_t)H * H;
+  const ShadowSet x = shadow_carve(shadows);
+  AdamShadowArgs a; std::memset(&a, 0, sizeof(a));
+  struct Cov { size_t off, len; } cov[ADAM_SHADOW_MAXB];
+  int ncov = 0;
+  bool ok = true;
+  auto blk = [&](const float* src, int rows, int cols, us16* plain, int pN, int pn0, us16* trans, int tK, int tk0) {
+    if (!src || src < p || src + (size_t)rows * cols > p + n) { ok = false; return; }
+    AdamShadowBlock& B = a.blk[a.nblk++];
+    B.off = (size_t)(src - p); B.rows = rows; B.cols = cols; B.plain = plain; B.pN = pN; B.pn0 = pn0; B.trans = trans; B.tK = tK; B.tk0 = tk0;
+    cov[ncov++] = Cov{B.off, (size_t)rows * cols};
+  };
+  const float* const* P = params;
+  blk(P[CAMO_P_RG_PROJ_W], H, D, x.Wrg, H, 0, nullptr, 0, 0);
+  blk(P[CAMO_P_KG_PROJ_W], H, D, x.Wkg, H, 0, nullptr, 0, 0);
+  blk(P[CAMO_P_A1_IN_W], H, H, x.Wqkv_rg, 3 * H, 0, x.WcRgT, 3 * H, 0);                    // Wq1
+  blk(P[CAMO_P_A1_IN_W] ? P[CAMO_P_A1_IN_W] + HH : nullptr, 2 * H, H, x.Wqkv_kg, 3 * H, H, x.WcKgT, 3 * H, H);   // Wk1 | Wv1
+  blk(P[CAMO_P_A2_IN_W], H, H, x.Wqkv_kg, 3 * H, 0, x.WcKgT, 3 * H, 0);                    // Wq2
+  blk(P[CAMO_P_A2_IN_W] ? P[CAMO_P_A2_IN_W] + HH : nullptr, 2 * H, H, x.Wqkv_rg, 3 * H, H, x.WcRgT, 3 * H, H);   // Wk2 | Wv2
+  blk(P[CAMO_P_A1_OUT_W], H, H, x.Wo1, H, 0, x.Wo1T, H, 0);
+  blk(P[CAMO_P_A2_OUT_W], H, H, x.Wo2, H, 0, x.Wo2T, H, 0);
+  blk(P[CAMO_P_F1_W0], 2 * H, H, x.W1, 2 * H, 0, x.W1T, 2 * H, 0);
+  blk(P[CAMO_P_F2_W0], 2 * H, H, x.W2, 2 * H, 0, x.W2T, 2 * H, 0);
+  if (!ok) return fail(CAMO_E_ARG, "the shadowed parameters must lie inside the flat buffer [p, p + n)");
+  // the rest of the flat buffer: the gaps between the shadowed blocks, in address order
+  for (int i = 1; i < ncov; ++i)
+    for (int j = i; j > 0 && cov[j].off < cov[j - 1].off; --j) { const Cov t = cov[j]; cov[j] = cov[j - 1]; cov[j - 1] = t; }
+  size_t at = 0;
+  for (int i = 0; i <= ncov; ++i) {
+    const size_t end = i < ncov ? cov[i].off : n;
+    if (end < at) return fail(CAMO_E_ARG, "overlapping parameter blocks");
+    if (end > at) {
+      if (a.nrange >= ADAM_SHADOW_MAXR) return fail(CAMO_E_ARG, "too many gaps between the shadowed parameters");
+      if ((at & 3) || ((end - at) & 3)) return fail(CAMO_E_ARG, "parameters must be 16-byte aligned slices of the flat buffer");
+      a.range_begin[a.nrange] = at; a.range_len[a.nrange++] = end - at;
+    }
+    if (i < ncov) at = cov[i].off + cov[i].len;
+  }
+  CK(launch_clip_adamw_shadows(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, step, zero_grads, a,
+                               static_cast<hipStream_t>(stream)), "clip+adamw+shadows");
   return 0;
 }
 

@@ -62,3 +62,23 @@ struct TailFusedArgs {
 int tail_fused_ok(int B, int C);
 int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream);
 int tail_timeouts(unsigned int* out);
+
+// ---- AdamW that also emits the bf16 weight shadows of the fused row-tile schedule (fused_rows.h), so that the next training
+// step needs no shadow launch.  A "row block" is a run of rows of one parameter matrix; it feeds one plain shadow (rows pn0.. of a
+// logical [pN][cols] matrix) and optionally one transposed shadow (its rows are k' = tk0.. of a logical [tN = cols][tK]).
+struct AdamShadowBlock {
+  size_t off;                       // element offset of the row block in the flat parameter / gradient / moment buffers
+  int rows, cols;                   // rows % 32 == 0, cols % 64 == 0, row-major with ld = cols
+  unsigned short* plain; int pN, pn0;
+  unsigned short* trans; int tK, tk0;       // trans == nullptr: none
+  int tile_begin;                   // (filled by the launcher) first 32 x 64 tile of this block
+};
+#define ADAM_SHADOW_MAXB 12
+#define ADAM_SHADOW_MAXR 16
+struct AdamShadowArgs {
+  AdamShadowBlock blk[ADAM_SHADOW_MAXB]; int nblk;
+  size_t range_begin[ADAM_SHADOW_MAXR], range_len[ADAM_SHADOW_MAXR]; int nrange;   // the rest of the flat buffer, elementwise (16-byte aligned runs)
+  int tiles, nbig;                  // (launcher) tile blocks; ranges [0, nbig) are the long ones
+};
+int launch_clip_adamw_shadows(float* p, float* g, float* m, float* v, float* sumsq, float max_norm, float lr, float b1, float b2,
+                              float eps, float wd, int step, int zero_grads, AdamShadowArgs& a, hipStream_t stream);

@@ -1232,6 +1232,129 @@ int launch_sumsq(const float* g, size_t n, float* out, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+// AdamW + weight shadows.  Blocks [0, tiles): one 32-row x 64-column tile of a shadowed matrix each -- thread (r = tid >> 3,
+// c = tid & 7) owns the 8 consecutive elements (row r, columns 8c..8c+7): the same arithmetic as clip_adamw_kernel on two
+// float4s per buffer, then (1) those 8 new values, rounded to bf16, ARE one 16-byte chunk of the plain shadow (fragment order
+// [wave][k step][tile][lane][8], lane = row + 32 * (k half): fused_rows.h) -- stored straight from registers; (2) the tile goes
+// to LDS as bf16 and comes back by columns: a chunk of the transposed shadow is 8 consecutive ROWS of one column.
+// Blocks [tiles, ...): the rest of the flat buffer (biases, LayerNorm, per-sample tail), elementwise.
+__device__ __forceinline__ size_t shadow_chunk(int N, int K, int n, int k0) {       // chunk index of (row n, columns k0..k0+7) in fragment order
+  const int KS = K >> 4, NTw = N >> 7, tile32 = n >> 5;
+  const int w = tile32 / NTw, t = tile32 - w * NTw;
+  return (((size_t)w * KS + (k0 >> 4)) * NTw + t) * 64 + (n & 31) + 32 * ((k0 >> 3) & 1);
+}
+
+__global__ __launch_bounds__(256) void adamw_shadow_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, float* __restrict__ sumsq, float max_norm, float lr,
+                                                           float b1, float b2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2,
+                                                           int zero_grads, const AdamShadowArgs a) {
+  __shared__ float red[4];
+  __shared__ __attribute__((aligned(16))) unsigned short tile[32 * 72];     // [32 rows][64 columns] bf16, pitch 72
+  const int tid = threadIdx.x;
+  {
+    const float part = wave_sum(sumsq[1 + tid]);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+  }
+  const float total = (red[0] + red[1]) + (red[2] + red[3]);
+  if (blockIdx.x == 0 && tid == 0) sumsq[0] = total;
+  const float coef = fminf(1.0f, max_norm / (sqrtf(total) + 1e-6f));
+  const float decay = 1.0f - lr * wd, step = lr * inv_bc1, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  auto upd = [&](float& pi, float& gi, float& mi, float& vi) {
+    gi *= coef;
+    pi *= decay;
+    mi = mi * b1 + gi * omb1;
+    vi = vi * b2 + gi * gi * omb2;
+    pi -= step * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    if (zero_grads) gi = 0.f;
+  };
+  if ((int)blockIdx.x < a.tiles) {
+    int bi = 0;
+#pragma unroll
+    for (int i = 1; i < ADAM_SHADOW_MAXB; ++i)
+      if (i < a.nblk && (int)blockIdx.x >= a.blk[i].tile_begin) bi = i;
+    const AdamShadowBlock& B = a.blk[bi];
+    const int tl = (int)blockIdx.x - B.tile_begin, ct = B.cols >> 6;
+    const int tr = tl / ct, tc = tl - tr * ct;              // tile (rows 32 tr.., columns 64 tc..)
+    const int r = tid >> 3, c = tid & 7;
+    const int row = 32 * tr + r, col = 64 * tc + 8 * c;
+    const size_t e = B.off + (size_t)row * B.cols + col;
+    float4* p4 = reinterpret_cast<float4*>(p + e); float4* g4 = reinterpret_cast<float4*>(g + e);
+    float4* m4 = reinterpret_cast<float4*>(m + e); float4* v4 = reinterpret_cast<float4*>(v + e);
+    float4 pa = p4[0], pb = p4[1], ga = g4[0], gb = g4[1], ma = m4[0], mb = m4[1], va = v4[0], vb = v4[1];
+    upd(pa.x, ga.x, ma.x, va.x); upd(pa.y, ga.y, ma.y, va.y); upd(pa.z, ga.z, ma.z, va.z); upd(pa.w, ga.w, ma.w, va.w);
+    upd(pb.x, gb.x, mb.x, vb.x); upd(pb.y, gb.y, mb.y, vb.y); upd(pb.z, gb.z, mb.z, vb.z); upd(pb.w, gb.w, mb.w, vb.w);
+    p4[0] = pa; p4[1] = pb; g4[0] = ga; g4[1] = gb; m4[0] = ma; m4[1] = mb; v4[0] = va; v4[1] = vb;
+    const uint4 ch = make_uint4(pack2(pa.x, pa.y), pack2(pa.z, pa.w), pack2(pb.x, pb.y), pack2(pb.z, pb.w));
+    reinterpret_cast<uint4*>(B.plain)[shadow_chunk(B.pN, B.cols, B.pn0 + row, col)] = ch;
+    if (B.trans) {                                          // (block-uniform)
+      *reinterpret_cast<uint4*>(tile + r * 72 + 8 * c) = ch;
+      __syncthreads();
+      const int cl = tid & 63, rc = tid >> 6;               // column 64 tc + cl, rows 8 rc .. 8 rc + 7 of the tile
+      unsigned short t8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t8[i] = tile[(8 * rc + i) * 72 + cl];
+      const uint4 tch = make_uint4((unsigned)t8[0] | ((unsigned)t8[1] << 16), (unsigned)t8[2] | ((unsigned)t8[3] << 16),
+                                   (unsigned)t8[4] | ((unsigned)t8[5] << 16), (unsigned)t8[6] | ((unsigned)t8[7] << 16));
+      reinterpret_cast<uint4*>(B.trans)[shadow_chunk(B.cols, B.tK, 64 * tc + cl, B.tk0 + 32 * tr + 8 * rc)] = tch;
+    }
+    return;
+  }
+  // the rest.  The launcher sorted the ranges by length, longest first: ranges [0, nbig) are shared grid-stride by the
+  // elementwise blocks, the short ones (biases, LayerNorm: a few hundred elements each) get a block each at the end --
+  // eleven ranges looked at by every thread was eleven rounds of scalar loads of their bounds for mostly nothing
+  const int eb = (int)blockIdx.x - a.tiles, neb = (int)gridDim.x - a.tiles;
+  auto run = [&](int ri, size_t first, size_t stride) {
+    const size_t n4 = a.range_len[ri] >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p + a.range_begin[ri]); float4* g4 = reinterpret_cast<float4*>(g + a.range_begin[ri]);
+    float4* m4 = reinterpret_cast<float4*>(m + a.range_begin[ri]); float4* v4 = reinterpret_cast<float4*>(v + a.range_begin[ri]);
+    for (size_t i = first; i < n4; i += stride) {
+      float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+      upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+      p4[i] = pp; g4[i] = gg; m4[i] = mm; v4[i] = vv;
+    }
+  };
+  const int nsmall = a.nrange - a.nbig;                      // the last nsmall blocks take one short range each
+  if (eb >= neb - nsmall) run(a.nbig + (eb - (neb - nsmall)), tid, 256);
+  else for (int ri = 0; ri < a.nbig; ++ri) run(ri, (size_t)eb * 256 + tid, (size_t)(neb - nsmall) * 256);
+}
+
+int launch_clip_adamw_shadows(float* p, float* g, float* m, float* v, float* sumsq, float max_norm, float lr, float b1, float b2,
+                              float eps, float wd, int step, int zero_grads, AdamShadowArgs& a, hipStream_t stream) {
+  if (a.nblk < 1 || a.nblk > ADAM_SHADOW_MAXB || a.nrange < 0 || a.nrange > ADAM_SHADOW_MAXR) return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
+    return (int)hipErrorInvalidValue;
+  int tiles = 0;
+  for (int i = 0; i < a.nblk; ++i) {
+    AdamShadowBlock& B = a.blk[i];
+    if ((B.rows & 31) || (B.cols & 63) || (B.off & 3) || !B.plain || (B.pN & 127) || (B.pn0 & 31) || (B.trans && ((B.cols & 127) || (B.tK & 15) || (B.tk0 & 31))))
+      return (int)hipErrorInvalidValue;
+    B.tile_begin = tiles;
+    tiles += (B.rows >> 5) * (B.cols >> 6);
+  }
+  size_t rest = 0;
+  for (int i = 0; i < a.nrange; ++i) { if ((a.range_begin[i] & 3) || (a.range_len[i] & 3)) return (int)hipErrorInvalidValue; rest += a.range_len[i]; }
+  a.tiles = tiles;
+  for (int i = 1; i < a.nrange; ++i)                         // longest first
+    for (int j = i; j > 0 && a.range_len[j] > a.range_len[j - 1]; --j) {
+      const size_t tb = a.range_begin[j], tl = a.range_len[j];
+      a.range_begin[j] = a.range_begin[j - 1]; a.range_len[j] = a.range_len[j - 1]; a.range_begin[j - 1] = tb; a.range_len[j - 1] = tl;
+    }
+  a.nbig = 0;
+  size_t big = 0;
+  while (a.nbig < a.nrange && a.range_len[a.nbig] >= 8192) big += a.range_len[a.nbig++];
+  size_t nb = (big / 4 + 255) / 256;                         // blocks for the long ranges ...
+  if (nb < 1) nb = 1;
+  if (nb > 1000) nb = 1000;
+  nb += (size_t)(a.nrange - a.nbig);                         // ... + one per short range
+  const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+  const int prof = gemm_prof_open(stream, 0.0, PROF_OPT);
+  hipLaunchKernelGGL(adamw_shadow_kernel, dim3((unsigned)(tiles + nb)), dim3(256), 0, stream, p, g, m, v, sumsq, max_norm, lr, b1, b2, eps, wd,
+                     (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), zero_grads, a);
+  gemm_prof_close(prof, stream);
+  return (int)hipGetLastError();
+}
+
 int launch_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sumsq, float max_norm,
                       float lr, float b1, float b2, float eps, float wd, int step, int zero_grads, hipStream_t stream) {
   const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);

@@ -88,6 +88,9 @@ class FusionEngine:
         self._gtab = None
         self._offsets_cache = {}
         self._ws = None
+        self._shadows = None          # persistent bf16 weight shadows of the fused schedule (camo_shadow_bytes)
+        self._shadows_version = None  # param_version() right after the optimizer call that left them current
+        self._plist = None
         self._seed_base = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self._calls = 0
         self.reflatten()
@@ -125,6 +128,9 @@ class FusionEngine:
         self.flat_grads = None
         self._ptab = self._gtab = None
         self._ws = None
+        self._shadows = None
+        self._shadows_version = None
+        self._plist = None
         self._offsets_cache = {}
         if dev.type == "cuda":
             n = len(self.slots)
@@ -233,6 +239,32 @@ class FusionEngine:
             self._ws = torch.empty(int(need * 1.25), dtype=torch.uint8, device=batch.rg.device)
         return self._ws
 
+    def shadow_buffer(self):
+        """Caller-owned weight shadows for camo_forward_loss_backward / camo_clip_adamw_shadows, or None when the model's
+        configuration has no fused schedule (or the model is not in bf16 mode)."""
+        if self.module().precision != "bf16" or self.flat_params.device.type != "cuda":
+            return None
+        if self._shadows is None:
+            need = _lib.lib().camo_shadow_bytes(C.byref(self.dims))
+            if need == 0:
+                return None
+            self._shadows = torch.empty(need, dtype=torch.uint8, device=self.flat_params.device)
+            self._shadows_version = None
+        return self._shadows
+
+    def param_version(self):
+        """Torch's in-place version counters of the flat buffer and of every parameter (a parameter written through
+        ``copy_`` / ``load_state_dict`` / any in-place op bumps its own counter, not the flat buffer's; the library's kernels
+        bump none).  Writes through ``param.data`` are invisible to torch and therefore to this."""
+        if self._plist is None:                               # (walking the module tree costs ~30 us of host time per call)
+            self._plist = list(self.module().parameters())
+        return (self.flat_params._version, sum(p._version for p in self._plist))
+
+    def shadows_current(self):
+        """True when the shadows were left by the last optimizer call AND nothing on the torch side has written the parameters
+        since."""
+        return self._shadows is not None and self._shadows_version is not None and self._shadows_version == self.param_version()
+
     def next_seed(self):
         self._calls += 1
         return (self._seed_base + 0x9E3779B97F4A7C15 * self._calls) & 0xFFFFFFFFFFFFFFFF
@@ -267,11 +299,13 @@ class FusionEngine:
                                           _lib.FLAG_ATTN_MAPS if had_attention else 0, _stream_ptr(self.device))
         _lib.check(rc, "camo_backward")
 
-    def train_raw(self, batch, ws, mask_label, edge_label, score_label, training, seed, gtab, tail_event=None):
+    def train_raw(self, batch, ws, mask_label, edge_label, score_label, training, seed, gtab, tail_event=None, use_shadows=False):
         """The native training call (camo_forward_loss_backward): forward, the reference's 4-term loss and backward into
         the flat gradient buffer in one library call.  Returns (outs [B, 2C+2], loss_terms [B, 4], pred int32 [B]).
         ``tail_event``: raw hipEvent_t handle (int) recorded when the per-sample tail's gradients are final
-        (``tail_grad_offset()`` .. end of the flat buffer): the hook for overlapping the data-parallel all-reduce."""
+        (``tail_grad_offset()`` .. end of the flat buffer): the hook for overlapping the data-parallel all-reduce.
+        ``use_shadows``: keep the fused schedule's weight shadows in the engine's persistent buffer and skip rebuilding them
+        when the optimizer left them current (``FusedClipAdamW.step(shadows=True)``)."""
         mod = self.module()
         dev = batch.rg.device
         check_labels(mask_label, self.dims.num_classes)
@@ -281,12 +315,15 @@ class FusionEngine:
         outs = torch.empty(batch.B, self.out_width, dtype=torch.float32, device=dev)
         terms = torch.empty(batch.B, 4, dtype=torch.float32, device=dev)
         pred = torch.empty(batch.B, dtype=torch.int32, device=dev)
+        sh = self.shadow_buffer() if use_shadows else None
+        valid = int(sh is not None and self.shadows_current())
+        self._shadows_version = None                         # (whatever happens next, they are consumed: the optimizer renews them)
         with _on(self.device):
             rc = _lib.lib().camo_forward_loss_backward(
                 C.byref(self.dims), self._ptab, gtab, _ptr(batch.rg), _ptr(batch.offsets), _ptr(batch.desc),
                 _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(y), _ptr(e), _ptr(s),
                 _ptr(outs), _ptr(terms), _ptr(pred), int(bool(training)), seed, _PREC[mod.precision],
-                C.c_void_p(tail_event) if tail_event else None, _stream_ptr(self.device))
+                C.c_void_p(tail_event) if tail_event else None, _ptr(sh) if sh is not None else None, valid, _stream_ptr(self.device))
         _lib.check(rc, "camo_forward_loss_backward")
         return outs, terms, pred
 

@@ -49,11 +49,13 @@ class FusedClipAdamW:
         self.lr = cosine_warm_restarts_lr(self.base_lr, epoch, T_0, T_mult)
         return self.lr
 
-    def step(self, allreduce=None, zero_grads=False):
+    def step(self, allreduce=None, zero_grads=False, shadows=False):
         """``allreduce``: optional callable applied to the flat gradient buffer before the norm
         (data-parallel SUM, see ddp.py).  ``zero_grads``: clear the gradient buffer in the same pass
         (the next minibatch's ``zero_grad()`` fused in) instead of leaving the clipped gradients in
-        it.  Returns nothing; ``grad_norm()`` reads the norm lazily."""
+        it.  ``shadows``: also leave the fused schedule's bf16 weight shadows of the updated parameters in the engine's
+        persistent buffer (camo_clip_adamw_shadows), so that the next ``train_raw(use_shadows=True)`` needs no shadow
+        launch.  Returns nothing; ``grad_norm()`` reads the norm lazily."""
         eng = self.engine
         _lib.require_device(eng.flat_params, "model parameters")
         # param.grad views are attached once; walking named_parameters() every step cost ~130 us of host time
@@ -66,6 +68,15 @@ class FusedClipAdamW:
         with _on(eng.device):
             st = _stream_ptr(eng.device)
             _lib.check(L.camo_grad_sumsq(_ptr(g), g.numel(), _ptr(ss), st), "camo_grad_sumsq")
+            sh = eng.shadow_buffer() if shadows else None
+            if sh is not None:
+                _lib.check(L.camo_clip_adamw_shadows(C.byref(eng.dims), eng._ptab, _ptr(eng.flat_params), _ptr(g), _ptr(m), _ptr(v), g.numel(),
+                                                     _ptr(ss), self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
+                                                     self.weight_decay, self.step_count, int(bool(zero_grads)), _ptr(sh), st),
+                           "camo_clip_adamw_shadows")
+                eng._shadows_version = eng.param_version()
+                return
+            eng._shadows_version = None
             _lib.check(L.camo_clip_adamw(_ptr(eng.flat_params), _ptr(g), _ptr(m), _ptr(v), g.numel(), _ptr(ss),
                                          self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
                                          self.weight_decay, self.step_count, int(bool(zero_grads)), st), "camo_clip_adamw")

@@ -167,13 +167,17 @@ def pack_samples(batch, device):
 class NativeTrainer:
     """One optimizer step = one packed minibatch through the HIP path."""
 
-    def __init__(self, model, lr=5e-4, weight_decay=1e-4, max_norm=1.0, grad_allreduce=None, keep_grads=False, fused_call=True):
+    def __init__(self, model, lr=5e-4, weight_decay=1e-4, max_norm=1.0, grad_allreduce=None, keep_grads=False, fused_call=True,
+                 reuse_shadows=True):
         """``keep_grads``: leave the clipped gradients in ``param.grad`` after the step, as the reference's
         clip_grad_norm_ does (costs one extra clearing pass per step); by default the optimizer kernel
         clears the gradient buffer itself, which is the reference's per-minibatch ``zero_grad()`` [:239]
         moved to the end of the previous step."""
         self.keep_grads = keep_grads
         self.fused_call = fused_call      # one camo_forward_loss_backward instead of forward / loss / backward calls
+        # the optimizer kernel leaves the next step's bf16 weight shadows ready (one launch less per step); guarded by the
+        # parameters' torch version counter, so a load_state_dict or any other torch-side write in between is noticed
+        self.reuse_shadows = reuse_shadows and fused_call
         self.model = model
         self.engine = model._engine
         self.opt = FusedClipAdamW(model, lr=lr, weight_decay=weight_decay, max_norm=max_norm)
@@ -198,12 +202,13 @@ class NativeTrainer:
             split = eng.tail_grad_offset()
             ev = ar.tail_event(eng.device) if split else None
         if self.fused_call:
-            _, terms, pred = eng.train_raw(batch, ws, mask_label, edge_label, score_label, training, seed, eng._gtab, tail_event=ev)
+            _, terms, pred = eng.train_raw(batch, ws, mask_label, edge_label, score_label, training, seed, eng._gtab, tail_event=ev,
+                                           use_shadows=self.reuse_shadows)
         else:
             outs, _ = eng.forward_raw(batch, ws, training, seed)
             terms, d_pre, pred = multitask_loss(outs, mask_label, edge_label, score_label, self.num_classes, pre_activation=True)
             eng.backward_raw(batch, ws, outs, d_pre, training, seed, eng._gtab, pre_activation=True)
-        self.opt.step(allreduce=(lambda g: ar(g, split=split)) if ev else ar, zero_grads=not self.keep_grads)
+        self.opt.step(allreduce=(lambda g: ar(g, split=split)) if ev else ar, zero_grads=not self.keep_grads, shadows=self.reuse_shadows)
         self._grads_clean = not self.keep_grads
         return terms, pred
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CAMO_ABI_VERSION 5
+#define CAMO_ABI_VERSION 6
 
 enum {
   CAMO_OK = 0,
@@ -168,6 +168,17 @@ int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sum
                     float max_norm, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int32_t step, int32_t zero_grads, void* stream);
 
+/* The same update that ALSO leaves the fused schedule's bf16 weight shadows of the updated parameters in `shadows`
+ * (camo_shadow_bytes(dims) bytes; 0 = the configuration has no fused schedule): the shadowed matrices are walked in
+ * 32 x 64 tiles whose new values go out as fragment-order chunks straight from registers (plain) and through an LDS
+ * transpose (the backward's transposed copies); everything else in [p, p + n) is updated elementwise as above.
+ * params: the parameter table of camo_forward (pointers into [p, p + n)); bit-identical parameters, moments and
+ * gradients to camo_clip_adamw.  Pair with camo_forward_loss_backward(..., shadows, shadows_valid = 1). */
+size_t camo_shadow_bytes(const camo_dims_t* dims);
+int camo_clip_adamw_shadows(const camo_dims_t* dims, const float* const* params, float* p, float* g, float* m, float* v,
+                            size_t n, float* sumsq, float max_norm, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int32_t step, int32_t zero_grads, void* shadows, void* stream);
+
 /* camo_forward_loss_backward: the native training call = camo_forward (training / seed / precision as there),
  * camo_loss on its outputs with the labels y [B] (int64), e [B], s [B], and camo_backward on the loss gradient:
  * same results, fewer launches (the head output layer, the loss and that layer's backward run as one kernel).
@@ -179,12 +190,19 @@ int camo_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sum
  *   contiguous run when the gradients live in one flat buffer in table order) and CAMO_P_F1_W3/B3 -- i.e. before the
  *   node-level backward launches.  A data-parallel caller starts the all-reduce of that run behind the event and the
  *   rest behind the call (ddp.py: BucketedGradAllReducer).  Every schedule records it (at the end when it has no
- *   earlier point: late fusion). */
+ *   earlier point: late fusion).
+ * shadows (may be null; camo_shadow_bytes() bytes, 256-byte aligned, caller-owned, persistent across steps): where the
+ *   fused schedule keeps its bf16 weight shadows instead of the per-batch workspace.  shadows_valid != 0 is the caller's
+ *   PROMISE that they hold the current parameters -- i.e. that the last writer of the parameters was
+ *   camo_clip_adamw_shadows on this buffer -- and lets the call skip rebuilding them (one launch less per step).  With
+ *   shadows_valid == 0 the call rebuilds them there.  Ignored (and shadows_valid rejected) on calls that do not take the
+ *   fused schedule. */
 int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
                                const int32_t* rg_offsets, const void* batch_desc, const float* kg,
                                int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes,
                                const int64_t* y, const float* e, const float* s, float* outs, float* loss_terms, int32_t* pred,
-                               int32_t training, uint64_t seed, int32_t precision, void* tail_event, void* stream);
+                               int32_t training, uint64_t seed, int32_t precision, void* tail_event, void* shadows,
+                               int32_t shadows_valid, void* stream);
 
 /* ---- testing hooks ---------------------------------------------------------
  * Not part of the operator surface; used by tests/ to check kernels in isolation.

@@ -3,7 +3,7 @@
 
   python profiles/dispatch_table.py out.csv LABEL=trace.csv [LABEL=trace.csv ...]
 
-A step = the launches from one shadow_kernel (first launch of a step of the fused schedule) up to the next.  Durations are
+A step = the launches from one shadow_kernel (or, when the optimizer left the weight shadows ready, one front_kernel) up to the next.  Durations are
 averaged by position over every complete step of the trace that has the most common launch sequence (warm-up, the batch
 sweep and the forward-only leg of bench.py have other sequences and drop out); gap = start minus the previous launch's end.
 """
@@ -19,12 +19,15 @@ def short(name):
 
 def table(path):
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
-    steps, cur = [], None
+    steps, cur, prev = [], None, ""
     for r in rows:
-        if "shadow_kernel" in r["Kernel_Name"]:
+        name = short(r["Kernel_Name"])
+        # a step starts with the shadow launch, or -- when the optimizer left the shadows ready -- with the front kernel
+        if name == "shadow_kernel" or (name.startswith("front_kernel") and prev != "shadow_kernel"):
             if cur: steps.append(cur)
             cur = []
         if cur is not None: cur.append(r)
+        prev = name
     seqs = Counter(tuple(short(r["Kernel_Name"]) for r in s) for s in steps)
     seq = max(seqs, key=lambda k: (seqs[k] * ("sumsq_kernel" in k), len(k)))        # the training step's sequence
     sel = [s for s in steps if tuple(short(r["Kernel_Name"]) for r in s) == seq]

@@ -9,7 +9,7 @@ gfx950 correction (guide, 'HBM'): FETCH_SIZE counts 128-B requests at 64 B for w
 reads, i.e. reports half the bytes -> doubled here; WRITE_SIZE is exact for 16-B/lane stores and
 float atomics.  Both counters are in KB.  Per kernel (short name: namespace, template arguments and
 argument list stripped): launches, bytes per launch; plus the all-kernel bytes per step, a step
-being one launch of shadow_kernel (the first launch of every training step of the fused schedule).
+being one launch of tail_fused_kernel (once per training step of the fused schedule at B <= 16).
 """
 import csv, glob, json, re, sys
 
@@ -34,7 +34,7 @@ def per_kernel(d, counter):
 def main():
     fetch_dir, write_dir = sys.argv[1], sys.argv[2]
     fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
-    steps_f = max(fe.get("shadow_kernel", [0, 1])[1], 1); steps_w = max(wr.get("shadow_kernel", [0, 1])[1], 1)
+    steps_f = max(fe.get("tail_fused_kernel", [0, 1])[1], 1); steps_w = max(wr.get("tail_fused_kernel", [0, 1])[1], 1)
     kernels, per_step = {}, 0.0
     for k in sorted(set(fe) | set(wr)):
         f_kb, nf = fe.get(k, [0.0, 0]); w_kb, nw = wr.get(k, [0.0, 0])

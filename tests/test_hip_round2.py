@@ -191,3 +191,54 @@ def test_tail_kernel_never_times_out_in_this_process():
     process has the GPU's CUs to itself; the counter is sticky, so this covers every fused training step the tests above ran."""
     from camouflage_multimodal_amd import _lib
     assert _lib.tail_timeouts() == 0
+
+
+def test_adamw_leaves_the_next_steps_weight_shadows(kg_real):
+    """camo_clip_adamw_shadows: (1) the same parameters, moments and gradients as camo_clip_adamw, bit for bit; (2) the bf16
+    weight shadows it leaves are byte-identical to the ones the forward would rebuild from the updated parameters, so a step
+    that trusts them (shadows_valid) computes the same thing; (3) a torch-side write to the parameters in between is noticed."""
+    import copy
+    from camouflage_multimodal_amd import NativeTrainer
+    cfg = OP.full_cfg()
+    nrs = [303, 64, 33, 530, 17]
+    rg = torch.from_numpy(np.concatenate([OP.make_rg(n, 128, seed=50 + i) for i, n in enumerate(nrs)])).cuda()
+    kg = torch.from_numpy(np.stack([kg_real] * len(nrs))).cuda()
+    y, e, s = (torch.from_numpy(v) for v in OP.make_labels(len(nrs), seed=3))
+    ma = make_model(cfg, 1, "bf16").train()
+    mb = make_model(cfg, 1, "bf16").train()
+    ta, tb = NativeTrainer(ma, reuse_shadows=True), NativeTrainer(mb, reuse_shadows=False)
+    # (1) one step each from identical gradients: run the forward/backward once, copy the gradients over
+    ea, eb = ma._engine, mb._engine
+    ga, gb = ea.ensure_flat_grads(attach=False), eb.ensure_flat_grads(attach=False)
+    batch = ea.make_batch(rg, nrs, kg)
+    ea.train_raw(batch, ea.workspace(batch), y, e, s, True, 77, ea._gtab, use_shadows=True)
+    gb.copy_(ga)
+    ta.opt.step(zero_grads=False, shadows=True); tb.opt.step(zero_grads=False, shadows=False)
+    torch.cuda.synchronize()
+    assert torch.equal(ea.flat_params, eb.flat_params) and torch.equal(ga, gb)
+    ma_, va_, _ = ta.opt._state(); mb_, vb_, _ = tb.opt._state()
+    assert torch.equal(ma_, mb_) and torch.equal(va_, vb_)
+    # (2) the shadows AdamW left == the shadows the forward rebuilds from those parameters
+    assert ea.shadows_current()
+    left = ea._shadows.clone()
+    ea._shadows_version = None                                # force a rebuild into the same buffer
+    ea.train_raw(batch, ea.workspace(batch), y, e, s, True, 78, ea._gtab, use_shadows=True)
+    torch.cuda.synchronize()
+    assert torch.equal(left, ea._shadows)
+    # whole steps through the trainer, with and without reuse, stay together (run-to-run noise of the fp32 atomics only)
+    ga.zero_(); gb.zero_()
+    mb.load_state_dict(copy.deepcopy(ma.state_dict()))
+    tb.opt.load_state_dict(copy.deepcopy(ta.opt.state_dict()))
+    for step in range(3):
+        ta.step(rg, nrs, kg, y, e, s, seed=100 + step); tb.step(rg, nrs, kg, y, e, s, seed=100 + step)
+    torch.cuda.synchronize()
+    pa, pb = t2n(ea.flat_params), t2n(eb.flat_params)
+    err = np.abs(pa - pb)
+    # (three bf16 steps apart only by the order of fp32 atomics: a ReLU unit within rounding of zero can still flip, see tests/dev_relu_flip.py)
+    assert err.max() <= 2.2 * 5e-4 * 3 and (err <= 5e-6 + 1e-4 * np.abs(pb)).mean() > 0.97, (err.max(), (err <= 5e-6 + 1e-4 * np.abs(pb)).mean())
+    # (3) staleness: the optimizer just left them current; a load_state_dict makes them stale
+    assert ea.shadows_current()
+    ma.load_state_dict(copy.deepcopy(mb.state_dict()))
+    assert not ea.shadows_current()
+    ta.step(rg, nrs, kg, y, e, s, seed=7)                     # rebuilds, then continues
+    assert ea.shadows_current()
