@@ -1027,7 +1027,8 @@ int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* para
   if (shadows_valid && !shadows) return fail(CAMO_E_ARG, "shadows_valid without a shadow buffer");
   // external shadows are used by the fused schedule only; whether the call takes it is known from its arguments
   const bool ext = shadows && params && !check_dims(dims, B, T, Nk) && fused17_ok(*dims, params, precision, Nk, max_nr);
-  if (shadows_valid && !ext) return fail(CAMO_E_ARG, "shadows_valid on a call that does not take the fused schedule");
+  // (a call that takes another schedule -- Nk > 16, a 5000-node sample, ... -- builds what it needs in its workspace and leaves the
+  // external shadows alone: the promise is simply not used)
   if (ext && (reinterpret_cast<uintptr_t>(shadows) & 255)) return fail(CAMO_E_ARG, "the shadow buffer must be 256-byte aligned");
   t_shadows = ext ? shadows : nullptr; t_shadows_valid = ext && shadows_valid != 0;
   t_tail_event = static_cast<hipEvent_t>(tail_event);

@@ -1251,6 +1251,25 @@ __global__ __launch_bounds__(256) void adamw_shadow_kernel(float* __restrict__ p
   __shared__ float red[4];
   __shared__ __attribute__((aligned(16))) unsigned short tile[32 * 72];     // [32 rows][64 columns] bf16, pitch 72
   const int tid = threadIdx.x;
+  // a tile block issues its eight 16-byte loads BEFORE the norm's partial sums are fetched and reduced: one memory round trip
+  // for both instead of two in a row
+  const bool is_tile = (int)blockIdx.x < a.tiles;
+  int bi = 0, tr = 0, tc = 0;
+  const int r = tid >> 3, c = tid & 7;
+  float4 *p4 = nullptr, *g4 = nullptr, *m4 = nullptr, *v4 = nullptr;
+  float4 pa, pb, ga, gb, ma, mb, va, vb;
+  if (is_tile) {
+#pragma unroll
+    for (int i = 1; i < ADAM_SHADOW_MAXB; ++i)
+      if (i < a.nblk && (int)blockIdx.x >= a.blk[i].tile_begin) bi = i;
+    const AdamShadowBlock& B = a.blk[bi];
+    const int tl = (int)blockIdx.x - B.tile_begin, ct = B.cols >> 6;
+    tr = tl / ct; tc = tl - tr * ct;                        // tile (rows 32 tr.., columns 64 tc..)
+    const size_t e = B.off + (size_t)(32 * tr + r) * B.cols + 64 * tc + 8 * c;
+    p4 = reinterpret_cast<float4*>(p + e); g4 = reinterpret_cast<float4*>(g + e);
+    m4 = reinterpret_cast<float4*>(m + e); v4 = reinterpret_cast<float4*>(v + e);
+    pa = p4[0]; pb = p4[1]; ga = g4[0]; gb = g4[1]; ma = m4[0]; mb = m4[1]; va = v4[0]; vb = v4[1];
+  }
   {
     const float part = wave_sum(sumsq[1 + tid]);
     if ((tid & 63) == 0) red[tid >> 6] = part;
@@ -1268,20 +1287,9 @@ __global__ __launch_bounds__(256) void adamw_shadow_kernel(float* __restrict__ p
     pi -= step * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
     if (zero_grads) gi = 0.f;
   };
-  if ((int)blockIdx.x < a.tiles) {
-    int bi = 0;
-#pragma unroll
-    for (int i = 1; i < ADAM_SHADOW_MAXB; ++i)
-      if (i < a.nblk && (int)blockIdx.x >= a.blk[i].tile_begin) bi = i;
+  if (is_tile) {
     const AdamShadowBlock& B = a.blk[bi];
-    const int tl = (int)blockIdx.x - B.tile_begin, ct = B.cols >> 6;
-    const int tr = tl / ct, tc = tl - tr * ct;              // tile (rows 32 tr.., columns 64 tc..)
-    const int r = tid >> 3, c = tid & 7;
     const int row = 32 * tr + r, col = 64 * tc + 8 * c;
-    const size_t e = B.off + (size_t)row * B.cols + col;
-    float4* p4 = reinterpret_cast<float4*>(p + e); float4* g4 = reinterpret_cast<float4*>(g + e);
-    float4* m4 = reinterpret_cast<float4*>(m + e); float4* v4 = reinterpret_cast<float4*>(v + e);
-    float4 pa = p4[0], pb = p4[1], ga = g4[0], gb = g4[1], ma = m4[0], mb = m4[1], va = v4[0], vb = v4[1];
     upd(pa.x, ga.x, ma.x, va.x); upd(pa.y, ga.y, ma.y, va.y); upd(pa.z, ga.z, ma.z, va.z); upd(pa.w, ga.w, ma.w, va.w);
     upd(pb.x, gb.x, mb.x, vb.x); upd(pb.y, gb.y, mb.y, vb.y); upd(pb.z, gb.z, mb.z, vb.z); upd(pb.w, gb.w, mb.w, vb.w);
     p4[0] = pa; p4[1] = pb; g4[0] = ga; g4[1] = gb; m4[0] = ma; m4[1] = mb; v4[0] = va; v4[1] = vb;

@@ -195,8 +195,7 @@ int camo_clip_adamw_shadows(const camo_dims_t* dims, const float* const* params,
  *   fused schedule keeps its bf16 weight shadows instead of the per-batch workspace.  shadows_valid != 0 is the caller's
  *   PROMISE that they hold the current parameters -- i.e. that the last writer of the parameters was
  *   camo_clip_adamw_shadows on this buffer -- and lets the call skip rebuilding them (one launch less per step).  With
- *   shadows_valid == 0 the call rebuilds them there.  Ignored (and shadows_valid rejected) on calls that do not take the
- *   fused schedule. */
+ *   shadows_valid == 0 the call rebuilds them there.  Both are ignored on calls that do not take the fused schedule. */
 int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* params, float* const* grads, const float* rg,
                                const int32_t* rg_offsets, const void* batch_desc, const float* kg,
                                int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes,

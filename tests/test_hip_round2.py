@@ -225,20 +225,45 @@ def test_adamw_leaves_the_next_steps_weight_shadows(kg_real):
     ea.train_raw(batch, ea.workspace(batch), y, e, s, True, 78, ea._gtab, use_shadows=True)
     torch.cuda.synchronize()
     assert torch.equal(left, ea._shadows)
-    # whole steps through the trainer, with and without reuse, stay together (run-to-run noise of the fp32 atomics only)
+    # whole steps through the trainer, with and without reuse: the same losses step by step (parameters themselves drift apart by
+    # up to lr per step wherever Adam normalises a gradient that is rounding noise -- see helpers.assert_params_close -- so the
+    # losses are the robust witness)
     ga.zero_(); gb.zero_()
     mb.load_state_dict(copy.deepcopy(ma.state_dict()))
     tb.opt.load_state_dict(copy.deepcopy(ta.opt.state_dict()))
     for step in range(3):
-        ta.step(rg, nrs, kg, y, e, s, seed=100 + step); tb.step(rg, nrs, kg, y, e, s, seed=100 + step)
+        la, _ = ta.step(rg, nrs, kg, y, e, s, seed=100 + step); lb, _ = tb.step(rg, nrs, kg, y, e, s, seed=100 + step)
+        assert_close(t2n(la), t2n(lb), 1e-4 if step == 0 else 1e-2, 1e-3, f"loss terms, step {step}")
     torch.cuda.synchronize()
-    pa, pb = t2n(ea.flat_params), t2n(eb.flat_params)
-    err = np.abs(pa - pb)
-    # (three bf16 steps apart only by the order of fp32 atomics: a ReLU unit within rounding of zero can still flip, see tests/dev_relu_flip.py)
-    assert err.max() <= 2.2 * 5e-4 * 3 and (err <= 5e-6 + 1e-4 * np.abs(pb)).mean() > 0.97, (err.max(), (err <= 5e-6 + 1e-4 * np.abs(pb)).mean())
+    err = np.abs(t2n(ea.flat_params) - t2n(eb.flat_params))
+    assert err.max() <= 2.2 * 5e-4 * 3, err.max()
     # (3) staleness: the optimizer just left them current; a load_state_dict makes them stale
     assert ea.shadows_current()
     ma.load_state_dict(copy.deepcopy(mb.state_dict()))
     assert not ea.shadows_current()
     ta.step(rg, nrs, kg, y, e, s, seed=7)                     # rebuilds, then continues
     assert ea.shadows_current()
+
+
+def test_shadow_reuse_survives_batches_outside_the_fused_schedule(kg_real):
+    """The trainer's default (optimizer leaves the weight shadows, next call trusts them) with a batch the fused schedule does
+    not take in between (Nk = 17 > 16 runs on the GEMM-per-layer schedule): no error, and the steps after it are the same as
+    with reuse switched off (same seeds; fp32-atomics noise only)."""
+    from camouflage_multimodal_amd import NativeTrainer
+    cfg = OP.full_cfg()
+    nrs = [64, 200, 33]
+    rg = torch.from_numpy(np.concatenate([OP.make_rg(n, 128, seed=80 + i) for i, n in enumerate(nrs)])).cuda()
+    kg13 = torch.from_numpy(np.stack([kg_real] * 3)).cuda()
+    kg17 = torch.from_numpy(np.stack([OP.make_kg(17, 128, seed=5 + i) for i in range(3)])).cuda()
+    y, e, s = (torch.from_numpy(v) for v in OP.make_labels(3, seed=4))
+    res = []
+    for reuse in (True, False):
+        m = make_model(cfg, 2, "bf16").train()
+        tr = NativeTrainer(m, reuse_shadows=reuse)
+        for step, kg in enumerate((kg13, kg13, kg17, kg13, kg13)):
+            terms, _ = tr.step(rg, nrs, kg, y, e, s, seed=500 + step)
+        torch.cuda.synchronize()
+        assert torch.isfinite(terms).all()
+        res.append(t2n(m._engine.flat_params))
+    err = np.abs(res[0] - res[1])
+    assert err.max() <= 2.2 * 5e-4 * 5 and (err <= 5e-6 + 1e-4 * np.abs(res[1])).mean() > 0.97, (err.max(), (err <= 5e-6 + 1e-4 * np.abs(res[1])).mean())
