@@ -236,7 +236,7 @@ def main():
         names = ["grouped GEMM (gemm16_kernel / gemm_grouped_kernel: weight gradients in the fused schedule)", "front_kernel (fused forward: projection + in-projections)",
                  "back_kernel (fused forward: attention + out-projection + LayerNorm + FFN)", "bwd1_kernel (fused backward, first half)",
                  "bwd2_kernel (fused backward, second half)", "per-sample tail (tail_fused_kernel: one launch at B <= 16; gemm_skinny_kernel + heads_loss_kernel above)",
-                 "optimizer (sumsq_kernel, clip_adamw_kernel)", "shadow_kernel (bf16 weight shadows + clears)", "attention kernels (unfused schedules)", "other"]
+                 "optimizer (sumsq_kernel, adamw_shadow_kernel: AdamW that also leaves the next step's bf16 weight shadows)", "shadow_kernel (bf16 weight shadows + clears: only on steps whose shadows the optimizer did not leave)", "attention kernels (unfused schedules)", "other"]
         table = []
         for kind, nm in enumerate(names):
             kms, kn, kfl = C.c_double(), C.c_int32(), C.c_double()
