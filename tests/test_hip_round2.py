@@ -260,10 +260,13 @@ def test_shadow_reuse_survives_batches_outside_the_fused_schedule(kg_real):
     for reuse in (True, False):
         m = make_model(cfg, 2, "bf16").train()
         tr = NativeTrainer(m, reuse_shadows=reuse)
+        losses = []
         for step, kg in enumerate((kg13, kg13, kg17, kg13, kg13)):
             terms, _ = tr.step(rg, nrs, kg, y, e, s, seed=500 + step)
+            losses.append(t2n(terms))
         torch.cuda.synchronize()
-        assert torch.isfinite(terms).all()
-        res.append(t2n(m._engine.flat_params))
-    err = np.abs(res[0] - res[1])
-    assert err.max() <= 2.2 * 5e-4 * 5 and (err <= 5e-6 + 1e-4 * np.abs(res[1])).mean() > 0.97, (err.max(), (err <= 5e-6 + 1e-4 * np.abs(res[1])).mean())
+        assert all(np.isfinite(l).all() for l in losses)
+        res.append((losses, t2n(m._engine.flat_params)))
+    for step, (la, lb) in enumerate(zip(res[0][0], res[1][0])):           # (parameters drift by Adam's noise; the losses are the witness)
+        assert_close(la, lb, 1e-4 if step == 0 else 2e-2, 2e-3, f"loss terms, step {step}")
+    assert np.abs(res[0][1] - res[1][1]).max() <= 2.2 * 5e-4 * 5
