@@ -90,6 +90,47 @@ static void run_stage(int ksteps, const u32x4* buf, float* sink, int cus, int bl
          blocks_per_cu, bytes / 1024, us, bytes * blocks_per_cu / (us * 1e-6) / 1e9, ksteps * NT * 32 / 2400.0);
 }
 
+
+// Cold vs warm: in the product every node-level kernel of a B = 16 step meets its weights for the first time since the previous
+// step (307 MB of traffic ago: gone from the 4 MB L2s, still in the Infinity Cache).  thrash_kernel evicts the L2s between
+// launches; prefetch_kernel is what a preceding kernel's last blocks could do: every XCD (block b runs on XCD b % 8) reads the
+// whole buffer once, 1/32 per block.
+__global__ void thrash_kernel(u32x4* __restrict__ t, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    u32x4 v = t[i]; v.x += 1; t[i] = v;
+  }
+}
+__global__ void prefetch_kernel(const u32x4* __restrict__ w, size_t n16, unsigned int* sink) {
+  const int part = blockIdx.x >> 3, parts = gridDim.x >> 3;
+  const size_t per = (n16 + parts - 1) / parts, lo = part * per, hi = lo + per < n16 ? lo + per : n16;
+  unsigned int acc = 0;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) { const u32x4 v = w[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+template <int NT, int DEPTH>
+static void run_stage_cold(int ksteps, const u32x4* buf, float* sink, int cus, u32x4* trash, size_t trash_n) {
+  const size_t lds = 100 * 1024;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_kernel<NT, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t bytes = (size_t)4 * ksteps * NT * 1024;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  double us[4];
+  for (int mode = 0; mode < 4; ++mode) {                    // 0 thrash; 1 thrash + stage; 2 thrash + prefetch; 3 thrash + prefetch + stage
+    const int reps = 20;
+    for (int i = -3; i < reps; ++i) {
+      if (i == 0) hipEventRecord(e0);
+      hipLaunchKernelGGL(thrash_kernel, dim3(1024), dim3(256), 0, 0, trash, trash_n);
+      if (mode >= 2) hipLaunchKernelGGL(prefetch_kernel, dim3(256), dim3(256), 0, 0, buf, bytes / 16, reinterpret_cast<unsigned int*>(sink));
+      if (mode & 1) hipLaunchKernelGGL((stage_kernel<NT, DEPTH>), dim3(cus), dim3(256), lds, 0, buf, ksteps, sink);
+    }
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    us[mode] = ms * 1e3 / reps;
+  }
+  printf("cold stage NT %d  k steps %3d  %4zu KB/block: thrash %.2f us; stage after thrash %.2f us (%.1f GB/s per CU); prefetch %.2f us; stage after prefetch %.2f us (%.1f GB/s per CU)\n",
+         NT, ksteps, bytes / 1024, us[0], us[1] - us[0], bytes / ((us[1] - us[0]) * 1e-6) / 1e9, us[2] - us[0], us[3] - us[2],
+         bytes / ((us[3] - us[2]) * 1e-6) / 1e9);
+}
+
 template <int DEPTH>
 static void run(int waves_per_block, int blocks_per_cu, size_t bytes_per_block, const u32x4* buf, unsigned int* sink, int cus) {
   const int threads = 64 * waves_per_block;
@@ -133,5 +174,9 @@ int main() {
   run_stage<2, 12>(64, buf, fs, cus, 1);    // out-projection shape, long
   run_stage<4, 12>(64, buf, fs, cus, 1);    // FFN shape, long
   run_stage<6, 12>(64, buf, fs, cus, 2);
+  u32x4* trash; const size_t trash_bytes = (size_t)96 << 20; hipMalloc(&trash, trash_bytes); hipMemset(trash, 0, trash_bytes);
+  run_stage_cold<6, 12>(16, buf, fs, cus, trash, trash_bytes / 16);
+  run_stage_cold<6, 12>(64, buf, fs, cus, trash, trash_bytes / 16);
+  run_stage_cold<4, 12>(64, buf, fs, cus, trash, trash_bytes / 16);
   return 0;
 }
