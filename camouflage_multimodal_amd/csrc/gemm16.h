@@ -57,4 +57,5 @@ struct Gemm16Batch {
 };
 
 // Returns hipError_t as int; hipErrorInvalidValue for an unsupported problem.
+extern int g_gemm16_tn_kcap;         // developer A/B: > 0 pins the split-K depth (64-row tiles per block) of weight-gradient problems
 int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream);

@@ -611,14 +611,19 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
+int g_gemm16_tn_kcap = 0;             // developer A/B (camo_debug_set_option "tn_kcap"): > 0 pins the split-K depth
 int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
   if (gb.n <= 0) return 0;
   if (gb.n > GEMM16_MAXP) return (int)hipErrorInvalidValue;
-  // Split-K depth of the weight-gradient problems, in 64-row tiles per block.  Long chunks (16 tiles) keep the
-  // fp32 atomics of the epilogue rare -- they, not the K loop, dominate short chunks -- but a launch that would
-  // leave most CUs idle (the lone dW_rg / dW_kg launch) takes shorter chunks to spread over the chip.
+  // Split-K depth of the weight-gradient problems, in 64-row tiles per block: the longest of a short ladder that still gives
+  // ~2 blocks per CU.  Every block ends in 32 KB of fp32 atomics, which -- not the K loop -- set the launch's length once there
+  // are more blocks than that (measured, bf16 training step: B = 16 -> 16 tiles [8: +12 us, 32: +8 us]; B = 64 -> 64 tiles
+  // [16: +18 us, 8: +56 us]); a launch that would leave most CUs idle even at 16 (the general schedule's lone dW_rg / dW_kg
+  // launch) goes down to 8 to spread over the chip.
   int total = 0;
-  for (int kcap = 16;; kcap >>= 1) {
+  static const int kcaps[] = {512, 384, 256, 192, 128, 96, 64, 48, 32, 24, 16, 8};
+  for (int ci = 0;; ++ci) {
+    const int kcap = g_gemm16_tn_kcap > 0 ? g_gemm16_tn_kcap : kcaps[ci];
     total = 0;
     for (int i = 0; i < gb.n; ++i) {
       Gemm16Prob& p = gb.p[i];
@@ -660,7 +665,7 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
       p.tile_begin = total;
       total += tiles * p.ksplit;
     }
-    if (total >= 200 || kcap <= KCAP_MIN) break;
+    if (g_gemm16_tn_kcap > 0 || (kcap > 16 ? total >= 440 : total >= 200) || kcap <= KCAP_MIN) break;
   }
   bool has_tn = false, has_rows = false, has_virt = false;
   for (int i = 0; i < gb.n; ++i) {
@@ -680,7 +685,8 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
   double fl = 0.0;
   for (int i = 0; i < gb.n; ++i) fl += 2.0 * gb.p[i].M * (double)gb.p[i].N * gb.p[i].K;
   const int prof = gemm_prof_open(stream, fl);
-  // two register stages (four measured slower on every launch of the step)
+  // two register stages (four measured slower on every launch of the step; round 2: a weight-gradient-only kernel with four
+  // stages at two blocks per CU, 184 VGPRs, no spills: +1 us on the fused schedule's weight-gradient launch)
   if (has_rows) hipLaunchKernelGGL((gemm16_kernel<2, true>), dim3(total), dim3(256), lds, stream, gb, total);
   else          hipLaunchKernelGGL((gemm16_kernel<2, false>), dim3(total), dim3(256), lds, stream, gb, total);
   gemm_prof_close(prof, stream);
