@@ -283,10 +283,11 @@ def test_one_launch_tail_matches_separate_launches(training, B, kg_real, fused_o
 
 
 @pytest.mark.parametrize("nrs,nk,pseed", [([1], 1, 6), ([5, 700, 32], 16, 6), ([64] * 17, 13, 6), ([33, 31, 1, 2, 530, 96], 13, 7),
-                                          ([33, 31, 1, 2, 530, 96], 13, 8), ([1500, 17], 7, 6)])
+                                          ([33, 31, 1, 2, 530, 96], 13, 8), ([1500, 17], 7, 6), ([420 + 5 * i for i in range(24)], 13, 6)])
 def test_fused_training_step_shape_envelope(nrs, nk, pseed, fused_opts):
     """Envelope of the fused BACKWARD (and of the one-launch tail where B <= 16): one-node samples, Nk = 1 / 7 / 16, samples
-    that end exactly on a tile boundary, B = 17 (multi-launch tail behind fused node kernels), a 1500-node sample -- against the
+    that end exactly on a tile boundary, B = 17 (multi-launch tail behind fused node kernels), a 1500-node sample, 24 samples with
+    11 460 rows (the weight-gradient launch's split-K ladder picks a 24-tile chunk: not a power of two) -- against the
     oracle's train step with the same dropout masks.  The yardstick for "how far may bf16 operands move a gradient on THIS
     input" (tiny samples weigh single rows heavily) is the round-1 bf16 schedule's error on the same input.  (Parameter seeds
     are chosen so that no head unit with a large gradient has its pre-activation within bf16 noise of zero: with pseed = 6 the
