@@ -292,7 +292,7 @@ def main():
         fwd_flops = alg_step / FWDBWD_OVER_FWD
         extras["forward"] = {"value": round(args.batch / f_el, 1), "unit": "images/s", "ms_per_call": round(f_el * 1e3, 4),
                              "achieved_tflops": round(fwd_flops / f_el / 1e12, 2), "frac": round(fwd_flops / f_el / 1e12 / peak, 5),
-                             "mode": f"eval-mode camo_forward, B = {args.batch} packed, {args.precision}, algorithmic forward FLOPs / call time"}
+                             "mode": f"eval-mode camo_forward_cached (weight shadows kept across calls), B = {args.batch} packed, {args.precision}, algorithmic forward FLOPs / call time"}
         # (b) batch sweep of the training step: where the per-step floor stops dominating
         sweep = []
         for Bs in (1, 4, 16, 64, 256):

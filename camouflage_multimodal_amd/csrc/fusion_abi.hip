@@ -484,6 +484,7 @@ static thread_local void* t_zero_bwd1_ptr[FUSED_BWD1_MAXZ]; static thread_local 
 static thread_local int t_nzero_bwd1 = 0;
 static thread_local void* t_shadows = nullptr;
 static thread_local bool t_shadows_valid = false;
+static thread_local int t_shadows_state = 0;    // what the fused forward left in external shadows: 0 untouched, 1 forward set, 2 forward + transposed
 struct ShadowSet { us16 *Wrg, *Wkg, *Wqkv_rg, *Wqkv_kg, *Wo1, *Wo2, *W1, *W2, *W1T, *W2T, *Wo1T, *Wo2T, *WcRgT, *WcKgT; size_t bytes; };
 static ShadowSet shadow_carve(void* base) {
   ShadowSet x{};
@@ -517,6 +518,7 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
       J.src[0] = s0; J.rows[0] = r0; J.ld[0] = K; J.src[1] = s1; J.rows[1] = r1; J.ld[1] = K;
     };
     const bool build = !t_shadows_valid;        // (valid: camo_clip_adamw_shadows left them ready; only the clears ride in this launch)
+    if (t_shadows) t_shadows_state = save ? 2 : 1;
     if (build) {
     job(f.Wrg, H, D, P[CAMO_P_RG_PROJ_W], H); job(f.Wkg, H, D, P[CAMO_P_KG_PROJ_W], H);
     job(f.Wqkv_rg, 3 * H, H, P[CAMO_P_A1_IN_W], H, P[CAMO_P_A2_IN_W] + HH, 2 * H);       // [Wq1; Wk2; Wv2]: what RG rows are projected with
@@ -888,6 +890,22 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
                  uint64_t seed, int32_t precision, int32_t flags, void* stream) {
   return forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
                       attn_rg2kg, attn_kg2rg, training, seed, precision, flags, stream, nullptr);
+}
+
+int camo_forward_cached(const camo_dims_t* dims, const float* const* params, const float* rg, const int32_t* rg_offsets,
+                        const void* batch_desc, const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace,
+                        size_t workspace_bytes, float* outs, float* attn_rg2kg, float* attn_kg2rg, int32_t training,
+                        uint64_t seed, int32_t precision, int32_t flags, void* shadows, int32_t shadows_valid, int32_t* shadows_state,
+                        void* stream) {
+  if (shadows_state) *shadows_state = 0;
+  if (shadows_valid && !shadows) return fail(CAMO_E_ARG, "shadows_valid without a shadow buffer");
+  if (shadows && (reinterpret_cast<uintptr_t>(shadows) & 255)) return fail(CAMO_E_ARG, "the shadow buffer must be 256-byte aligned");
+  t_shadows = shadows; t_shadows_valid = shadows && shadows_valid != 0; t_shadows_state = 0;
+  const int rc = forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
+                              attn_rg2kg, attn_kg2rg, training, seed, precision, flags, stream, nullptr);
+  t_shadows = nullptr; t_shadows_valid = false;
+  if (rc == 0 && shadows_state) *shadows_state = t_shadows_state;
+  return rc;
 }
 
 // camo_forward_loss_backward's optional event: recorded on the stream as soon as the gradients of the per-sample tail (pooled

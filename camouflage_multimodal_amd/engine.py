@@ -89,7 +89,8 @@ class FusionEngine:
         self._offsets_cache = {}
         self._ws = None
         self._shadows = None          # persistent bf16 weight shadows of the fused schedule (camo_shadow_bytes)
-        self._shadows_version = None  # param_version() right after the optimizer call that left them current
+        self._shadows_version = None  # param_version() right after the call that left them current (optimizer step or forward)
+        self._shadows_full = False    # they include the transposed set the backward needs (an inference call builds the forward set only)
         self._plist = None
         self._seed_base = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self._calls = 0
@@ -270,8 +271,9 @@ class FusionEngine:
         return (self._seed_base + 0x9E3779B97F4A7C15 * self._calls) & 0xFFFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------ raw calls
-    def forward_raw(self, batch, ws, training, seed, want_attention=False, outs=None, inference=False):
-        """``inference``: no backward_raw will follow on this workspace (lets the library skip what it would save)."""
+    def forward_raw(self, batch, ws, training, seed, want_attention=False, outs=None, inference=False, cache_shadows=True):
+        """``inference``: no backward_raw will follow on this workspace (lets the library skip what it would save).
+        ``cache_shadows=False``: an inference call that keeps its weight shadows in ``ws`` like any other call (tests read them there)."""
         mod = self.module()
         if outs is None:
             outs = torch.empty(batch.B, self.out_width, dtype=torch.float32, device=batch.rg.device)
@@ -279,11 +281,25 @@ class FusionEngine:
         if want_attention and self.cross:
             a1 = torch.empty(batch.T, batch.Nk, dtype=torch.float32, device=batch.rg.device)
             a2 = torch.empty(batch.T, batch.Nk, dtype=torch.float32, device=batch.rg.device)
+        # inference calls keep the fused schedule's weight shadows in the engine's persistent buffer: a validation / prediction
+        # loop builds them once per parameter change instead of once per call (the library says what it left there)
+        sh = self.shadow_buffer() if (inference and cache_shadows and a1 is None) else None
         with _on(self.device):
-            rc = _lib.lib().camo_forward(C.byref(self.dims), self._ptab, _ptr(batch.rg), _ptr(batch.offsets),
-                                         _ptr(batch.desc), _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs),
-                                         _ptr(a1), _ptr(a2), int(bool(training)), seed, _PREC[mod.precision],
-                                         _lib.FWD_INFERENCE if inference else 0, _stream_ptr(self.device))
+            if sh is not None:
+                valid = int(self.shadows_current())
+                state = C.c_int32(0)
+                rc = _lib.lib().camo_forward_cached(C.byref(self.dims), self._ptab, _ptr(batch.rg), _ptr(batch.offsets),
+                                                    _ptr(batch.desc), _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(),
+                                                    _ptr(outs), None, None, int(bool(training)), seed, _PREC[mod.precision],
+                                                    _lib.FWD_INFERENCE, _ptr(sh), valid, C.byref(state), _stream_ptr(self.device))
+                if rc == 0 and state.value:
+                    self._shadows_full = state.value == 2 or bool(valid and self._shadows_full)
+                    self._shadows_version = self.param_version()
+            else:
+                rc = _lib.lib().camo_forward(C.byref(self.dims), self._ptab, _ptr(batch.rg), _ptr(batch.offsets),
+                                             _ptr(batch.desc), _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs),
+                                             _ptr(a1), _ptr(a2), int(bool(training)), seed, _PREC[mod.precision],
+                                             _lib.FWD_INFERENCE if inference else 0, _stream_ptr(self.device))
         _lib.check(rc, "camo_forward")
         return outs, ((a1, a2) if a1 is not None else None)
 
@@ -316,7 +332,7 @@ class FusionEngine:
         terms = torch.empty(batch.B, 4, dtype=torch.float32, device=dev)
         pred = torch.empty(batch.B, dtype=torch.int32, device=dev)
         sh = self.shadow_buffer() if use_shadows else None
-        valid = int(sh is not None and self.shadows_current())
+        valid = int(sh is not None and self.shadows_current() and self._shadows_full)
         self._shadows_version = None                         # (whatever happens next, they are consumed: the optimizer renews them)
         with _on(self.device):
             rc = _lib.lib().camo_forward_loss_backward(

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CAMO_ABI_VERSION 6
+#define CAMO_ABI_VERSION 7
 
 enum {
   CAMO_OK = 0,
@@ -121,6 +121,23 @@ int camo_forward(const camo_dims_t* dims, const float* const* params,
                  void* workspace, size_t workspace_bytes,
                  float* outs, float* attn_rg2kg, float* attn_kg2rg,
                  int32_t training, uint64_t seed, int32_t precision, int32_t flags, void* stream);
+
+/* camo_forward_cached: camo_forward for callers that run many forward calls between parameter changes -- validation and
+ * prediction loops (train_multimodal.py:304-342 validate_fixed, test_multimodal.py:105-150): the fused schedule's bf16 weight
+ * shadows live in the caller's persistent buffer (camo_shadow_bytes() bytes, 256-byte aligned) instead of the per-batch
+ * workspace, and a call with shadows_valid != 0 -- the caller's promise that the buffer holds the current parameters, i.e.
+ * that nothing wrote them since the call that reported the buffer filled -- skips the shadow launch (3 launches instead of 4
+ * per inference call).  *shadows_state (may be null) reports what the buffer holds after the call: 0 = untouched (the call
+ * took a schedule without shadows: Nk > 16, attention maps, f32 ...; a promise is then simply not used), 1 = the forward
+ * shadows (an inference call built them, or used valid ones), 2 = forward and transposed shadows (a call that saves for
+ * camo_backward built them: everything camo_forward_loss_backward(shadows_valid = 1) needs).  shadows == NULL: camo_forward. */
+int camo_forward_cached(const camo_dims_t* dims, const float* const* params,
+                        const float* rg, const int32_t* rg_offsets, const void* batch_desc,
+                        const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr,
+                        void* workspace, size_t workspace_bytes,
+                        float* outs, float* attn_rg2kg, float* attn_kg2rg,
+                        int32_t training, uint64_t seed, int32_t precision, int32_t flags,
+                        void* shadows, int32_t shadows_valid, int32_t* shadows_state, void* stream);
 
 /* ---- backward ------------------------------------------------------------
  * Stands behind loss.backward() through the model (train_multimodal.py:270):

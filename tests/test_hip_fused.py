@@ -85,7 +85,7 @@ def test_fused_forward_stage_by_stage(training, kg_real, fused_opts):
     fused_opts("fused_save", 1)
     ws = eng.workspace(batch, private=True)
     ws.zero_()
-    outs, _ = eng.forward_raw(batch, ws, training, seed, inference=True)
+    outs, _ = eng.forward_raw(batch, ws, training, seed, inference=True, cache_shadows=False)
     torch.cuda.synchronize()
     orc = FO.FusionOracle(cfg, prm)
     ref, caches = orc.forward_list(rg, kg, training=training, seed=seed)

@@ -270,3 +270,67 @@ def test_shadow_reuse_survives_batches_outside_the_fused_schedule(kg_real):
     for step, (la, lb) in enumerate(zip(res[0][0], res[1][0])):           # (parameters drift by Adam's noise; the losses are the witness)
         assert_close(la, lb, 1e-4 if step == 0 else 2e-2, 2e-3, f"loss terms, step {step}")
     assert np.abs(res[0][1] - res[1][1]).max() <= 2.2 * 5e-4 * 5
+
+
+def test_inference_calls_reuse_the_weight_shadows(kg_real):
+    """camo_forward_cached: a validation / prediction loop builds the fused schedule's weight shadows once per parameter change.
+    (1) cached and uncached calls give the same outputs; (2) the second call does not touch the shadow buffer; (3) a parameter
+    change through torch is noticed and the outputs follow the new parameters; (4) a training step after inference calls
+    rebuilds the full set (the inference call leaves the forward set only), and inference right after an optimizer step
+    uses what the optimizer left; (5) a batch outside the fused schedule (Nk = 17) leaves the buffer alone and is correct."""
+    import copy
+    from camouflage_multimodal_amd import NativeTrainer
+    cfg = OP.full_cfg()
+    nrs = [303, 64, 33, 530, 17]
+    rg = torch.from_numpy(np.concatenate([OP.make_rg(n, 128, seed=60 + i) for i, n in enumerate(nrs)])).cuda()
+    kg = torch.from_numpy(np.stack([kg_real] * len(nrs))).cuda()
+    kg17 = torch.from_numpy(np.stack([OP.make_kg(17, 128, seed=9 + i) for i in range(len(nrs))])).cuda()
+    y, e, s = (torch.from_numpy(v) for v in OP.make_labels(len(nrs), seed=5))
+    m = make_model(cfg, 3, "bf16").eval()
+    tr = NativeTrainer(m)
+    eng = m._engine
+
+    def uncached():                       # the plain entry point: shadows rebuilt in the workspace by the call itself
+        b = eng.make_batch(rg, nrs, kg)
+        outs, _ = eng.forward_raw(b, eng.workspace(b, private=True), False, 0, inference=False)
+        return t2n(outs)
+
+    # (1), (2)
+    o1 = t2n(tr.evaluate(rg, nrs, kg))
+    assert eng.shadows_current() and not eng._shadows_full
+    snap = eng._shadows.clone()
+    eng._shadows[-4096:].fill_(0x5A)      # the transposed set's tail is not part of the forward set: an inference call must not need it
+    o2 = t2n(tr.evaluate(rg, nrs, kg))
+    torch.cuda.synchronize()
+    assert torch.equal(eng._shadows[:-4096], snap[:-4096])
+    ref = uncached()
+    assert_close(o1, ref, 2e-6, 1e-5, "cached (building) call vs plain call")
+    assert_close(o2, ref, 2e-6, 1e-5, "cached (reusing) call vs plain call")
+    # (3)
+    other = make_model(cfg, 4, "bf16")
+    m.load_state_dict(copy.deepcopy(other.state_dict()))
+    assert not eng.shadows_current()
+    o3 = t2n(tr.evaluate(rg, nrs, kg))
+    assert eng.shadows_current()
+    assert_close(o3, uncached(), 2e-6, 1e-5, "after load_state_dict")
+    assert np.abs(o3 - o1).max() > 1e-3
+    # (5)
+    before = eng._shadows.clone()
+    o17 = t2n(tr.evaluate(rg, nrs, kg17))
+    b17 = eng.make_batch(rg, nrs, kg17)
+    p17, _ = eng.forward_raw(b17, eng.workspace(b17, private=True), False, 0, inference=False)
+    assert_close(o17, t2n(p17), 2e-6, 1e-5, "Nk = 17")
+    assert torch.equal(before, eng._shadows) and eng.shadows_current()
+    # (4) training after inference: same losses as a trainer that never reuses anything
+    m2 = make_model(cfg, 4, "bf16").train(); m.train()
+    t2 = NativeTrainer(m2, reuse_shadows=False)
+    for step in range(3):
+        la, _ = tr.step(rg, nrs, kg, y, e, s, seed=900 + step); lb, _ = t2.step(rg, nrs, kg, y, e, s, seed=900 + step)
+        assert_close(t2n(la), t2n(lb), 1e-4 if step == 0 else 1e-2, 1e-3, f"loss terms, step {step}")
+        if step == 1:                     # a validation pass in the middle of training: uses the optimizer's shadows, leaves them usable
+            m.eval(); m2.eval()
+            assert eng.shadows_current() and eng._shadows_full
+            va = t2n(tr.evaluate(rg, nrs, kg)); vb = t2n(t2.evaluate(rg, nrs, kg))
+            assert eng.shadows_current() and eng._shadows_full
+            assert_close(va, vb, 5e-3, 5e-3, "validation outputs in the middle of training")
+            m.train(); m2.train()
