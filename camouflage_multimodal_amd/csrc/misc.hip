@@ -1340,8 +1340,8 @@ int launch_clip_adamw_shadows(float* p, float* g, float* m, float* v, float* sum
     B.tile_begin = tiles;
     tiles += (B.rows >> 5) * (B.cols >> 6);
   }
-  size_t rest = 0;
-  for (int i = 0; i < a.nrange; ++i) { if ((a.range_begin[i] & 3) || (a.range_len[i] & 3)) return (int)hipErrorInvalidValue; rest += a.range_len[i]; }
+  for (int i = 0; i < a.nrange; ++i)
+    if ((a.range_begin[i] & 3) || (a.range_len[i] & 3)) return (int)hipErrorInvalidValue;
   a.tiles = tiles;
   for (int i = 1; i < a.nrange; ++i)                         // longest first
     for (int j = i; j > 0 && a.range_len[j] > a.range_len[j - 1]; --j) {
