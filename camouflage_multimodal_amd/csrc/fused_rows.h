@@ -81,6 +81,7 @@ struct Bwd1Args {
   us16* dQKV16; float* dKV;                    // out: dQ into columns 0..255 of [T][768]; dK|dV [B*Nk][512] += (atomics, zeroed by the caller)
   const us16* O2_16; us16* dO2_16; float* delta2;   // KG: attention output in, its gradient out [B*Nk][256], row-dots out [B][8][16]
   const int* off; const int* tile_off; const float* inv_nr; const int4* tile_desc;
+  const int* row_sample;                       // RG row -> sample (the batch descriptor's table)
   int B, Nk, rg_tiles_max, rows_rg; float qscale; DropCfg drop; unsigned long long* stamps;
   int writer_blocks;                           // (filled by the launcher)
   // clears for the weight-gradient launch (pad rows of its operands) when no shadow launch did them: one extra block each

@@ -700,29 +700,42 @@ __global__ __launch_bounds__(256, 2) void bwd1_kernel(const Bwd1Args a) {
   if ((int)blockIdx.x >= a.B + a.rg_tiles_max) {
     // writer blocks: materialise dH = mask * d(mean H) / n as the bf16 weight-gradient operand (the tiles above build the same
     // values on the fly and never store them: a store stream in the middle of their weight stream would stall it).
-    // One wave per row per pass; lane l covers features 8 l .. 8 l + 7: mask byte l of the row's 64.
+    // A wave takes WR consecutive rows per pass, lane l covers features 8 l .. 8 l + 7 (mask byte l of the row's 64); the pass is
+    // two dependent round trips (row -> sample and mask word, then the sample's gradient row) whatever WR is, and these blocks
+    // carry the kernel's 69 KB LDS reservation (two per CU: eight waves), so rows in flight per wave is what sets their rate
+    // -- one row per pass and a binary search for the sample left a 23 us train of writer blocks behind the tiles at B = 64
+    constexpr int WR = 4;
     const int wb = (int)blockIdx.x - a.B - a.rg_tiles_max;
     const int total_rows = a.rows_rg + a.B * a.Nk;
-    for (int r = wb * 4 + (tid >> 6); r < total_rows; r += 4 * a.writer_blocks) {
-      const bool isk = r >= a.rows_rg;
-      const Bwd1Stream& W = a.s[isk ? 1 : 0];
-      const int row = isk ? r - a.rows_rg : r;
-      int sb; float inv;
-      if (isk) { sb = row / a.Nk; inv = 1.0f / (float)a.Nk; }
-      else {
-        int lo = 0, hi = a.B - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.off[mid] <= row) lo = mid; else hi = mid - 1; }
-        sb = lo; inv = a.inv_nr[sb];
+    const float gscale = a.drop.scale;
+    for (int r0 = (wb * 4 + (tid >> 6)) * WR; r0 < total_rows; r0 += 4 * WR * a.writer_blocks) {
+      int sb[WR]; uint32_t word[WR]; bool isk[WR]; int row[WR];
+#pragma unroll
+      for (int k = 0; k < WR; ++k) {
+        const int r = min(r0 + k, total_rows - 1);
+        isk[k] = r >= a.rows_rg;
+        row[k] = isk[k] ? r - a.rows_rg : r;
+        sb[k] = isk[k] ? row[k] / a.Nk : a.row_sample[row[k]];
+        word[k] = a.s[isk[k] ? 1 : 0].mask[(size_t)row[k] * 16 + (lane >> 2)];
       }
-      const uint32_t word = W.mask[(size_t)row * 16 + (lane >> 2)];
-      const uint32_t bits = word >> (8 * (lane & 3));
-      const float gs = inv * a.drop.scale;
-      const float4 g0 = *reinterpret_cast<const float4*>(W.dHm + (size_t)sb * W.ld_dHm + 8 * lane);
-      const float4 g1 = *reinterpret_cast<const float4*>(W.dHm + (size_t)sb * W.ld_dHm + 8 * lane + 4);
-      auto sel = [&](int k, float g) { return ((bits >> k) & 1u) ? (uint32_t)f2bf(g * gs) : 0u; };
-      const u32x4 fr = u32x4{sel(0, g0.x) | (sel(1, g0.y) << 16), sel(2, g0.z) | (sel(3, g0.w) << 16),
-                             sel(4, g1.x) | (sel(5, g1.y) << 16), sel(6, g1.z) | (sel(7, g1.w) << 16)};
-      *reinterpret_cast<u32x4*>(W.dH16 + (size_t)row * 512 + 8 * lane) = fr;     // (write-through here: no gain at B = 16, +4 us at B = 64)
+      float4 g0[WR], g1[WR]; float inv[WR];
+#pragma unroll
+      for (int k = 0; k < WR; ++k) {
+        const Bwd1Stream& W = a.s[isk[k] ? 1 : 0];
+        const float* gp = W.dHm + (size_t)sb[k] * W.ld_dHm + 8 * lane;
+        g0[k] = *reinterpret_cast<const float4*>(gp); g1[k] = *reinterpret_cast<const float4*>(gp + 4);
+        inv[k] = isk[k] ? 1.0f / (float)a.Nk : a.inv_nr[sb[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < WR; ++k) {
+        if (r0 + k >= total_rows) break;
+        const uint32_t bits = word[k] >> (8 * (lane & 3));
+        const float gs = inv[k] * gscale;
+        auto sel = [&](int j, float g) { return ((bits >> j) & 1u) ? (uint32_t)f2bf(g * gs) : 0u; };
+        const u32x4 fr = u32x4{sel(0, g0[k].x) | (sel(1, g0[k].y) << 16), sel(2, g0[k].z) | (sel(3, g0[k].w) << 16),
+                               sel(4, g1[k].x) | (sel(5, g1[k].y) << 16), sel(6, g1[k].z) | (sel(7, g1[k].w) << 16)};
+        *reinterpret_cast<u32x4*>(a.s[isk[k] ? 1 : 0].dH16 + (size_t)row[k] * 512 + 8 * lane) = fr;     // (write-through here: no gain at B = 16, +4 us at B = 64)
+      }
     }
     return;
   }
@@ -1288,7 +1301,7 @@ size_t fused_bwd1_lds() { return W_LDS; }
 
 int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
   if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q16 || !a.KV16 || !a.dQKV16 || !a.dKV || !a.O2_16 || !a.dO2_16 || !a.delta2 ||
-      !a.off || !a.tile_off || !a.tile_desc || !a.inv_nr)
+      !a.off || !a.tile_off || !a.tile_desc || !a.inv_nr || !a.row_sample)
     return (int)hipErrorInvalidValue;
   for (int i = 0; i < 2; ++i) {
     const Bwd1Stream& S = a.s[i];
@@ -1303,7 +1316,7 @@ int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
     return true;
   }();
   (void)attr;
-  a.writer_blocks = (a.rows_rg + a.B * a.Nk + 3) / 4;                // one row per wave: a pass is a dependent load -> store chain
+  a.writer_blocks = (a.rows_rg + a.B * a.Nk + 15) / 16;              // four rows per wave per pass (see the kernel; eight: the same at B = 64, -5 us at B = 256)
   if (a.writer_blocks > 8192) a.writer_blocks = 8192;
   if (a.nzero < 0 || a.nzero > FUSED_BWD1_MAXZ) return (int)hipErrorInvalidValue;
   for (int i = 0; i < a.nzero; ++i)

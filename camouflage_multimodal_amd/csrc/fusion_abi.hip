@@ -725,7 +725,7 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
                        Gr[CAMO_P_LN2_W], Gr[CAMO_P_LN2_B]};
   a1.Q16 = f.Q16; a1.KV16 = f.KV16; a1.dQKV16 = f.dQKV16; a1.dKV = w.dKV;
   a1.O2_16 = f.O2_16; a1.dO2_16 = f.dO2_16; a1.delta2 = f.delta2;
-  a1.off = rg_offsets; a1.tile_off = bd.tile_off; a1.tile_desc = bd.tile_desc; a1.inv_nr = bd.inv_nr;
+  a1.off = rg_offsets; a1.tile_off = bd.tile_off; a1.tile_desc = bd.tile_desc; a1.inv_nr = bd.inv_nr; a1.row_sample = bd.row_sample;
   a1.B = B; a1.Nk = Nk; a1.rows_rg = T; a1.rg_tiles_max = T / 32 + B; a1.qscale = 1.0f / sqrtf(32.0f); a1.drop = drop;
   a1.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)2 * g_dbg_stamp_blocks * 8 : nullptr;
   a1.nzero = t_nzero_bwd1;
