@@ -57,6 +57,7 @@ struct BackArgs {
   const int* off; const int* tile_off; const float* inv_nr;
   const int4* tile_desc;                       // per 32-row RG tile {sample, first packed row, rows, 1 / Nr as bits}; sample = -1 past the last tile
   float* lse2;                                 // [B][8][16][2]: max and sum of the KG->RG softmax (saved for backward)
+  int lead_tiles;                              // (filled by the launcher) RG tile blocks dispatched in front of the KG split blocks
   float* part; int* tickets; int max_splits;   // KG->RG attention runs as ceil(Nr / 64) split blocks per sample (max_splits = the
                                                // largest count: grid sizing): partials [rg_tiles_max][8][FUSED_PART_FLOATS] indexed by
                                                // the split's first 32-row tile, and one ZEROED arrival counter per sample
@@ -64,6 +65,7 @@ struct BackArgs {
   DropCfg drop; int save;
   unsigned long long* stamps;                  // developer timeline (null in product calls)
 };
+extern int g_back_lead_mode;                   // developer A/B: 0 = KG split blocks always first
 int launch_fused_back(BackArgs& a, int variant, hipStream_t stream);
 
 // ---- backward, first half (see fused_rows.hip)

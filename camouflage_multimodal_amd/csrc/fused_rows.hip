@@ -507,7 +507,12 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nkg = a.B * a.max_splits;
-  const bool kg = (int)blockIdx.x < nkg;                                   // the KG attention splits are dispatched first
+  // Dispatch order.  Small batches: the KG attention splits first -- their sample's chain behind them is the kernel's critical
+  // path.  Large batches (more blocks than the 2 x 256 slots): one RG tile per CU first, then the splits, then the other tiles
+  // -- hundreds of light, latency-bound split blocks alone on the chip were 10 us (B = 64) to 45 us (B = 256) in which no
+  // weight stream ran.  vid = the block's id in the splits-first numbering.
+  const int vid = (int)blockIdx.x < a.lead_tiles ? nkg + (int)blockIdx.x : ((int)blockIdx.x < a.lead_tiles + nkg ? (int)blockIdx.x - a.lead_tiles : (int)blockIdx.x);
+  const bool kg = vid < nkg;
   const int rot = ROT ? (int)(blockIdx.x >> 3) : 0;
   char* bufO = smem + B_BUFO; char* bufY = smem + B_BUFY;
   float* red = reinterpret_cast<float*>(smem + B_RED);
@@ -519,8 +524,8 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
   Stage<4, 16, false, DEPTH> stf;
   if (!kg) sto.prefetch(reinterpret_cast<const u32x4*>(S.Wo) + (size_t)w * (16 * 2 * 64) + lane, rot);   // (flows during the attention)
   if (kg) {
-    b = (int)blockIdx.x / a.max_splits;
-    const int sp = (int)blockIdx.x - b * a.max_splits;
+    b = vid / a.max_splits;
+    const int sp = vid - b * a.max_splits;
     const int nsplit = (a.off[b + 1] - a.off[b] + SPLIT_ROWS - 1) / SPLIT_ROWS;
     if (sp >= nsplit) return;
     attn_kg_split(a, smem, b, sp, w, lane);
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
   } else {
     // one 16-byte load of the batch descriptor's tile table {sample, first row, rows, 1 / Nr} (a binary search of tile_off here was
     // five dependent global loads: 1.5-2 us before a tile's first useful instruction)
-    const int4 td = a.tile_desc[(int)blockIdx.x - nkg];
+    const int4 td = a.tile_desc[vid - nkg];
     if (td.x < 0) return;
     b = td.x; rowg0 = td.y; nrows = td.z; inv_n = __int_as_float(td.w);
     attn_rg_tile(a, smem, b, rowg0, nrows, w, lane);
@@ -1269,6 +1274,7 @@ int launch_fused_front(FrontArgs& a, int variant, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+int g_back_lead_mode = 1;
 int launch_fused_back(BackArgs& a, int variant, hipStream_t stream) {
   if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q16 || !a.KV16 || !a.Q2_16 || !a.KV2_16 || !a.off || !a.tile_off || !a.tile_desc || !a.inv_nr ||
       !a.part || !a.tickets || a.max_splits < 1 || a.max_splits > FUSED_MAX_SPLITS)
@@ -1287,6 +1293,7 @@ int launch_fused_back(BackArgs& a, int variant, hipStream_t stream) {
   }();
   (void)attr;
   const dim3 grid(a.B * a.max_splits + a.rg_tiles_max);
+  a.lead_tiles = (g_back_lead_mode != 0 && a.rows_rg / 32 >= 256 && (int)grid.x > 512) ? 256 : 0;      // (rows / 32 <= number of real tiles)
   // executed FLOPs per row: out-projection 256 -> 256, FFN layer 0 256 -> 512, both attention directions (2 x 2 x Nk x 256)
   const double rows = (double)a.rows_rg + (double)a.B * a.Nk;
   const int prof = gemm_prof_open(stream, 2.0 * rows * (256.0 * 256.0 + 256.0 * 512.0) + 8.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BACK);
