@@ -1210,6 +1210,7 @@ int camo_debug_set_option(const char* name, int32_t value) {
   if (std::strcmp(name, "fused_variant") == 0) { g_opt_fused_variant = value; return 0; }
   if (std::strcmp(name, "tail17") == 0) { g_opt_tail17 = value; return 0; }
   if (std::strcmp(name, "back_lead") == 0) { g_back_lead_mode = value; return 0; }
+  if (std::strcmp(name, "tn_balance") == 0) { g_gemm16_balance = value; return 0; }
   if (std::strcmp(name, "tn_kcap") == 0) { g_gemm16_tn_kcap = value; return 0; }
   return fail(CAMO_E_ARG, std::string("unknown option ") + name);
 }

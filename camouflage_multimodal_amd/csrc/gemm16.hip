@@ -572,8 +572,18 @@ __global__ __launch_bounds__(256, ROWS ? 2 : 3) void gemm16_kernel(const Gemm16B
   // XCD-aware block remap (bijective): blocks that share an XCD (bid % 8) take a contiguous run of tiles
   int bid = blockIdx.x;
   {
-    const int nwg = total_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int nwg = total_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    const int first = xcd * q + min(xcd, r);                  // the XCD's run in the plain remap
+    if (gb.n_heavy > 0) {
+      // the weight-gradient launch: long split-K blocks (RG-side problems) in front, short ones (the 13-row KG side) behind.  One
+      // contiguous run per XCD gave XCD 7 all the short blocks and 3 long ones (idle after 16 of the launch's 26 us) and the
+      // others 59 long ones each; here every XCD takes an equal share of each kind, still contiguous within the kind
+      const int nh = gb.n_heavy, qh = nh >> 3, rh = nh & 7;
+      const int hc = qh + (xcd < rh ? 1 : 0), hfirst = xcd * qh + min(xcd, rh);
+      bid = j < hc ? hfirst + j : nh + (first - hfirst) + (j - hc);
+    } else {
+      bid = first + j;
+    }
   }
   int pi = 0;
 #pragma unroll
@@ -611,6 +621,7 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
+int g_gemm16_balance = 1;             // developer A/B ("tn_balance")
 int g_gemm16_tn_kcap = 0;             // developer A/B (camo_debug_set_option "tn_kcap"): > 0 pins the split-K depth
 int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
   if (gb.n <= 0) return 0;
@@ -620,11 +631,11 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
   // are more blocks than that (measured, bf16 training step: B = 16 -> 16 tiles [8: +12 us, 32: +8 us]; B = 64 -> 64 tiles
   // [16: +18 us, 8: +56 us]); a launch that would leave most CUs idle even at 16 (the general schedule's lone dW_rg / dW_kg
   // launch) goes down to 8 to spread over the chip.
-  int total = 0;
+  int total = 0, kcap_used = 0;
   static const int kcaps[] = {512, 384, 256, 192, 128, 96, 64, 48, 32, 24, 16, 8};
   for (int ci = 0;; ++ci) {
     const int kcap = g_gemm16_tn_kcap > 0 ? g_gemm16_tn_kcap : kcaps[ci];
-    total = 0;
+    total = 0; kcap_used = kcap;
     for (int i = 0; i < gb.n; ++i) {
       Gemm16Prob& p = gb.p[i];
       const bool akm = p.flags & GF_A_KMAJOR, bkm = p.flags & GF_B_KMAJOR;
@@ -666,6 +677,16 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
       total += tiles * p.ksplit;
     }
     if (g_gemm16_tn_kcap > 0 || (kcap > 16 ? total >= 440 : total >= 200) || kcap <= KCAP_MIN) break;
+  }
+  gb.n_heavy = 0;
+  // (measured on the training step: B = 4 -2.8 us, B = 16 +-0, B = 64 +0.7 us -- with long chunks the short blocks no longer
+  // matter and the plain runs keep a K slice's tiles together; hence only up to 16-tile chunks)
+  if (g_gemm16_balance && kcap_used <= 16) {                  // a prefix of split-K problems followed by single-slice ones only
+    int i = 0;
+    while (i < gb.n && (gb.p[i].flags & GF_A_KMAJOR) && gb.p[i].ksplit > 1) ++i;
+    const int first_light = i;
+    while (i < gb.n && (gb.p[i].flags & GF_A_KMAJOR) && gb.p[i].ksplit == 1) ++i;
+    if (i == gb.n && first_light > 0 && first_light < gb.n) gb.n_heavy = gb.p[first_light].tile_begin;
   }
   bool has_tn = false, has_rows = false, has_virt = false;
   for (int i = 0; i < gb.n; ++i) {
