@@ -15,6 +15,8 @@ for B in (128, 16):
     steps = 20000 if B == 16 else 40
     for i in range(steps):
         terms, pred = tr.step(*bt[i % 4])
+        if i % 50 == 49:                       # a validation pass now and then: inference calls share the optimizer's weight shadows
+            model.eval(); tr.evaluate(*bt[(i // 50) % 4][:3]); tr.evaluate(*bt[(i // 50 + 1) % 4][:3]); model.train()
         if i % (steps // 8) == 0 or i == steps - 1:
             losses.append(float(terms.sum().item()) / B)
     torch.cuda.synchronize()
