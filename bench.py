@@ -303,8 +303,13 @@ def main():
             tb = timed_blocks(lambda i: trainer.step(*db[i % 2]), ks, 3, min_seconds=0.25)
             st = float(np.median(tb)) / ks
             fl = float(np.mean([algorithmic_flops(b[1]) for b in hb]))
+            # the same batches forward-only (eval mode, weight shadows kept across calls): where the forward's MFMA fraction goes with B
+            fb2 = timed_blocks(lambda i: trainer.evaluate(*db[i % 2][:3]), ks, 3, min_seconds=0.15)
+            ft = float(np.median(fb2)) / ks
             sweep.append({"batch": Bs, "ms_per_step": round(st * 1e3, 4), "images_per_s": round(Bs / st, 1),
-                          "whole_step_tflops": round(fl / st / 1e12, 2), "frac": round(fl / st / 1e12 / peak, 5)})
+                          "whole_step_tflops": round(fl / st / 1e12, 2), "frac": round(fl / st / 1e12 / peak, 5),
+                          "forward_ms": round(ft * 1e3, 4), "forward_images_per_s": round(Bs / ft, 1),
+                          "forward_tflops": round(fl / FWDBWD_OVER_FWD / ft / 1e12, 2), "forward_frac": round(fl / FWDBWD_OVER_FWD / ft / 1e12 / peak, 5)})
             del db
         extras["sweep"] = sweep
         # (c) the exact-f32 mode (f32-input MFMA, general schedule) on the headline batch
