@@ -34,7 +34,7 @@ struct FrontStream {
 #define FUSED_FRONT_MAXZ 4
 #define FUSED_BWD1_MAXZ 16
 struct FrontArgs {
-  FrontStream s[2]; float qscale; int save; unsigned long long* stamps;
+  FrontStream s[2]; float qscale; int save; unsigned long long* stamps; int exp;   // exp: developer experiments (timing only), 0 in product calls
   // clears that ride at the end of every block when no shadow launch precedes this one (the step's atomics block, d(mean H)):
   // 16-byte aligned, sizes multiples of 16; spread over the grid
   void* zero_ptr[FUSED_FRONT_MAXZ]; unsigned zero_bytes[FUSED_FRONT_MAXZ]; int nzero;
@@ -62,7 +62,7 @@ struct BackArgs {
                                                // largest count: grid sizing): partials [rg_tiles_max][8][FUSED_PART_FLOATS] indexed by
                                                // the split's first 32-row tile, and one ZEROED arrival counter per sample
   int B, Nk, rg_tiles_max, rows_rg;             // rows_rg = T (launch-timing bookkeeping only)
-  DropCfg drop; int save;
+  DropCfg drop; int save; int exp;
   unsigned long long* stamps;                  // developer timeline (null in product calls)
 };
 extern int g_back_lead_mode;                   // developer A/B: 0 = KG split blocks always first
@@ -114,3 +114,13 @@ size_t fused_bwd2_lds();
 #define FUSED_MAX_SPLITS 64
 size_t fused_front_lds();
 size_t fused_back_lds();
+
+// ---- wide row tiles for large batches (fused_wide.hip): the same argument blocks, weight shadows and tile table; a block of 8
+// waves owns rt (1, 2 or 4) consecutive 32-row tiles and feeds rt MFMAs from every weight fragment it loads.  The back kernel
+// computes the KG->RG attention partials inside the RG blocks (one per run of sub-tiles of a sample: partial slot = the run's
+// first tile), so BackArgs::max_splits / lead_tiles are unused there; a sample may span at most FUSED_WIDE_MAXSEG blocks.
+#define FUSED_WIDE_MAXSEG 48
+int launch_wide_front(FrontArgs& a, int rt, hipStream_t stream, int kg_only = 0);     // kg_only: stream 1 (the KG rows) alone
+int launch_wide_rgfwd(const FrontStream& f, float qscale, BackArgs& b, int rt, int max_nr, hipStream_t stream);   // RG rows: front + back in one launch
+int launch_wide_back(BackArgs& a, int rt, int max_nr, hipStream_t stream);
+int wide_max_rows(int rt);

@@ -99,7 +99,7 @@ __device__ __forceinline__ void stamp(unsigned long long* stamps, int k) {
 // until the end-of-kernel write-back, which then has that much less to do before the next launch may start
 // (tile outputs of one training step: ~60 MB; measured -2.5 us per step at B = 16)
 __device__ __forceinline__ void store16_wt(void* p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");   // (s_nop: the data registers may be rewritten right behind an asm store)
 }
 template <int LOG2C>
 __device__ __forceinline__ void copy_out(const char* lds, int pitch, int col_byte0, us16* dst, int ld, size_t row0, int nrows) {
@@ -412,7 +412,7 @@ __device__ __forceinline__ void attn_kg_split(const BackArgs& a, char* smem, int
       const int idx = lane + 64 * r;                       // float4 idx of the [16][32] tile
       const f32x4 v = *reinterpret_cast<const f32x4*>(zt + 4 * idx);
       float* dst = part + 32 + 4 * idx;
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
     }
   }
 }

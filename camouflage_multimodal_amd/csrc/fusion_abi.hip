@@ -40,6 +40,9 @@ unsigned long long* g_dbg_stamps = nullptr;   // testing hook: timeline buffer o
 int g_dbg_stamp_blocks = 0;
 int g_opt_tail17 = -1;                        // 0 = never take the one-launch tail (misc.hip, tail_fused_kernel)
 int g_opt_fused_variant = 1;                  // developer A/B of the fused kernels' weight streaming (fused_rows.h)
+int g_opt_fused_rt = -1;     // wide row tiles (fused_wide.hip): -1 = by batch size, 0 = never, 1 / 2 / 4 = that many 32-row tiles per block
+int g_opt_fused_one = 1;     // wide tiles: 1 = the RG rows' forward as ONE launch behind the KG rows' front half (rgfwd_kernel), 0 = front + back launches
+int g_opt_exp = 0;           // developer experiments inside the wide kernels (timing only)
 int g_opt_fused_save = 0;  // 1 = inference calls of the fused schedule also write what a backward would need (tests read it back)
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -505,6 +508,16 @@ static void bind_shadows(Ws& w) {                 // (after every carve() of a c
   f.W1T = x.W1T; f.W2T = x.W2T; f.Wo1T = x.Wo1T; f.Wo2T = x.Wo2T; f.WcRgT = x.WcRgT; f.WcKgT = x.WcKgT;
 }
 
+// Which tile family a fused forward takes (fused_rows.h): 0 = 32-row tiles, one per block of 4 waves (small batches: one tile
+// per CU is all there is); 2 / 4 = that many tiles per block of 8 waves (fused_wide.hip), chosen so that the blocks still fill the chip.
+static int wide_rt(int T, int max_nr) {
+  int rt = g_opt_fused_rt;
+  if (rt < 0) rt = T >= 4 * 32 * 224 ? 4 : 0;
+  if (rt != 0 && rt != 1 && rt != 2 && rt != 4) rt = 0;
+  if (rt && max_nr > wide_max_rows(rt) - 64 * rt) rt = 0;
+  return rt;
+}
+
 int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg, const int32_t* rg_offsets, const Desc& bd,
                     const float* kg, int B, int T, int Nk, int max_nr, const Ws& w, const DropCfg& drop, bool save, hipStream_t st) {
   const int H = 256, D = 128, TK = B * Nk;
@@ -578,11 +591,14 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   fa.qscale = 1.0f / sqrtf(32.0f); fa.save = save ? 1 : 0;
   fa.s[0] = FrontStream{rg, T, f.Wrg, P[CAMO_P_RG_PROJ_B], f.Wqkv_rg, P[CAMO_P_A1_IN_B], P[CAMO_P_A2_IN_B] + H, f.X16, f.R16, f.Q16, f.KV2_16, 0};
   fa.s[1] = FrontStream{kg, TK, f.Wkg, P[CAMO_P_KG_PROJ_B], f.Wqkv_kg, P[CAMO_P_A2_IN_B], P[CAMO_P_A1_IN_B] + H, f.KG16, f.G16, f.Q2_16, f.KV16, 0};
-  fa.stamps = g_dbg_stamps;
+  fa.stamps = g_dbg_stamps; fa.exp = g_opt_exp;
   fa.nzero = t_nzero_front;
   for (int i = 0; i < t_nzero_front; ++i) { fa.zero_ptr[i] = t_zero_front_ptr[i]; fa.zero_bytes[i] = t_zero_front_bytes[i]; }
   t_nzero_front = 0;
-  CK(launch_fused_front(fa, g_opt_fused_variant, st), "fused forward, front half");
+  const int rt = wide_rt(T, max_nr);
+  const bool one = rt >= 2 && g_opt_fused_one != 0;
+  if (rt) CK(launch_wide_front(fa, rt, st, one ? 1 : 0), one ? "fused forward, KG rows' front half (wide tiles)" : "fused forward, front half (wide tiles)");
+  else CK(launch_fused_front(fa, g_opt_fused_variant, st), "fused forward, front half");
   BackArgs ba; std::memset(&ba, 0, sizeof(ba));
   ba.s[0] = BackStream{f.Wo1, P[CAMO_P_A1_OUT_B], f.W1, P[CAMO_P_F1_B0], P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], f.R16,
                        f.O16, f.Y16, f.XH16, f.rstd1, f.mask1, w.Ymean, w.H1mean, SITE_FFN_RG};
@@ -592,9 +608,11 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   ba.off = rg_offsets; ba.tile_off = bd.tile_off; ba.tile_desc = bd.tile_desc; ba.inv_nr = bd.inv_nr; ba.lse2 = f.lse2;
   ba.B = B; ba.Nk = Nk; ba.rows_rg = T; ba.rg_tiles_max = T / 32 + B;          // >= sum of ceil(Nr / 32); surplus blocks exit at once
   ba.part = f.part; ba.tickets = w.tickets; ba.max_splits = (max_nr + 63) / 64;
-  ba.drop = drop; ba.save = save ? 1 : 0;
+  ba.drop = drop; ba.save = save ? 1 : 0; ba.exp = g_opt_exp;
   ba.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)g_dbg_stamp_blocks * 8 : nullptr;
-  CK(launch_fused_back(ba, g_opt_fused_variant, st), "fused forward, back half");
+  if (one) CK(launch_wide_rgfwd(fa.s[0], fa.qscale, ba, rt, max_nr, st), "fused forward, RG rows in one launch (wide tiles)");
+  else if (rt) CK(launch_wide_back(ba, rt, max_nr, st), "fused forward, back half (wide tiles)");
+  else CK(launch_fused_back(ba, g_opt_fused_variant, st), "fused forward, back half");
   return 0;
 }
 
@@ -1207,6 +1225,9 @@ int camo_debug_set_option(const char* name, int32_t value) {
   if (std::strcmp(name, "sched16") == 0) { g_opt_sched16 = value; return 0; }
   if (std::strcmp(name, "fused") == 0) { g_opt_fused = value; return 0; }
   if (std::strcmp(name, "fused_save") == 0) { g_opt_fused_save = value; return 0; }
+  if (std::strcmp(name, "fused_rt") == 0) { g_opt_fused_rt = value; return 0; }
+  if (std::strcmp(name, "exp") == 0) { g_opt_exp = value; return 0; }
+  if (std::strcmp(name, "fused_one") == 0) { g_opt_fused_one = value; return 0; }
   if (std::strcmp(name, "fused_variant") == 0) { g_opt_fused_variant = value; return 0; }
   if (std::strcmp(name, "tail17") == 0) { g_opt_tail17 = value; return 0; }
   if (std::strcmp(name, "back_lead") == 0) { g_back_lead_mode = value; return 0; }

@@ -26,7 +26,7 @@ def _opt(name, value):
 @pytest.fixture
 def fused_opts():
     yield _opt
-    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1)
+    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1); _opt("fused_rt", -1)
 
 
 def bf16_round(x):
@@ -70,8 +70,12 @@ def close_rel(got, want, rel, what, mean_rel=None, flips=0.0):
 NRS = [303, 64, 1, 530, 65, 127, 31, 32, 33]
 
 
+@pytest.mark.parametrize("rt", [0, 1, 2, 4])
 @pytest.mark.parametrize("training", [False, True])
-def test_fused_forward_stage_by_stage(training, kg_real, fused_opts):
+def test_fused_forward_stage_by_stage(training, rt, kg_real, fused_opts):
+    """rt = 0: the 32-row tile kernels (fused_rows.hip); rt = 1, 2, 4: the wide-tile kernels (fused_wide.hip) with that many
+    32-row tiles per block -- the same saved tensors, pooled sums and logits."""
+    fused_opts("fused_rt", rt)
     cfg = OP.full_cfg()
     prm = OP.make_params(cfg, 0)
     m = make_model(cfg, 0, "bf16")
@@ -137,10 +141,12 @@ def test_fused_forward_stage_by_stage(training, kg_real, fused_opts):
     assert_close(t2n(outs), t2n(outs16), 1.5e-3, 0, "fused vs bf16-resident schedule")
 
 
-@pytest.mark.parametrize("nrs,nk", [([1], 1), ([5, 700, 32], 16), ([64] * 40, 13), ([2048, 17], 13)])
-def test_fused_forward_shapes(nrs, nk, fused_opts):
+@pytest.mark.parametrize("rt", [0, 2, 4])
+@pytest.mark.parametrize("nrs,nk", [([1], 1), ([5, 700, 32], 16), ([64] * 40, 13), ([2048, 17], 13), ([128, 256, 127, 129, 1, 383], 13)])
+def test_fused_forward_shapes(nrs, nk, rt, fused_opts):
     """Envelope of the fused schedule: one-node samples, Nk = 1 and 16, tiles that end on a sample boundary, more samples than
     KG blocks per wave, a 2048-node sample (64 key chunks per KG block)."""
+    fused_opts("fused_rt", rt)
     cfg = OP.full_cfg()
     m = make_model(cfg, 2, "bf16").eval()
     orc = FO.FusionOracle(cfg, OP.make_params(cfg, 2))
