@@ -14,9 +14,9 @@ typedef unsigned short us16;
 
 // ---- weight shadows: W [N][K] fp32 -> bf16 in the order a block's 4 waves stream it:  [wave][k step of 16][tile of 32 rows][lane][8]
 // with row n = 32 (wave * N/128 + tile) + (lane & 31), k = 16 kstep + 8 (lane >> 5) + j  (tests/test_fragment_maps.py::frag_order).
-// A logical W is up to 3 source blocks stacked along N (transposed == 0: W[n][k] = src_i[(n - n0_i) * ld_i + k]) or, for the
+// A logical W is up to 4 source blocks stacked along N (transposed == 0: W[n][k] = src_i[(n - n0_i) * ld_i + k]) or, for the
 // backward's dy.W products, stacked along K and read transposed (transposed == 1: W[n][k] = src_i[(k - k0_i) * ld_i + n]).
-struct ShadowJob { us16* dst; int N, K, transposed, nsrc; const float* src[3]; int rows[3]; int ld[3]; int chunk_begin; };
+struct ShadowJob { us16* dst; int N, K, transposed, nsrc; const float* src[4]; int rows[4]; int ld[4]; int chunk_begin; int lo; };   // lo: the residual plane bf16(W - bf16(W))
 #define SHADOW_MAXJ 24
 #define SHADOW_MAXZ 24
 struct ShadowBatch { ShadowJob j[SHADOW_MAXJ]; int n; void* zero_ptr[SHADOW_MAXZ]; size_t zero_bytes[SHADOW_MAXZ]; int nzero; };
@@ -32,12 +32,16 @@ struct FrontStream {
   int tile_begin;
 };
 #define FUSED_FRONT_MAXZ 4
+#define FUSED_FRONT_MAXX 10
 #define FUSED_BWD1_MAXZ 16
 struct FrontArgs {
   FrontStream s[2]; float qscale; int save; unsigned long long* stamps; int exp;   // exp: developer experiments (timing only), 0 in product calls
   // clears that ride at the end of every block when no shadow launch precedes this one (the step's atomics block, d(mean H)):
   // 16-byte aligned, sizes multiples of 16; spread over the grid
   void* zero_ptr[FUSED_FRONT_MAXZ]; unsigned zero_bytes[FUSED_FRONT_MAXZ]; int nzero;
+  // wide tiles only: weight-shadow jobs that ride in extra blocks behind the tile blocks (the per-sample tail's hi / lo planes,
+  // tail_wide.h: rebuilt by every call that takes the wide tail, so they need no validity tracking)
+  ShadowJob xjob[FUSED_FRONT_MAXX]; int nxjob; int xchunks; int xblock0;       // (xchunks, xblock0: filled by the launcher)
 };
 int launch_fused_front(FrontArgs& a, int variant, hipStream_t stream);   // variant: 0 <depth 12>, 1 <depth 12, rotated k order> (default), 2 <depth 16, rotated>
 

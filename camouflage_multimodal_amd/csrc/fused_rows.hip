@@ -15,6 +15,7 @@
 // the next MFMA's operand").  Stages whose epilogue reduces over ROWS (the pooled FFN activation) swap the operands:
 // lane = feature, registers = rows.
 #include "fused_rows.h"
+#include "shadow_inl.h"
 #include "gemm.h"      // launch timing hooks (gemm_prof_open / close)
 
 namespace {
@@ -123,31 +124,7 @@ __global__ __launch_bounds__(256) void shadow_kernel(const ShadowBatch sb, int t
 #pragma unroll
   for (int i = 1; i < SHADOW_MAXJ; ++i)
     if (i < sb.n && gid >= sb.j[i].chunk_begin) ji = i;
-  const ShadowJob& J = sb.j[ji];
-  const int c = gid - J.chunk_begin;
-  // chunk c = ((w * KS + ks) * NTw + t) * 64 + lane
-  const int KS = J.K >> 4, NTw = J.N >> 7;
-  const int lane = c & 63;
-  int r = c >> 6;
-  const int t = r % NTw; r /= NTw;
-  const int ks = r % KS; const int w = r / KS;
-  const int n = 32 * (w * NTw + t) + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
-  float v[8];
-  if (!J.transposed) {
-    int i = 0, nn = n;
-    while (i + 1 < J.nsrc && nn >= J.rows[i]) { nn -= J.rows[i]; ++i; }
-    // (two 16-byte loads: eight dword loads of 64 different cache lines each kept the address unit busy 4x longer)
-    const float4* p = reinterpret_cast<const float4*>(J.src[i] + (size_t)nn * J.ld[i] + k0);
-    const float4 a = p[0], b = p[1];
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  } else {
-    int i = 0, kk = k0;
-    while (i + 1 < J.nsrc && kk >= J.rows[i]) { kk -= J.rows[i]; ++i; }      // (source blocks are multiples of 8 rows)
-    const float* p = J.src[i] + (size_t)kk * J.ld[i] + n;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = p[(size_t)e * J.ld[i]];
-  }
-  reinterpret_cast<u32x4*>(J.dst)[c] = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+  shadow_chunk(sb.j[ji], gid - sb.j[ji].chunk_begin);
 }
 
 // ------------------------------------------------------------------------------------------------ forward, front half
@@ -1222,7 +1199,7 @@ int launch_weight_shadows(ShadowBatch& sb, hipStream_t stream) {
   int total = 0;
   for (int i = 0; i < sb.n; ++i) {
     ShadowJob& J = sb.j[i];
-    if ((J.N & 127) || (J.K & 15) || J.nsrc < 1 || J.nsrc > 3 || !J.dst || !al16(J.dst)) return (int)hipErrorInvalidValue;
+    if ((J.N & 127) || (J.K & 15) || J.nsrc < 1 || J.nsrc > 4 || !J.dst || !al16(J.dst)) return (int)hipErrorInvalidValue;
     int sum = 0;
     for (int s = 0; s < J.nsrc; ++s) {
       if (!J.src[s] || (J.rows[s] & 7) || (!J.transposed && (!al16(J.src[s]) || (J.ld[s] & 3)))) return (int)hipErrorInvalidValue;

@@ -19,6 +19,7 @@
 // sub-tiles of the same sample; the block that completes a sample (arrival counter) combines the partials and runs the 13-row
 // KG chain at the end of its own work.
 #include "fused_rows.h"
+#include "shadow_inl.h"
 #include "gemm.h"      // launch timing hooks
 
 namespace {
@@ -152,6 +153,16 @@ template <int RT, int DEPTH>
 __global__ __launch_bounds__(NTH, 2) void front8_kernel(const FrontArgs a) {
   using Cfg = FrontCfg<RT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x >= a.xblock0) {                           // extra blocks: weight-shadow chunks (FrontArgs::xjob)
+    const int gid = ((int)blockIdx.x - a.xblock0) * NTH + (int)threadIdx.x;
+    if (gid >= a.xchunks) return;
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < FUSED_FRONT_MAXX; ++i)
+      if (i < a.nxjob && gid >= a.xjob[i].chunk_begin) ji = i;
+    shadow_chunk(a.xjob[ji], gid - a.xjob[ji].chunk_begin);
+    return;
+  }
   const FrontStream& S = a.s[(int)blockIdx.x >= a.s[1].tile_begin ? 1 : 0];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(NTH, 2) void front8_kernel(const FrontArgs a) {
   for (int zi = 0; zi < a.nzero; ++zi) {                    // (behind the tile's own stores: nothing of this block waits for them)
     u32x4* z = static_cast<u32x4*>(a.zero_ptr[zi]);
     const unsigned n16 = a.zero_bytes[zi] >> 4;
-    for (unsigned i = blockIdx.x * NTH + tid; i < n16; i += gridDim.x * NTH) z[i] = u32x4{0u, 0u, 0u, 0u};
+    for (unsigned i = blockIdx.x * NTH + tid; i < n16; i += (unsigned)a.xblock0 * NTH) z[i] = u32x4{0u, 0u, 0u, 0u};      // (the tile blocks only)
   }
   stamp(a.stamps, 7);
 }
@@ -1191,6 +1202,19 @@ int launch_wide_front(FrontArgs& a, int rt, hipStream_t stream, int kg_only) {
   if (a.nzero < 0 || a.nzero > FUSED_FRONT_MAXZ) return (int)hipErrorInvalidValue;
   for (int i = 0; i < a.nzero; ++i)
     if (!a.zero_ptr[i] || !al16(a.zero_ptr[i]) || (a.zero_bytes[i] & 15)) return (int)hipErrorInvalidValue;
+  if (a.nxjob < 0 || a.nxjob > FUSED_FRONT_MAXX) return (int)hipErrorInvalidValue;
+  a.xchunks = 0;
+  for (int i = 0; i < a.nxjob; ++i) {
+    ShadowJob& J = a.xjob[i];
+    if ((J.N & 127) || (J.K & 15) || J.nsrc < 1 || J.nsrc > 4 || !J.dst || !al16(J.dst) || J.transposed) return (int)hipErrorInvalidValue;
+    int sum = 0;
+    for (int q = 0; q < J.nsrc; ++q) { if (!J.src[q] || !al16(J.src[q]) || (J.ld[q] & 3)) return (int)hipErrorInvalidValue; sum += J.rows[q]; }
+    if (sum != J.N) return (int)hipErrorInvalidValue;
+    J.chunk_begin = a.xchunks;
+    a.xchunks += J.N * J.K / 8;
+  }
+  a.xblock0 = total;
+  total += (a.xchunks + NTH - 1) / NTH;
   const int prof = gemm_prof_open(stream, 2.0 * ((kg_only ? 0.0 : (double)a.s[0].M) + a.s[1].M) * (128.0 * 256.0 + 256.0 * 768.0), PROF_FRONT);
   if (rt == 1) front8_launch<1>(a, total, stream); else if (rt == 2) front8_launch<2>(a, total, stream); else front8_launch<4>(a, total, stream);
   gemm_prof_close(prof, stream);

@@ -22,6 +22,7 @@
 #include "attn.h"
 #include "gemm.h"
 #include "fused_rows.h"
+#include "tail_wide.h"
 #include "gemm16.h"
 #include "misc.h"
 #include "rg_gnn.h"
@@ -42,6 +43,7 @@ int g_opt_tail17 = -1;                        // 0 = never take the one-launch t
 int g_opt_fused_variant = 1;                  // developer A/B of the fused kernels' weight streaming (fused_rows.h)
 int g_opt_fused_rt = -1;     // wide row tiles (fused_wide.hip): -1 = by batch size, 0 = never, 1 / 2 / 4 = that many 32-row tiles per block
 int g_opt_fused_one = 1;     // wide tiles: 1 = the RG rows' forward as ONE launch behind the KG rows' front half (rgfwd_kernel), 0 = front + back launches
+int g_opt_tailw = -1;        // the per-sample tail of wide-tile inference calls as one launch (tail_wide.h): 0 = never
 int g_opt_exp = 0;           // developer experiments inside the wide kernels (timing only)
 int g_opt_fused_save = 0;  // 1 = inference calls of the fused schedule also write what a backward would need (tests read it back)
 
@@ -111,6 +113,7 @@ struct Ws {
     us16 *W1T, *W2T, *Wo1T, *Wo2T, *WcRgT, *WcKgT;
     us16 *dH16, *dH2_16, *dU16, *dU2_16, *dQKV16, *dQKVkg16, *dR16, *dG16, *dO2_16;
     float *delta2, *dGpart;
+    us16* tailw[10];      // hi / lo planes of the per-sample tail's weights (tail_wide.h): W13, W23, Wfu0 [256 x 512], Wfu3 [256 x 256], heads [512 x 256]
   } f;
   int* tickets;         // [2][B] arrival counters (forward: KG->RG attention splits; backward: a sample's RG tiles), in the zero block
   float* dQ2acc;        // [TK][H] fp32 sums of the KG->RG query gradient (in the zero block, fused backward)
@@ -193,6 +196,7 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
         f.dH16 = c.take<us>(Tp * 2 * H); f.dH2_16 = c.take<us>(TKp * 2 * H); f.dU16 = c.take<us>(Tp * H); f.dU2_16 = c.take<us>(TKp * H);
         f.dQKV16 = c.take<us>(Tp * 3 * H); f.dQKVkg16 = c.take<us>(TKp * 3 * H); f.dR16 = c.take<us>(Tp * H); f.dG16 = c.take<us>(TKp * H);
         f.dO2_16 = c.take<us>(TKp * H); f.delta2 = c.take<float>((size_t)B * 8 * 16); f.dGpart = c.take<float>(TKp * H);
+        for (int i = 0; i < 10; ++i) f.tailw[i] = c.take<us>(i < 6 ? 2 * H * H : (i < 8 ? H * H : 2 * H * H));
       }
     }
   } else {
@@ -510,16 +514,22 @@ static void bind_shadows(Ws& w) {                 // (after every carve() of a c
 
 // Which tile family a fused forward takes (fused_rows.h): 0 = 32-row tiles, one per block of 4 waves (small batches: one tile
 // per CU is all there is); 2 / 4 = that many tiles per block of 8 waves (fused_wide.hip), chosen so that the blocks still fill the chip.
-static int wide_rt(int T, int max_nr) {
+static int wide_rt(int T, int max_nr, bool save = false) {
   int rt = g_opt_fused_rt;
-  if (rt < 0) rt = T >= 4 * 32 * 224 ? 4 : 0;
+  // by size: inference calls with at least ~one 128-row block per CU.  Calls that save for a backward stay on the 32-row kernels:
+  // the saved-tensor stores of the one-launch kernel are not tuned yet (measured slower: B = 64 step 0.53 vs 0.40 ms)
+  if (rt < 0) rt = (!save && T >= 4 * 32 * 224) ? 4 : 0;
   if (rt != 0 && rt != 1 && rt != 2 && rt != 4) rt = 0;
   if (rt && max_nr > wide_max_rows(rt) - 64 * rt) rt = 0;
   return rt;
 }
 
+static bool tailw_taken(const camo_dims_t& d, int B, int T, int max_nr, bool save) {
+  return g_opt_tailw != 0 && g_opt_fused_one != 0 && wide_rt(T, max_nr, save) >= 2 && tail_wide_ok(B, d.num_classes);
+}
+
 int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg, const int32_t* rg_offsets, const Desc& bd,
-                    const float* kg, int B, int T, int Nk, int max_nr, const Ws& w, const DropCfg& drop, bool save, hipStream_t st) {
+                    const float* kg, int B, int T, int Nk, int max_nr, const Ws& w, const DropCfg& drop, bool save, hipStream_t st, bool want_tailw = false) {
   const int H = 256, D = 128, TK = B * Nk;
   const size_t HH = (size_t)H * H;
   const Ws::F17& f = w.f;
@@ -595,8 +605,29 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   fa.nzero = t_nzero_front;
   for (int i = 0; i < t_nzero_front; ++i) { fa.zero_ptr[i] = t_zero_front_ptr[i]; fa.zero_bytes[i] = t_zero_front_bytes[i]; }
   t_nzero_front = 0;
-  const int rt = wide_rt(T, max_nr);
+  const int rt = wide_rt(T, max_nr, save);
   const bool one = rt >= 2 && g_opt_fused_one != 0;
+  if (one && want_tailw) {
+    // the per-sample tail's weights as hi / lo bf16 planes in fragment order: extra blocks of the KG rows' front launch
+    const size_t HH = (size_t)H * H;
+    const float* hsrc[4] = {P[CAMO_P_HEADS], P[CAMO_P_HEADS + 4], P[CAMO_P_HEADS + 8], P[CAMO_P_HEADS + 12]};
+    auto xj = [&](us* dst, int N, int K, const float* src, int lo) {
+      ShadowJob& J = fa.xjob[fa.nxjob++];
+      std::memset(&J, 0, sizeof(J));
+      J.dst = dst; J.N = N; J.K = K; J.nsrc = 1; J.src[0] = src; J.rows[0] = N; J.ld[0] = K; J.lo = lo;
+    };
+    (void)HH;
+    for (int lo = 0; lo < 2; ++lo) {
+      xj(w.f.tailw[0 + lo], H, 2 * H, P[CAMO_P_F1_W3], lo); xj(w.f.tailw[2 + lo], H, 2 * H, P[CAMO_P_F2_W3], lo);
+      xj(w.f.tailw[4 + lo], H, 2 * H, P[CAMO_P_FU_W0], lo); xj(w.f.tailw[6 + lo], H, H, P[CAMO_P_FU_W3], lo);
+    }
+    for (int lo = 0; lo < 2; ++lo) {      // the four heads' first layers [128 x 256] each, stacked
+      ShadowJob& J = fa.xjob[fa.nxjob++];
+      std::memset(&J, 0, sizeof(J));
+      J.dst = w.f.tailw[8 + lo]; J.N = 2 * H; J.K = H; J.nsrc = 4; J.lo = lo;
+      for (int x = 0; x < 4; ++x) { J.src[x] = hsrc[x]; J.rows[x] = H / 2; J.ld[x] = H; }
+    }
+  }
   if (rt) CK(launch_wide_front(fa, rt, st, one ? 1 : 0), one ? "fused forward, KG rows' front half (wide tiles)" : "fused forward, front half (wide tiles)");
   else CK(launch_fused_front(fa, g_opt_fused_variant, st), "fused forward, front half");
   BackArgs ba; std::memset(&ba, 0, sizeof(ba));
@@ -850,7 +881,19 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   if (!P[CAMO_P_KG_PROJ_W] && Dk != H) return fail(CAMO_E_ARG, "kg_proj weight missing but kg_dim != hidden_dim");
   const size_t HH2 = (size_t)H * H;
   if (use17) {
-    if (int e = forward_nodes17(d, P, rg, rg_offsets, bd, kg, B, T, Nk, max_nr, w, drop, save17, st)) return e;
+    const bool tailw = (flags & CAMO_FWD_INFERENCE) && !fl && !fl17 && tailw_taken(d, B, T, max_nr, save17);
+    if (int e = forward_nodes17(d, P, rg, rg_offsets, bd, kg, B, T, Nk, max_nr, w, drop, save17, st, tailw)) return e;
+    if (tailw) {
+      TailWideArgs ta; std::memset(&ta, 0, sizeof(ta));
+      ta.Ymean = w.Ymean; ta.H1mean = w.H1mean; ta.Y2mean = w.Y2mean; ta.H2mean = w.H2mean;
+      const us* const* tw = w.f.tailw;
+      ta.T13h = tw[0]; ta.T13l = tw[1]; ta.T23h = tw[2]; ta.T23l = tw[3]; ta.Tfu0h = tw[4]; ta.Tfu0l = tw[5]; ta.Tfu3h = tw[6]; ta.Tfu3l = tw[7]; ta.Th0h = tw[8]; ta.Th0l = tw[9];
+      ta.b13 = P[CAMO_P_F1_B3]; ta.b23 = P[CAMO_P_F2_B3]; ta.bfu0 = P[CAMO_P_FU_B0]; ta.bfu3 = P[CAMO_P_FU_B3];
+      for (int x = 0; x < 4; ++x) { ta.bh0[x] = P[CAMO_P_HEADS + 4 * x + 1]; ta.Wh3[x] = P[CAMO_P_HEADS + 4 * x + 2]; ta.bh3[x] = P[CAMO_P_HEADS + 4 * x + 3]; }
+      ta.outs = outs; ta.B = B; ta.C = d.num_classes; ta.drop = drop;
+      CK(launch_tail_wide(ta, st), "per-sample tail (wide, one launch)");
+      return 0;
+    }
   } else if (use16) {
     if (int e = forward_nodes16(d, P, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, w, attn_rg2kg, attn_kg2rg, drop, st)) return e;
   } else {
@@ -1228,6 +1271,7 @@ int camo_debug_set_option(const char* name, int32_t value) {
   if (std::strcmp(name, "fused_rt") == 0) { g_opt_fused_rt = value; return 0; }
   if (std::strcmp(name, "exp") == 0) { g_opt_exp = value; return 0; }
   if (std::strcmp(name, "fused_one") == 0) { g_opt_fused_one = value; return 0; }
+  if (std::strcmp(name, "tailw") == 0) { g_opt_tailw = value; return 0; }
   if (std::strcmp(name, "fused_variant") == 0) { g_opt_fused_variant = value; return 0; }
   if (std::strcmp(name, "tail17") == 0) { g_opt_tail17 = value; return 0; }
   if (std::strcmp(name, "back_lead") == 0) { g_back_lead_mode = value; return 0; }

@@ -26,7 +26,7 @@ def _opt(name, value):
 @pytest.fixture
 def fused_opts():
     yield _opt
-    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1); _opt("fused_rt", -1)
+    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1); _opt("fused_rt", -1); _opt("tailw", -1); _opt("fused_one", 1)
 
 
 def bf16_round(x):
@@ -336,3 +336,28 @@ def test_fused_training_step_shape_envelope(nrs, nk, pseed, fused_opts):
     print(f"nrs={nrs[:6]} nk={nk}: global relative gradient error fused {ea:.4f} (worst {wa[1]} {wa[0]:.3f}) | gemm-per-layer {eb:.4f} (worst {wb[1]} {wb[0]:.3f})")
     assert ea < max(5e-2, 1.5 * eb), (ea, eb)
     assert wa[0] < max(0.12, 2.0 * wb[0]), (wa, wb)
+
+
+@pytest.mark.parametrize("B,ncls", [(1, 2), (17, 2), (32, 2), (33, 3), (100, 2)])
+def test_wide_tail_matches_separate_launches(B, ncls, kg_real, fused_opts):
+    """The per-sample tail of wide-tile inference calls as ONE launch (csrc/tail_wide.hip: 32 samples per block, two-plane bf16
+    operands, three MFMA products per term) against the five fp32 GEMM launches it replaces, on the same node-level kernels, and
+    against the oracle.  The two tails differ by the dropped x_lo * W_lo term (2^-18 relative) and summation order."""
+    cfg = OP.full_cfg(dict(num_classes=ncls))
+    m = make_model(cfg, 5, "bf16").eval()
+    eng = m._engine
+    rs = np.random.RandomState(B)
+    nrs = [int(x) for x in rs.randint(1, 200, size=B)]
+    rg = [OP.make_rg(n, 128, seed=500 + i) for i, n in enumerate(nrs)]
+    kg = np.stack([kg_real * (1.0 + 0.01 * (i % 7)) for i in range(B)]).astype(np.float32)
+    batch = eng.make_batch(torch.from_numpy(np.concatenate(rg)).cuda(), nrs, torch.from_numpy(kg).cuda())
+    fused_opts("fused_rt", 4)
+    res = []
+    for mode in (-1, 0):
+        fused_opts("tailw", mode)
+        o, _ = eng.forward_raw(batch, eng.workspace(batch, private=True), False, 7, inference=True, cache_shadows=False)
+        res.append(t2n(o))
+    assert np.isfinite(res[0]).all()
+    assert_close(res[0], res[1], 2e-5, 1e-5, "one-launch wide tail vs five launches")
+    ref, _ = FO.FusionOracle(cfg, OP.make_params(cfg, 5)).forward_list(rg, kg)
+    assert_close(res[0], outs6(ref), 1e-3, 0, "wide tail vs oracle")
