@@ -138,9 +138,15 @@ def require_device(t, name):
                         "fallback (move the model and its inputs to 'cuda').")
 
 
-def tail_timeouts():
-    """Number of arrival waits of the one-launch tail kernel that gave up since the library was loaded (synchronous; see
-    camo_tail_timeouts in include/camo_fusion.h).  Anything but 0 means a training step produced wrong results."""
+def tail_timeouts(device=None):
+    """Number of arrival waits of the one-launch tail kernel that gave up on ``device`` (default: the current HIP device) since the
+    library was loaded (synchronous; see camo_tail_timeouts in include/camo_fusion.h).  A step that hit one is not applied: its
+    loss terms are NaN and the optimizer kernels skip an update whose gradient norm is not finite."""
     n = C.c_uint32(0)
-    check(lib().camo_tail_timeouts(C.byref(n)), "camo_tail_timeouts")
+    if device is not None:
+        import torch
+        with torch.cuda.device(device):
+            check(lib().camo_tail_timeouts(C.byref(n)), "camo_tail_timeouts")
+    else:
+        check(lib().camo_tail_timeouts(C.byref(n)), "camo_tail_timeouts")
     return int(n.value)

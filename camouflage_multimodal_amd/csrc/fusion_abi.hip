@@ -960,6 +960,11 @@ int camo_forward_cached(const camo_dims_t* dims, const float* const* params, con
                         void* stream) {
   if (shadows_state) *shadows_state = 0;
   if (shadows_valid && !shadows) return fail(CAMO_E_ARG, "shadows_valid without a shadow buffer");
+  // A call that saves for camo_backward would leave the backward's transposed shadows in the caller's buffer, where camo_backward
+  // (which takes no shadow argument) cannot find them, and its deferred clears in thread-local state that any other forward call
+  // drops: the training pair is camo_forward_loss_backward, which owns both halves.
+  if (shadows && !(flags & CAMO_FWD_INFERENCE))
+    return fail(CAMO_E_UNSUPPORTED, "camo_forward_cached with a shadow buffer serves inference calls only (flags must contain CAMO_FWD_INFERENCE)");
   if (shadows && (reinterpret_cast<uintptr_t>(shadows) & 255)) return fail(CAMO_E_ARG, "the shadow buffer must be 256-byte aligned");
   t_shadows = shadows; t_shadows_valid = shadows && shadows_valid != 0; t_shadows_state = 0;
   const int rc = forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
@@ -1272,6 +1277,7 @@ int camo_debug_set_option(const char* name, int32_t value) {
   if (std::strcmp(name, "exp") == 0) { g_opt_exp = value; return 0; }
   if (std::strcmp(name, "fused_one") == 0) { g_opt_fused_one = value; return 0; }
   if (std::strcmp(name, "tailw") == 0) { g_opt_tailw = value; return 0; }
+  if (std::strcmp(name, "tail_skip_arrival") == 0) { g_tail_debug_skip = value; return 0; }
   if (std::strcmp(name, "fused_variant") == 0) { g_opt_fused_variant = value; return 0; }
   if (std::strcmp(name, "tail17") == 0) { g_opt_tail17 = value; return 0; }
   if (std::strcmp(name, "back_lead") == 0) { g_back_lead_mode = value; return 0; }

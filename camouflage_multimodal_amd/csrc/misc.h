@@ -58,7 +58,9 @@ struct TailFusedArgs {
   float *dcomb, *dHm1, *dHm2;                               // mode 1 out: d(mean Z) [B][512]; d(mean H) [B][512] x 2, ZEROED (accumulated with atomics)
   int B, C, mode; DropCfg drop;
   unsigned long long* stamps;                               // developer timeline (null in product calls)
+  int debug_skip;                                           // (launcher) developer hook: block id + 1 that skips its first arrival
 };
+extern int g_tail_debug_skip;
 int tail_fused_ok(int B, int C);
 int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream);
 int tail_timeouts(unsigned int* out);

@@ -533,17 +533,24 @@ __device__ unsigned int g_tail_timeouts = 0;
 __device__ __forceinline__ void tstamp(unsigned long long* stamps, int k) {
   if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 32 + k] = __builtin_amdgcn_s_memrealtime();
 }
-__device__ __forceinline__ void tail_arrive_wait(unsigned int* counter, unsigned int* timeout) {
+// A wait that gives up must not become a parameter update: besides raising the call's flag and the sticky counter it sets
+// g_tail_poison, which the step's norm launch (sumsq_kernel, next on the stream) turns into a NaN gradient norm -- and the optimizer
+// kernels skip a step whose norm is not finite (clip_adamw_kernel / adamw_shadow_kernel).  The block that writes the outputs and
+// the loss terms writes NaN there when its own wait gave up (lds_flag), so the caller sees the step in band as well.
+__device__ unsigned int g_tail_poison = 0;      // set by a wait that gave up, consumed by the next sumsq_kernel (same stream: the step's norm launch)
+__device__ __forceinline__ void tail_arrive_wait(unsigned int* counter, unsigned int* timeout, int* lds_flag, bool skip_arrival = false) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's atomics are acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!skip_arrival) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned int spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)TG) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > (1u << 21)) {
         __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicAdd(&g_tail_timeouts, 1u);
+        __hip_atomic_store(&g_tail_poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *lds_flag = 1;
         break;
       }
     }
@@ -574,6 +581,8 @@ constexpr int TF_THREADS = 1024;
 
 __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ int s_timed_out;                                // a wait of this block gave up (tail_arrive_wait)
+  if (threadIdx.x == 0) s_timed_out = 0;                     // (ordered before its first use by the barriers of the first wait)
   const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x, B = a.B, C = a.C, Wd = 2 * C + 2;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 8), t = tid & 255, wv = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
   const int b0 = 4 * q, B4 = (B + 3) & ~3;
@@ -704,7 +713,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
     }
   }
   tstamp(a.stamps, 3);
-  tail_arrive_wait(a.counters + 0, a.counters + 3);
+  tail_arrive_wait(a.counters + 0, a.counters + 3, &s_timed_out, a.debug_skip == (int)blockIdx.x + 1);
   tstamp(a.stamps, 4);
   {
     const float4 v4 = tid < B * 64 ? reinterpret_cast<const float4*>(a.F1sum)[tid] : z4;
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
     }
   }
   tstamp(a.stamps, 7);
-  tail_arrive_wait(a.counters + 1, a.counters + 3);
+  tail_arrive_wait(a.counters + 1, a.counters + 3, &s_timed_out);
   tstamp(a.stamps, 8);
   {
     float4 v4[2];
@@ -793,7 +802,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
     if (x == 3) acc = 1.0f / (1.0f + __expf(-acc));
     if (kq == 0) {
       outsS[b * TF_MAXW + o] = acc;
-      if (g == 0) a.outs[p] = acc;
+      if (g == 0) a.outs[p] = s_timed_out ? __uint_as_float(0x7FC00000u) : acc;
     }
   }
   __syncthreads();
@@ -803,6 +812,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
     float t4[4]; int pr = 0;
     loss_sample<true>(outsS + tid * TF_MAXW, (int)a.y[tid], a.e[tid], a.s[tid], C, t4, nullptr, dpre + tid * TF_MAXW, &pr);
     if (g == 0) {
+      if (s_timed_out) t4[0] = t4[1] = t4[2] = t4[3] = __uint_as_float(0x7FC00000u);
       a.terms[4 * tid] = t4[0]; a.terms[4 * tid + 1] = t4[1]; a.terms[4 * tid + 2] = t4[2]; a.terms[4 * tid + 3] = t4[3];
       if (a.pred) a.pred[tid] = pr;
     }
@@ -909,7 +919,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
     }
   }
   tstamp(a.stamps, 15);
-  tail_arrive_wait(a.counters + 2, a.counters + 3);
+  tail_arrive_wait(a.counters + 2, a.counters + 3, &s_timed_out);
   tstamp(a.stamps, 16);
   {
     const float4 v4 = tid < B * 64 ? reinterpret_cast<const float4*>(a.dF1sum)[tid] : z4;
@@ -1017,7 +1027,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) out[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    // a one-launch tail whose wait gave up earlier on this stream (tail_arrive_wait): the step's norm becomes NaN, the optimizer skips it
+    if (blockIdx.x == 0 && atomicExch(&g_tail_poison, 0u) != 0u) tot = __uint_as_float(0x7FC00000u);
+    out[1 + blockIdx.x] = tot;
+  }
 }
 
 // clip_grad_norm_(max_norm) then AdamW (torch semantics: decoupled decay first,
@@ -1036,6 +1051,9 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
   const float total = (red[0] + red[1]) + (red[2] + red[3]);
   if (blockIdx.x == 0 && threadIdx.x == 0) sumsq[0] = total;
   const float coef = fminf(1.0f, max_norm / (sqrtf(total) + 1e-6f));
+  // A gradient norm that is not finite (a tail-kernel wait that gave up poisons it: tail_arrive_wait) makes this a no-op step:
+  // parameters and moments stay, the gradients are cleared as usual.  (torch would write NaN into every parameter.)
+  const bool skip_step = !(total < __builtin_huge_valf());
   const float decay = 1.0f - lr * wd, step = lr * inv_bc1, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   const size_t stride = (size_t)gridDim.x * 256;
   const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
@@ -1044,6 +1062,7 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
   float4* p4 = reinterpret_cast<float4*>(p); float4* g4 = reinterpret_cast<float4*>(g);
   float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
   auto upd = [&](float& pi, float& gi, float& mi, float& vi) {
+    if (skip_step) { if (zero_grads) gi = 0.f; return; }
     gi *= coef;
     pi *= decay;
     mi = mi * b1 + gi * omb1;
@@ -1202,6 +1221,10 @@ int launch_heads_loss(const float* hid, const HeadsOut& hp, const long long* y, 
   return (int)hipGetLastError();
 }
 
+// developer hook (camo_debug_set_option "tail_skip_arrival" = block id + 1): that block of the NEXT one-launch tail skips its first
+// arrival, so the others' wait times out deterministically -- the only way to test the give-up path without sharing the GPU
+int g_tail_debug_skip = 0;
+
 int tail_fused_ok(int B, int C) {
   // every block of the launch waits for the other 63: all of them must be resident at once, one per CU (1024 threads, 148 KB of
   // LDS), so the device (or the partition this process sees) must have at least that many CUs
@@ -1215,8 +1238,10 @@ int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream) {
     return true;
   }();
   (void)attr;
+  TailFusedArgs aa = a;
+  aa.debug_skip = g_tail_debug_skip; g_tail_debug_skip = 0;
   const int prof = gemm_prof_open(stream, 0.0, PROF_TAIL);
-  hipLaunchKernelGGL(tail_fused_kernel, dim3(TG), dim3(TF_THREADS), TF_LDS_FLOATS * 4, stream, a);
+  hipLaunchKernelGGL(tail_fused_kernel, dim3(TG), dim3(TF_THREADS), TF_LDS_FLOATS * 4, stream, aa);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
@@ -1278,8 +1303,12 @@ __global__ __launch_bounds__(256) void adamw_shadow_kernel(float* __restrict__ p
   const float total = (red[0] + red[1]) + (red[2] + red[3]);
   if (blockIdx.x == 0 && tid == 0) sumsq[0] = total;
   const float coef = fminf(1.0f, max_norm / (sqrtf(total) + 1e-6f));
+  // A gradient norm that is not finite (a tail-kernel wait that gave up poisons it: tail_arrive_wait) makes this a no-op step:
+  // parameters and moments stay, the gradients are cleared as usual.  (torch would write NaN into every parameter.)
+  const bool skip_step = !(total < __builtin_huge_valf());
   const float decay = 1.0f - lr * wd, step = lr * inv_bc1, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   auto upd = [&](float& pi, float& gi, float& mi, float& vi) {
+    if (skip_step) { if (zero_grads) gi = 0.f; return; }
     gi *= coef;
     pi *= decay;
     mi = mi * b1 + gi * omb1;

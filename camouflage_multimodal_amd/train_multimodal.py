@@ -288,7 +288,7 @@ def fit(config, train_loader, val_loader, device="cuda", grad_allreduce=None, lo
         loader = train_loader(epoch) if callable(train_loader) else train_loader
         tl, tf1 = train_epoch_fixed(model, loader, trainer, device, epoch + 1)
         vl, vf1, a0, a1 = validate_fixed(model, val_loader, device)
-        if _lib.tail_timeouts():
+        if _lib.tail_timeouts(device):
             raise _lib.CamoError("the one-launch tail kernel timed out waiting for its own blocks (GPU shared with another process?): "
                                  "this epoch's results are invalid")
         trainer.opt.set_epoch(epoch + 1)                     # scheduler.step() [:439]: a checkpoint carries the NEXT epoch's lr

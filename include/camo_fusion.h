@@ -129,8 +129,10 @@ int camo_forward(const camo_dims_t* dims, const float* const* params,
  * that nothing wrote them since the call that reported the buffer filled -- skips the shadow launch (3 launches instead of 4
  * per inference call).  *shadows_state (may be null) reports what the buffer holds after the call: 0 = untouched (the call
  * took a schedule without shadows: Nk > 16, attention maps, f32 ...; a promise is then simply not used), 1 = the forward
- * shadows (an inference call built them, or used valid ones), 2 = forward and transposed shadows (a call that saves for
- * camo_backward built them: everything camo_forward_loss_backward(shadows_valid = 1) needs).  shadows == NULL: camo_forward. */
+ * shadows (an inference call built them, or used valid ones); 2 is reported by camo_forward_loss_backward only (forward and
+ * transposed shadows).  With a shadow buffer the call must be an inference call (flags contain CAMO_FWD_INFERENCE), else
+ * CAMO_E_UNSUPPORTED: camo_backward takes no shadow argument, so a saving call's transposed shadows would be out of its reach --
+ * the training pair is camo_forward_loss_backward.  shadows == NULL: camo_forward. */
 int camo_forward_cached(const camo_dims_t* dims, const float* const* params,
                         const float* rg, const int32_t* rg_offsets, const void* batch_desc,
                         const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr,

@@ -29,6 +29,14 @@ SITE_HEAD0 = 6  # +0 mask, +1 instance, +2 edge, +3 score
 SITE_LATE0 = 10  # +0, +1: the two hidden layers of LateFusion
 
 
+def bf16_round(x):
+    """float32 -> bfloat16 -> float32, round to nearest even (what v_cvt_pk_bf16_f32 / a cast to __bf16 does)."""
+    x = np.ascontiguousarray(x, dtype=f32)
+    u = x.view(np.uint32).astype(np.uint64)
+    u = (u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) >> np.uint64(16)
+    return (u.astype(np.uint32) << np.uint32(16)).view(f32).reshape(x.shape)
+
+
 def _fmix32(x):
     x = x.astype(np.uint64)
     x ^= x >> np.uint64(16)
@@ -109,9 +117,36 @@ def collapse_inputs(rg, kg):
 class FusionOracle:
     """MultimodalCamouflageDetector (fusion_model.py:174-246) in numpy."""
 
-    def __init__(self, cfg, params):
+    def __init__(self, cfg, params, bf16_operands=False):
+        """``bf16_operands``: restate the bf16 mode of the HIP path instead of the reference's fp32 arithmetic -- every tensor the
+        fused kernels hand to an MFMA as a bf16 operand (inputs, node-level weights, R / G, the pre-scaled
+        queries, keys, values, attention probabilities, attention outputs, LayerNorm outputs; in backward the FFN gradient rows,
+        dU, dO, dS, the dropped probabilities, dQ / dK / dV, dR / dG and the saved normalised LayerNorm input) is rounded to
+        bf16 where the kernels round it; sums stay fp32, the per-sample tail stays fp32.  The f32 mode is the one pinned to the
+        reference's golden vectors; this mode differs from it only through ``self.q`` (identity when off)."""
         self.cfg = full_cfg(cfg)
         self.p = {k: np.asarray(v, dtype=f32) for k, v in params.items()}
+        self.bf16 = bool(bf16_operands)
+        self.q = bf16_round if self.bf16 else (lambda x: x)
+        # Per-sample tail units (fusion layer 0, the heads' hidden layers) whose pre-activation sits within ``near_eps`` of the ReLU
+        # threshold are recorded in ``near`` as (site, sample, unit, value) when it is a list: an implementation that sums in
+        # another order may land on the other side of zero there, and ONE such unit moves a head's gradient by percent.
+        # ``relu_flip``: set of (site, sample, unit) whose ReLU decision is inverted -- tests enumerate the admissible sign
+        # patterns of the recorded units instead of picking inputs that happen to have none (tests/helpers.py).
+        self.kg_block = 64                  # keys per flash block of the KG->RG attention in the fused 32-row kernels (bf16 mode only)
+        self.near = None
+        self.near_eps = 2e-4
+        self.relu_flip = frozenset()
+
+    def _relu_tail(self, x, site, b_index):
+        pos = x > 0
+        if self.near is not None:
+            for u in np.nonzero(np.abs(x[0]) < self.near_eps)[0]:
+                self.near.append((site, b_index, int(u), float(x[0, u])))
+        for (s_, b_, u) in self.relu_flip:
+            if s_ == site and b_ == b_index:
+                pos[0, u] = not pos[0, u]
+        return np.where(pos, x, f32(0)), pos
         if self.cfg["fusion_type"] not in ("cross_attention", "late"):
             raise ValueError(f"Unknown fusion_type: {self.cfg['fusion_type']}")
 
@@ -133,40 +168,68 @@ class FusionOracle:
             kg_row_base = b_index * Nk
         scale = f32(1.0 / np.sqrt(dh))
         ca = {}
-        # fusion_model.py:108-109
-        R = _linear(rg, P["fusion.rg_proj.weight"], P["fusion.rg_proj.bias"]) if "fusion.rg_proj.weight" in P else rg
-        G = _linear(kg, P["fusion.kg_proj.weight"], P["fusion.kg_proj.bias"]) if "fusion.kg_proj.weight" in P else kg
-        # fusion_model.py:112-118 -- MHA, query=rg, key=value=kg
-        Wi, bi = P["fusion.cross_attn_rg2kg.in_proj_weight"], P["fusion.cross_attn_rg2kg.in_proj_bias"]
-        Q = _linear(R, Wi[:H], bi[:H]); Kk = _linear(G, Wi[H:2 * H], bi[H:2 * H]); Vk = _linear(G, Wi[2 * H:], bi[2 * H:])
-        Qh = Q.reshape(Nr, nh, dh); Kh = Kk.reshape(Nk, nh, dh); Vh = Vk.reshape(Nk, nh, dh)
-        S = np.einsum("thd,jhd->thj", Qh, Kh).astype(f32) * scale            # [Nr, nh, Nk]
+        q = self.q                          # (bf16 mode: operand rounding; identity in the pinned f32 mode)
+        W = (lambda name: q(P[name]))      # node-level weights are MFMA operands
+        rg, kg = q(rg), q(kg)
+        # fusion_model.py:108-109  (bf16 mode: R / G exist only as bf16 -- operand of the in-projections AND the residual)
+        R = q(_linear(rg, W("fusion.rg_proj.weight"), P["fusion.rg_proj.bias"])) if "fusion.rg_proj.weight" in P else rg
+        G = q(_linear(kg, W("fusion.kg_proj.weight"), P["fusion.kg_proj.bias"])) if "fusion.kg_proj.weight" in P else kg
+        # fusion_model.py:112-118 -- MHA, query=rg, key=value=kg.  (bf16 mode: the queries are scaled BEFORE they are rounded,
+        # as the kernels store them; Q here stays the unscaled fp32 value of the reference, Qs is what the scores see)
+        Wi, bi = W("fusion.cross_attn_rg2kg.in_proj_weight"), P["fusion.cross_attn_rg2kg.in_proj_bias"]
+        Q = _linear(R, Wi[:H], bi[:H]); Kk = q(_linear(G, Wi[H:2 * H], bi[H:2 * H])); Vk = q(_linear(G, Wi[2 * H:], bi[2 * H:]))
+        Qs = q(Q * scale)
+        Qh = Qs.reshape(Nr, nh, dh); Kh = Kk.reshape(Nk, nh, dh); Vh = Vk.reshape(Nk, nh, dh)
+        S = np.einsum("thd,jhd->thj", Qh, Kh).astype(f32)                     # [Nr, nh, Nk]
+        if not self.bf16:                                                     # (the pinned mode keeps the reference's order: scale after the product)
+            S = np.einsum("thd,jhd->thj", Q.reshape(Nr, nh, dh), Kh).astype(f32) * scale
         Pm = _softmax(S, axis=2)
         Pd, m_a1 = _drop(Pm, seed, SITE_ATTN_RG2KG, row_base * nh * Nk, pd, training)
-        O = np.einsum("thj,jhd->thd", Pd, Vh).astype(f32).reshape(Nr, H)
-        A = _linear(O, P["fusion.cross_attn_rg2kg.out_proj.weight"], P["fusion.cross_attn_rg2kg.out_proj.bias"])
-        # fusion_model.py:119-120
+        O = q(np.einsum("thj,jhd->thd", q(Pd), Vh).astype(f32).reshape(Nr, H))
+        A = _linear(O, W("fusion.cross_attn_rg2kg.out_proj.weight"), P["fusion.cross_attn_rg2kg.out_proj.bias"])
+        # fusion_model.py:119-120  (the mean pool of Z uses the fp32 LayerNorm output; the first FFN layer its bf16 copy)
         Y, xh1, rstd1 = _layernorm(R + A, P["fusion.ln_rg.weight"], P["fusion.ln_rg.bias"])
-        H1 = np.maximum(_linear(Y, P["fusion.ffn_rg.0.weight"], P["fusion.ffn_rg.0.bias"]), 0)
+        H1 = np.maximum(_linear(q(Y), W("fusion.ffn_rg.0.weight"), P["fusion.ffn_rg.0.bias"]), 0)
         H1d, m_f1 = _drop(H1, seed, SITE_FFN_RG, row_base * 2 * H, pd, training)
         Z = Y + _linear(H1d, P["fusion.ffn_rg.3.weight"], P["fusion.ffn_rg.3.bias"])
         # fusion_model.py:123-129 -- MHA, query=kg, key=value=rg_proj
-        Wi2, bi2 = P["fusion.cross_attn_kg2rg.in_proj_weight"], P["fusion.cross_attn_kg2rg.in_proj_bias"]
-        Q2 = _linear(G, Wi2[:H], bi2[:H]); K2 = _linear(R, Wi2[H:2 * H], bi2[H:2 * H]); V2 = _linear(R, Wi2[2 * H:], bi2[2 * H:])
-        Q2h = Q2.reshape(Nk, nh, dh); K2h = K2.reshape(Nr, nh, dh); V2h = V2.reshape(Nr, nh, dh)
-        S2 = np.einsum("jhd,thd->thj", Q2h, K2h).astype(f32) * scale          # stored [Nr, nh, Nk]
+        Wi2, bi2 = W("fusion.cross_attn_kg2rg.in_proj_weight"), P["fusion.cross_attn_kg2rg.in_proj_bias"]
+        Q2 = _linear(G, Wi2[:H], bi2[:H]); K2 = q(_linear(R, Wi2[H:2 * H], bi2[H:2 * H])); V2 = q(_linear(R, Wi2[2 * H:], bi2[2 * H:]))
+        Q2s = q(Q2 * scale)
+        Q2h = Q2s.reshape(Nk, nh, dh); K2h = K2.reshape(Nr, nh, dh); V2h = V2.reshape(Nr, nh, dh)
+        S2 = np.einsum("jhd,thd->thj", Q2h, K2h).astype(f32)                  # stored [Nr, nh, Nk]
+        if not self.bf16:
+            S2 = np.einsum("jhd,thd->thj", Q2.reshape(Nk, nh, dh), K2h).astype(f32) * scale
         P2 = _softmax(S2, axis=0)                                             # softmax over keys t
         P2d, m_a2 = _drop(P2, seed, SITE_ATTN_KG2RG, row_base * nh * Nk, pd, training)
-        O2 = np.einsum("thj,thd->jhd", P2d, V2h).astype(f32).reshape(Nk, H)
-        A2 = _linear(O2, P["fusion.cross_attn_kg2rg.out_proj.weight"], P["fusion.cross_attn_kg2rg.out_proj.bias"])
+        if self.bf16:
+            # the kernels run this direction flash-style over blocks of ``kg_block`` keys: exponentials relative to the BLOCK's
+            # maximum, dropped, rounded to bf16 for the value product; the blocks' fp32 partial sums {max, sum, Z} are combined
+            # afterwards.  (Rounding the normalised probabilities instead has the same relative error but not the same bits, and
+            # the 13 KG rows of a sample are few enough for that to show in their FFN's ReLU decisions.)
+            kb = int(self.kg_block)
+            M = S2.max(axis=0)                                                # [nh, Nk]
+            num = np.zeros((Nk, nh, dh), f32); den = np.zeros((nh, Nk), f32)
+            for t0 in range(0, Nr, kb):
+                sl = slice(t0, min(Nr, t0 + kb))
+                mb = S2[sl].max(axis=0)
+                eb = np.exp(S2[sl] - mb).astype(f32)
+                ed = eb if m_a2 is None else eb * m_a2[sl]
+                zb = np.einsum("thj,thd->jhd", q(ed), V2h[sl]).astype(f32)
+                w = np.exp(mb - M).astype(f32)                                # [nh, Nk]
+                num += zb * w.T[:, :, None]; den += eb.sum(axis=0, dtype=f32) * w
+            O2 = q((num / den.T[:, :, None]).astype(f32).reshape(Nk, H))
+        else:
+            O2 = np.einsum("thj,thd->jhd", P2d, V2h).astype(f32).reshape(Nk, H)
+        A2 = _linear(O2, W("fusion.cross_attn_kg2rg.out_proj.weight"), P["fusion.cross_attn_kg2rg.out_proj.bias"])
         # fusion_model.py:130-131
         Y2, xh2, rstd2 = _layernorm(G + A2, P["fusion.ln_kg.weight"], P["fusion.ln_kg.bias"])
-        H2 = np.maximum(_linear(Y2, P["fusion.ffn_kg.0.weight"], P["fusion.ffn_kg.0.bias"]), 0)
+        H2 = np.maximum(_linear(q(Y2), W("fusion.ffn_kg.0.weight"), P["fusion.ffn_kg.0.bias"]), 0)
         H2d, m_f2 = _drop(H2, seed, SITE_FFN_KG, kg_row_base * 2 * H, pd, training)
         Zk = Y2 + _linear(H2d, P["fusion.ffn_kg.3.weight"], P["fusion.ffn_kg.3.bias"])
         # fusion_model.py:134-139
         comb = np.concatenate([Z.mean(axis=0, dtype=f32), Zk.mean(axis=0, dtype=f32)])[None, :]
-        F1 = np.maximum(_linear(comb, P["fusion.fusion_layer.0.weight"], P["fusion.fusion_layer.0.bias"]), 0)
+        F1, F1pos = self._relu_tail(_linear(comb, P["fusion.fusion_layer.0.weight"], P["fusion.fusion_layer.0.bias"]), SITE_FUSE, b_index)
         F1d, m_fu = _drop(F1, seed, SITE_FUSE, b_index * H, pd, training)
         fused = _linear(F1d, P["fusion.fusion_layer.3.weight"], P["fusion.fusion_layer.3.bias"])
         outs, hc = self._heads(fused, training, seed, b_index)
@@ -174,9 +237,9 @@ class FusionOracle:
         # torch's MHA does with need_weights=True, average_attn_weights=True
         outs["attn_rg2kg"] = Pd.mean(axis=1, dtype=f32)            # [Nr, Nk]
         outs["attn_kg2rg"] = P2d.mean(axis=1, dtype=f32).T.copy()  # [Nk, Nr]
-        ca.update(rg=rg, kg=kg, R=R, G=G, Q=Q, Kk=Kk, Vk=Vk, Pm=Pm, Pd=Pd, m_a1=m_a1, O=O, xh1=xh1, rstd1=rstd1,
+        ca.update(rg=rg, kg=kg, R=R, G=G, Q=Q, Qs=Qs, Q2s=Q2s, Kk=Kk, Vk=Vk, Pm=Pm, Pd=Pd, m_a1=m_a1, O=O, xh1=xh1, rstd1=rstd1,
                   Y=Y, H1=H1, H1d=H1d, m_f1=m_f1, Q2=Q2, K2=K2, V2=V2, P2=P2, P2d=P2d, m_a2=m_a2, O2=O2,
-                  xh2=xh2, rstd2=rstd2, Y2=Y2, H2=H2, H2d=H2d, m_f2=m_f2, comb=comb, F1=F1, F1d=F1d, m_fu=m_fu,
+                  xh2=xh2, rstd2=rstd2, Y2=Y2, H2=H2, H2d=H2d, m_f2=m_f2, comb=comb, F1=F1, F1pos=F1pos, F1d=F1d, m_fu=m_fu,
                   fused=fused, heads=hc, Nr=Nr, Nk=Nk)
         return outs, ca
 
@@ -187,13 +250,13 @@ class FusionOracle:
         outs, hc = {}, {}
         for i, (hn, on) in enumerate((("mask_head", "mask"), ("instance_head", "instance"),
                                       ("edge_head", "edge"), ("score_head", "score"))):
-            h = np.maximum(_linear(fused, P[f"{hn}.0.weight"], P[f"{hn}.0.bias"]), 0)
+            h, hpos = self._relu_tail(_linear(fused, P[f"{hn}.0.weight"], P[f"{hn}.0.bias"]), SITE_HEAD0 + i, b_index)
             hd, m = _drop(h, seed, SITE_HEAD0 + i, b_index * (F // 2), pd, training)
             o = _linear(hd, P[f"{hn}.3.weight"], P[f"{hn}.3.bias"])
             if on == "score":
                 o = _sigmoid(o)
             outs[on] = o[0]
-            hc[hn] = (h, hd, m)
+            hc[hn] = (h, hd, m, hpos)
         return outs, hc
 
     def _forward_late(self, rg, kg, training, seed, b_index):
@@ -235,7 +298,7 @@ class FusionOracle:
         fused = ca["fused"]
         dfused = np.zeros_like(fused)
         for hn, on in (("mask_head", "mask"), ("instance_head", "instance"), ("edge_head", "edge"), ("score_head", "score")):
-            h, hd, m = ca["heads"][hn]
+            h, hd, m, hpos = ca["heads"][hn]
             do = np.asarray(d[on], f32).reshape(1, -1)
             if on == "score":
                 o = _sigmoid(_linear(hd, P[f"{hn}.3.weight"], P[f"{hn}.3.bias"]))
@@ -244,7 +307,7 @@ class FusionOracle:
             dh = do @ P[f"{hn}.3.weight"]
             if m is not None:
                 dh = dh * m
-            dh = dh * (h > 0)
+            dh = dh * hpos
             _acc(g, f"{hn}.0.weight", dh.T @ fused); _acc(g, f"{hn}.0.bias", dh.sum(0))
             dfused = dfused + dh @ P[f"{hn}.0.weight"]
         return dfused
@@ -276,59 +339,70 @@ class FusionOracle:
         dF1 = dfused @ P["fusion.fusion_layer.3.weight"]
         if ca["m_fu"] is not None:
             dF1 = dF1 * ca["m_fu"]
-        dF1 = dF1 * (ca["F1"] > 0)
+        dF1 = dF1 * ca["F1pos"]
         _acc(g, "fusion.fusion_layer.0.weight", dF1.T @ ca["comb"]); _acc(g, "fusion.fusion_layer.0.bias", dF1.sum(0))
         dcomb = dF1 @ P["fusion.fusion_layer.0.weight"]
+        if dbg is not None:
+            dbg["dcomb"] = dcomb
         dZ = np.repeat(dcomb[:, :H] / f32(Nr), Nr, axis=0)
         dZk = np.repeat(dcomb[:, H:] / f32(Nk), Nk, axis=0)
 
+        q = self.q
+        W = (lambda name: q(P[name]))
+
         def ffn_ln_bwd(dZ_, pre, Y_, H_, Hd_, m_, xh_, rstd_, ln):
             _acc(g, f"fusion.{pre}.3.weight", dZ_.T @ Hd_); _acc(g, f"fusion.{pre}.3.bias", dZ_.sum(0))
-            dH = dZ_ @ P[f"fusion.{pre}.3.weight"]
-            if m_ is not None:
-                dH = dH * m_
-            dH = dH * (H_ > 0)
+            # (bf16 mode: the per-sample gradient row is rounded, then masked: the kernels' dH operand)
+            dH = q(dZ_ @ P[f"fusion.{pre}.3.weight"] * (f32(1.0) if m_ is None else f32(m_.max() if m_.size else 1.0)))
+            dH = dH * (H_ > 0) if m_ is None else dH * (m_ > 0) * (H_ > 0)
             if dbg is not None:
                 dbg["dH_" + pre] = dH
-            _acc(g, f"fusion.{pre}.0.weight", dH.T @ Y_); _acc(g, f"fusion.{pre}.0.bias", dH.sum(0))
-            dY = dZ_ + dH @ P[f"fusion.{pre}.0.weight"]
-            dU, dgam, dbet = _layernorm_bwd(dY, xh_, rstd_, P[f"fusion.{ln}.weight"])
+            _acc(g, f"fusion.{pre}.0.weight", dH.T @ q(Y_)); _acc(g, f"fusion.{pre}.0.bias", dH.sum(0))
+            dY = dZ_ + dH @ W(f"fusion.{pre}.0.weight")
+            dU, dgam, dbet = _layernorm_bwd(dY, q(xh_), rstd_, P[f"fusion.{ln}.weight"])
             _acc(g, f"fusion.{ln}.weight", dgam); _acc(g, f"fusion.{ln}.bias", dbet)
-            return dU
+            return q(dU)
 
         dU = ffn_ln_bwd(dZ, "ffn_rg", ca["Y"], ca["H1"], ca["H1d"], ca["m_f1"], ca["xh1"], ca["rstd1"], "ln_rg")
         dU2 = ffn_ln_bwd(dZk, "ffn_kg", ca["Y2"], ca["H2"], ca["H2d"], ca["m_f2"], ca["xh2"], ca["rstd2"], "ln_kg")
         dR = dU.copy(); dG = dU2.copy()
-        # --- rg2kg attention
+        # --- rg2kg attention  (scores were taken with the pre-scaled queries Qs = q(Q * scale): dK = dS^T Qs, dQ = scale * dS K)
         a = "fusion.cross_attn_rg2kg"
         _acc(g, f"{a}.out_proj.weight", dU.T @ ca["O"]); _acc(g, f"{a}.out_proj.bias", dU.sum(0))
-        dO = (dU @ P[f"{a}.out_proj.weight"]).reshape(Nr, nh, dh_)
-        Vh = ca["Vk"].reshape(Nk, nh, dh_); Kh = ca["Kk"].reshape(Nk, nh, dh_); Qh = ca["Q"].reshape(Nr, nh, dh_)
+        dO = q(dU @ W(f"{a}.out_proj.weight")).reshape(Nr, nh, dh_)
+        Vh = ca["Vk"].reshape(Nk, nh, dh_); Kh = ca["Kk"].reshape(Nk, nh, dh_); Qsh = ca["Qs"].reshape(Nr, nh, dh_)
         dPd = np.einsum("thd,jhd->thj", dO, Vh).astype(f32)
-        dVk = np.einsum("thj,thd->jhd", ca["Pd"], dO).astype(f32).reshape(Nk, H)
+        dVk = np.einsum("thj,thd->jhd", q(ca["Pd"]), dO).astype(f32).reshape(Nk, H)
         dP = dPd if ca["m_a1"] is None else dPd * ca["m_a1"]
-        dS = ca["Pm"] * (dP - (ca["Pm"] * dP).sum(axis=2, keepdims=True, dtype=f32))
-        dQ = (np.einsum("thj,jhd->thd", dS, Kh).astype(f32) * scale).reshape(Nr, H)
-        dKk = (np.einsum("thj,thd->jhd", dS, Qh).astype(f32) * scale).reshape(Nk, H)
-        Wi = P[f"{a}.in_proj_weight"]
+        dS = q(ca["Pm"] * (dP - (ca["Pm"] * dP).sum(axis=2, keepdims=True, dtype=f32)))
+        dQ = q((np.einsum("thj,jhd->thd", dS, Kh).astype(f32) * scale).reshape(Nr, H))
+        dKk = np.einsum("thj,thd->jhd", dS, Qsh).astype(f32).reshape(Nk, H)
+        if not self.bf16:
+            dKk = (np.einsum("thj,thd->jhd", dS, ca["Q"].reshape(Nr, nh, dh_)).astype(f32) * scale).reshape(Nk, H)
+        dKk, dVk = q(dKk), q(dVk)                   # (fp32 sums over the rows, rounded when they become operands)
+        Wi = W(f"{a}.in_proj_weight")
         gW = np.concatenate([dQ.T @ ca["R"], dKk.T @ ca["G"], dVk.T @ ca["G"]], axis=0)
         _acc(g, f"{a}.in_proj_weight", gW); _acc(g, f"{a}.in_proj_bias", np.concatenate([dQ.sum(0), dKk.sum(0), dVk.sum(0)]))
         dR += dQ @ Wi[:H]; dG += dKk @ Wi[H:2 * H] + dVk @ Wi[2 * H:]
         # --- kg2rg attention
         a = "fusion.cross_attn_kg2rg"
         _acc(g, f"{a}.out_proj.weight", dU2.T @ ca["O2"]); _acc(g, f"{a}.out_proj.bias", dU2.sum(0))
-        dO2 = (dU2 @ P[f"{a}.out_proj.weight"]).reshape(Nk, nh, dh_)
-        V2h = ca["V2"].reshape(Nr, nh, dh_); K2h = ca["K2"].reshape(Nr, nh, dh_); Q2h = ca["Q2"].reshape(Nk, nh, dh_)
+        dO2 = q(dU2 @ W(f"{a}.out_proj.weight")).reshape(Nk, nh, dh_)
+        V2h = ca["V2"].reshape(Nr, nh, dh_); K2h = ca["K2"].reshape(Nr, nh, dh_); Q2sh = ca["Q2s"].reshape(Nk, nh, dh_)
         dP2d = np.einsum("jhd,thd->thj", dO2, V2h).astype(f32)
-        dV2 = np.einsum("thj,jhd->thd", ca["P2d"], dO2).astype(f32).reshape(Nr, H)
+        dV2 = q(np.einsum("thj,jhd->thd", q(ca["P2d"]), dO2).astype(f32).reshape(Nr, H))
         dP2 = dP2d if ca["m_a2"] is None else dP2d * ca["m_a2"]
-        dS2 = ca["P2"] * (dP2 - (ca["P2"] * dP2).sum(axis=0, keepdims=True, dtype=f32))
+        dS2 = q(ca["P2"] * (dP2 - (ca["P2"] * dP2).sum(axis=0, keepdims=True, dtype=f32)))
         dQ2 = (np.einsum("thj,thd->jhd", dS2, K2h).astype(f32) * scale).reshape(Nk, H)
-        dK2 = (np.einsum("thj,jhd->thd", dS2, Q2h).astype(f32) * scale).reshape(Nr, H)
-        Wi2 = P[f"{a}.in_proj_weight"]
+        dK2 = np.einsum("thj,jhd->thd", dS2, Q2sh).astype(f32).reshape(Nr, H)
+        if not self.bf16:
+            dK2 = (np.einsum("thj,jhd->thd", dS2, ca["Q2"].reshape(Nk, nh, dh_)).astype(f32) * scale).reshape(Nr, H)
+        dQ2, dK2 = q(dQ2), q(dK2)
+        Wi2 = W(f"{a}.in_proj_weight")
         gW2 = np.concatenate([dQ2.T @ ca["G"], dK2.T @ ca["R"], dV2.T @ ca["R"]], axis=0)
         _acc(g, f"{a}.in_proj_weight", gW2); _acc(g, f"{a}.in_proj_bias", np.concatenate([dQ2.sum(0), dK2.sum(0), dV2.sum(0)]))
         dG += dQ2 @ Wi2[:H]; dR += dK2 @ Wi2[H:2 * H] + dV2 @ Wi2[2 * H:]
+        dR, dG = q(dR), q(dG)
         if dbg is not None:
             dbg.update(dU=dU, dU2=dU2, dO=dO.reshape(Nr, H), dO2=dO2.reshape(Nk, H), dQ=dQ, dKk=dKk, dVk=dVk, dQ2=dQ2, dK2=dK2, dV2=dV2,
                        dR=dR, dG=dG)

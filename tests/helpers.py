@@ -58,3 +58,32 @@ def assert_params_close(a, b, lr, real, what=""):
     if not (err <= tol).all():
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError(f"{what}: at {i}: got {a[i]!r} want {b[i]!r} (|err|={err[i]:.3e}, tol={tol[i]:.3e}, real={real[i]})")
+
+
+def oracle_step_at_relu_thresholds(make_oracle, step, got_grads, max_units=24):
+    """The oracle's training step whose admissible ReLU sign pattern fits ``got_grads`` best.  A per-sample tail unit (fusion
+    layer 0, a head's hidden layer) whose pre-activation is within 1e-4 of zero may come out on the other side of the threshold
+    in an implementation that sums in another order (the kernels' pre-activations differ from the oracle's by ~2e-5), and one
+    such unit moves a head's gradient by percent -- an admissible difference, not an error.  ``make_oracle()`` -> a fresh oracle,
+    ``step(oracle)`` -> its train_step result.  The units near the threshold are recorded in a first pass (about one per seven
+    samples); each is then tried flipped, greedily, and kept flipped when that fits better (their effects are separate paths)."""
+    orc = make_oracle()
+    orc.near = []
+    orc.near_eps = 1e-4
+    ref = step(orc)
+    units = [(s, b, u) for s, b, u, _ in orc.near]
+    assert len(units) <= max_units, f"{len(units)} tail units within {orc.near_eps} of the ReLU threshold: {orc.near}"
+
+    def err(r):
+        num = sum(float(((got_grads[k].astype(np.float64) - r["raw_grads"][k]) ** 2).sum()) for k in got_grads)
+        den = sum(float((r["raw_grads"][k].astype(np.float64) ** 2).sum()) for k in got_grads)
+        return np.sqrt(num / den)
+    best, best_err, flips = ref, err(ref), []
+    for u in units:
+        o = make_oracle()
+        o.relu_flip = frozenset(flips + [u])
+        r = step(o)
+        e = err(r)
+        if e < best_err:
+            best, best_err, flips = r, e, flips + [u]
+    return best, list(orc.near), flips

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close
+from helpers import assert_close, oracle_step_at_relu_thresholds
 from oracle import fusion_oracle as FO
 from oracle import params as OP
 from test_fragment_maps import frag_order
@@ -162,10 +162,9 @@ def test_fused_forward_shapes(nrs, nk, rt, fused_opts):
 
 @pytest.mark.parametrize("training", [False, True])
 def test_fused_backward_stage_by_stage(training, kg_real, fused_opts):
-    """The fused backward kernels against the oracle's intermediate activation gradients, then every parameter gradient.
-    Stage bounds are gross-error bounds (a wrong fragment map or index is O(1) off): <= 1 % of the elements further than 8 %
-    of the tensor's maximum, mean error <= 1.5-2 %; the parameter gradients at the end carry the parity claim (global
-    relative error < 5 %, north_star's bf16 budget)."""
+    """The fused backward kernels against the intermediate activation gradients of the oracle in its bf16-operand mode, then every
+    parameter gradient: absolute bounds (global relative error < 0.2 %, every tensor that carries weight < 1 %; measured 0.002-0.01 %
+    and <= 0.1 %), no other HIP schedule as a yardstick."""
     cfg = OP.full_cfg()
     prm = OP.make_params(cfg, 0)
     m = make_model(cfg, 0, "bf16")
@@ -181,12 +180,12 @@ def test_fused_backward_stage_by_stage(training, kg_real, fused_opts):
     ws.zero_()
     g = eng.ensure_flat_grads(attach=True)
     g.zero_()
-    orc = FO.FusionOracle(cfg, prm)
+    orc = FO.FusionOracle(cfg, OP.make_params(cfg, 0), bf16_operands=True)      # rounds what the kernels round (oracle/fusion_oracle.py)
     ref = FO.train_step(orc, FO.AdamW(orc.p), rg, kg, y, e, s, training=training, seed=seed, debug=True)
     # forward on the HIP path, then backward from the ORACLE's loss gradient: the focal term's gradient is steep in the
-    # logits, and this test is about the backward kernels, not about how bf16 logit noise moves d(loss)/d(logits)
+    # logits, and this test is about the backward kernels, not about how logit noise moves d(loss)/d(logits)
     outs, _ = eng.forward_raw(batch, ws, training, seed)
-    assert_close(t2n(outs), outs6(ref["outs"]), 2e-3, 0, "outputs")
+    assert_close(t2n(outs), outs6(ref["outs"]), 5e-4, 0, "outputs")
     d_outs = []
     for b in range(B):
         ob = {k: ref["outs"][k][b] for k in ("mask", "instance", "edge", "score")}
@@ -204,24 +203,27 @@ def test_fused_backward_stage_by_stage(training, kg_real, fused_opts):
         except AssertionError as ex:
             failures.append(str(ex)[:300])
     cat = lambda k: np.concatenate([d[k] for d in dbg])
-    sc = np.float32(1.0 / np.sqrt(32.0))
-    close_rel(ws_bf16(eng, batch, ws, "dH16", T, 2 * H), cat("dH_ffn_rg"), 8e-2, "dH (RG)", 3.8e-03, flips=1e-2)
-    close_rel(ws_bf16(eng, batch, ws, "dH2_16", B * Nk, 2 * H), cat("dH_ffn_kg"), 8e-2, "dH (KG)", 15.0e-03, flips=1e-2)
-    close_rel(ws_bf16(eng, batch, ws, "dU16", T, H), cat("dU"), 8e-2, "dU", 11.2e-03, flips=1e-2)
-    close_rel(ws_bf16(eng, batch, ws, "dU2_16", B * Nk, H), cat("dU2"), 8e-2, "dU2", 15.0e-03, flips=1e-2)
-    close_rel(ws_bf16(eng, batch, ws, "dO2_16", B * Nk, H), cat("dO2"), 8e-2, "dO2", 15.0e-03, flips=1e-2)
+    # stage bounds against the bf16-operand oracle: <= 0.2 % of the elements further than 2 % of the tensor's maximum (a bf16 value
+    # that lands on the other side of a rounding boundary moves by 0.4 % of itself; sums of such values by less), mean error <= 0.3 %
+    R, M, F = 2e-2, 3e-3, 2e-3
+    close_rel(ws_bf16(eng, batch, ws, "dH16", T, 2 * H), cat("dH_ffn_rg"), R, "dH (RG)", M, flips=F)
+    close_rel(ws_bf16(eng, batch, ws, "dH2_16", B * Nk, 2 * H), cat("dH_ffn_kg"), R, "dH (KG)", M, flips=F)
+    close_rel(ws_bf16(eng, batch, ws, "dU16", T, H), cat("dU"), R, "dU", M, flips=F)
+    close_rel(ws_bf16(eng, batch, ws, "dU2_16", B * Nk, H), cat("dU2"), R, "dU2", M, flips=F)
+    close_rel(ws_bf16(eng, batch, ws, "dO2_16", B * Nk, H), cat("dO2"), R, "dO2", M, flips=F)
     d2 = ws_f32(eng, batch, ws, "delta2", B * 8 * 16).reshape(B, 8, 16)
     want_d2 = np.stack([(d["dO2"].reshape(Nk, 8, 32) * c["O2"].reshape(Nk, 8, 32)).sum(-1).T for d, c in zip(dbg, caches)])   # [B][8][Nk]
-    close_rel(d2[:, :, :Nk], want_d2, 8e-2, "delta2 = dO2 . O2", 1.5e-2, flips=2e-2)
+    # (row-dots and query-gradient sums are small differences of large terms: their own, wider bound)
+    close_rel(d2[:, :, :Nk], want_d2, 5e-2, "delta2 = dO2 . O2", 1e-2, flips=2e-2)
     dqkv = ws_bf16(eng, batch, ws, "dQKV16", T, 3 * H)
-    close_rel(dqkv[:, :H], cat("dQ"), 8e-2, "dQ", 15.0e-03, flips=1e-2)
-    close_rel(dqkv[:, H:2 * H], cat("dK2"), 8e-2, "dK2", 15.0e-03, flips=1e-2)
-    close_rel(dqkv[:, 2 * H:], cat("dV2"), 8e-2, "dV2", 15.0e-03, flips=1e-2)
-    close_rel(ws_f32(eng, batch, ws, "dKV", B * Nk * 2 * H).reshape(B * Nk, 2 * H), np.concatenate([cat("dKk"), cat("dVk")], axis=1), 8e-2, "dK | dV sums", 15.0e-03, flips=1e-2)
-    close_rel(ws_f32(eng, batch, ws, "dQ2acc", B * Nk * H).reshape(B * Nk, H), cat("dQ2"), 8e-2, "dQ2 sums", 15.0e-03, flips=1e-2)
-    close_rel(ws_bf16(eng, batch, ws, "dQKVkg16", B * Nk, 3 * H), np.concatenate([cat("dQ2"), cat("dKk"), cat("dVk")], axis=1), 8e-2, "dQKV (KG rows)", 15.0e-03, flips=1e-2)
-    close_rel(ws_bf16(eng, batch, ws, "dR16", T, H), cat("dR"), 8e-2, "dR", 15.0e-03, flips=1e-2)
-    close_rel(ws_bf16(eng, batch, ws, "dG16", B * Nk, H), cat("dG"), 8e-2, "dG", 18.8e-03, flips=1e-2)
+    close_rel(dqkv[:, :H], cat("dQ"), R, "dQ", M, flips=F)
+    close_rel(dqkv[:, H:2 * H], cat("dK2"), R, "dK2", M, flips=F)
+    close_rel(dqkv[:, 2 * H:], cat("dV2"), R, "dV2", M, flips=F)
+    close_rel(ws_f32(eng, batch, ws, "dKV", B * Nk * 2 * H).reshape(B * Nk, 2 * H), np.concatenate([cat("dKk"), cat("dVk")], axis=1), R, "dK | dV sums", M, flips=F)
+    close_rel(ws_f32(eng, batch, ws, "dQ2acc", B * Nk * H).reshape(B * Nk, H), cat("dQ2"), 5e-2, "dQ2 sums", 1e-2, flips=2e-2)
+    close_rel(ws_bf16(eng, batch, ws, "dQKVkg16", B * Nk, 3 * H), np.concatenate([cat("dQ2"), cat("dKk"), cat("dVk")], axis=1), R, "dQKV (KG rows)", M, flips=F)
+    close_rel(ws_bf16(eng, batch, ws, "dR16", T, H), cat("dR"), R, "dR", M, flips=F)
+    close_rel(ws_bf16(eng, batch, ws, "dG16", B * Nk, H), cat("dG"), R, "dG", M, flips=F)
     num = den = 0.0
     rels = []
     for k, p in m.named_parameters():
@@ -230,23 +232,11 @@ def test_fused_backward_stage_by_stage(training, kg_real, fused_opts):
         rels.append((np.sqrt(((got - want) ** 2).sum()) / max(np.sqrt((want ** 2).sum()), 1e-30), np.sqrt((want ** 2).sum()), k))
     rels.sort(reverse=True)
     total = np.sqrt(num / den)
-    print("fused backward: global relative gradient error", total, "worst", [(f"{r:.3f}", f"{n:.2e}", k) for r, n, k in rels[:6]])
-    # the same call on the round-1 bf16-resident schedule (fp32 attention, fp32 activations between launches): how much of
-    # the error is this INPUT's sensitivity to bf16 operand rounding (one-node samples, ReLU units at their threshold)
-    fused_opts("fused", 0)
-    ws2 = eng.workspace(batch, private=True)
-    ws2.zero_()
-    g.zero_()
-    outs2, _ = eng.forward_raw(batch, ws2, training, seed)
-    eng.backward_raw(batch, ws2, outs2, d_outs, training, seed, eng._gtab)
-    torch.cuda.synchronize()
-    num2 = sum(((t2n(p.grad).astype(np.float64) - ref["raw_grads"][k]) ** 2).sum() for k, p in m.named_parameters())
-    total16 = np.sqrt(num2 / den)
-    print("same call, round-1 bf16-resident schedule: global relative gradient error", total16)
+    print("fused backward vs the bf16-operand oracle: global relative gradient error", total, "worst", [(f"{r:.4f}", f"{n:.2e}", k) for r, n, k in rels[:6]])
     assert not failures, "\n".join(failures)
-    assert total < max(5e-2, 1.5 * total16), (total, total16)
+    assert total < 2e-3, total
     gn = np.sqrt(den)
-    assert all(r < max(0.12, 2.5 * total16) for r, n, _ in rels if n > 1e-3 * gn), rels[:6]
+    assert all(r < 1e-2 for r, n, _ in rels if n > 1e-3 * gn), rels[:6]
 
 
 @pytest.mark.parametrize("training,B", [(False, 9), (True, 16), (True, 1), (True, 6), (True, 13), (True, 3)])
@@ -288,17 +278,18 @@ def test_one_launch_tail_matches_separate_launches(training, B, kg_real, fused_o
         assert float(np.abs(ga[k] - gb[k]).max()) <= tol * scale + 2e-7, (k, float(np.abs(ga[k] - gb[k]).max()), scale)
 
 
-@pytest.mark.parametrize("nrs,nk,pseed", [([1], 1, 6), ([5, 700, 32], 16, 6), ([64] * 17, 13, 6), ([33, 31, 1, 2, 530, 96], 13, 7),
-                                          ([33, 31, 1, 2, 530, 96], 13, 8), ([1500, 17], 7, 6), ([420 + 5 * i for i in range(24)], 13, 6)])
+@pytest.mark.parametrize("nrs,nk,pseed", [([1], 1, 6), ([5, 700, 32], 16, 6), ([64] * 17, 13, 6), ([33, 31, 1, 2, 530, 96], 13, 6),
+                                          ([33, 31, 1, 2, 530, 96], 13, 7), ([33, 31, 1, 2, 530, 96], 13, 8), ([1500, 17], 7, 6),
+                                          ([420 + 5 * i for i in range(24)], 13, 6), ([128] * 3 + [127, 129, 256, 64, 192], 13, 6)])
 def test_fused_training_step_shape_envelope(nrs, nk, pseed, fused_opts):
     """Envelope of the fused BACKWARD (and of the one-launch tail where B <= 16): one-node samples, Nk = 1 / 7 / 16, samples
-    that end exactly on a tile boundary, B = 17 (multi-launch tail behind fused node kernels), a 1500-node sample, 24 samples with
-    11 460 rows (the weight-gradient launch's split-K ladder picks a 24-tile chunk: not a power of two) -- against the
-    oracle's train step with the same dropout masks.  The yardstick for "how far may bf16 operands move a gradient on THIS
-    input" (tiny samples weigh single rows heavily) is the round-1 bf16 schedule's error on the same input.  (Parameter seeds
-    are chosen so that no head unit with a large gradient has its pre-activation within bf16 noise of zero: with pseed = 6 the
-    six-sample case has one such unit in each of three samples, and a single ReLU flip there moves instance_head.0.bias by 18 %
-    in whichever schedule lands on the other side of zero -- tests/dev_relu_flip.py shows the units.)"""
+    that end exactly on a 32-, 64- or 128-row boundary, B = 17 (multi-launch tail behind fused node kernels), a 1500-node sample,
+    24 samples with 11 460 rows (the weight-gradient launch's split-K ladder picks a 24-tile chunk: not a power of two) --
+    against the train step of the oracle in its bf16-operand mode with the same dropout masks, at FIXED bounds: global relative
+    gradient error < 0.2 %, every tensor that carries weight < 1 % (measured: 0.002-0.02 % and <= 0.2 %).  Tiny samples weigh single rows heavily, and with parameter
+    seed 6 the six-sample case has head units whose pre-activation sits within bf16 noise of zero in three samples: against
+    the reference-exact f32 oracle one such ReLU flip moves instance_head.0.bias by 18 % (tests/dev_relu_flip.py); the bf16-operand
+    oracle rounds what the kernels round and lands on the same side.  The f32 oracle still bounds the logits (north_star: 1e-3)."""
     cfg = OP.full_cfg()
     m = make_model(cfg, pseed, "bf16").train()
     eng = m._engine
@@ -307,35 +298,32 @@ def test_fused_training_step_shape_envelope(nrs, nk, pseed, fused_opts):
     kg = np.stack([OP.make_kg(nk, 128, seed=400 + i) for i in range(B)])
     y, e, s = OP.make_labels(B, seed=21)
     dseed = 1234
-    orc = FO.FusionOracle(cfg, OP.make_params(cfg, pseed))
-    ref = FO.train_step(orc, FO.AdamW(orc.p), rgl, kg, y, e, s, training=True, seed=dseed)
+    ref32, _ = FO.FusionOracle(cfg, OP.make_params(cfg, pseed)).forward_list(rgl, kg, training=True, seed=dseed)
     batch = eng.make_batch(torch.from_numpy(np.concatenate(rgl)).cuda(), list(nrs), torch.from_numpy(kg).cuda())
-
-    def errors(grads):
-        num = sum(float(((grads[k].astype(np.float64) - ref["raw_grads"][k]) ** 2).sum()) for k in grads)
-        den = sum(float((ref["raw_grads"][k].astype(np.float64) ** 2).sum()) for k in grads)
-        worst = max((float(np.sqrt(((grads[k].astype(np.float64) - ref["raw_grads"][k]) ** 2).sum() / max((ref["raw_grads"][k].astype(np.float64) ** 2).sum(), 1e-30))), k)
-                    for k in grads if (ref["raw_grads"][k].astype(np.float64) ** 2).sum() > 1e-6 * den)
-        return float(np.sqrt(num / den)), worst
-
-    res = []
-    for fused in (1, 0):
-        fused_opts("fused", fused)
-        ws = eng.workspace(batch, private=True)
-        g = eng.ensure_flat_grads(attach=True)
-        g.zero_()
-        outs, terms, pred = eng.train_raw(batch, ws, torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s), True, dseed, eng._gtab)
-        torch.cuda.synchronize()
-        grads = {k: t2n(p.grad).copy() for k, p in m.named_parameters()}
-        assert np.isfinite(t2n(outs)).all() and all(np.isfinite(v).all() for v in grads.values())
-        res.append((t2n(outs), t2n(terms), errors(grads)))
-    fused_opts("fused", -1)
-    (oa, ta, (ea, wa)), (ob, tb, (eb, wb)) = res
-    assert_close(oa, outs6(ref["outs"]), 2e-3, 0, "outputs")
-    assert_close(ta, ref["loss_terms"], 5e-3, 2e-3, "loss terms")
-    print(f"nrs={nrs[:6]} nk={nk}: global relative gradient error fused {ea:.4f} (worst {wa[1]} {wa[0]:.3f}) | gemm-per-layer {eb:.4f} (worst {wb[1]} {wb[0]:.3f})")
-    assert ea < max(5e-2, 1.5 * eb), (ea, eb)
-    assert wa[0] < max(0.12, 2.0 * wb[0]), (wa, wb)
+    ws = eng.workspace(batch, private=True)
+    g = eng.ensure_flat_grads(attach=True)
+    g.zero_()
+    outs, terms, pred = eng.train_raw(batch, ws, torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s), True, dseed, eng._gtab)
+    torch.cuda.synchronize()
+    grads = {k: t2n(p.grad).copy() for k, p in m.named_parameters()}
+    assert np.isfinite(t2n(outs)).all() and all(np.isfinite(v).all() for v in grads.values())
+    # (tail units whose pre-activation is within 2e-4 of the ReLU threshold may land on either side: helpers.py)
+    ref, near, flipped = oracle_step_at_relu_thresholds(
+        lambda: FO.FusionOracle(cfg, OP.make_params(cfg, pseed), bf16_operands=True),
+        lambda o: FO.train_step(o, FO.AdamW(o.p), rgl, kg, y, e, s, training=True, seed=dseed), grads)
+    if near:
+        print("tail units at the ReLU threshold (site, sample, unit, pre-activation):", near, "taken flipped:", flipped)
+    assert_close(t2n(outs), outs6(ref32), 1e-3, 0, "outputs vs the f32 oracle")
+    assert_close(t2n(outs), outs6(ref["outs"]), 5e-4, 0, "outputs vs the bf16-operand oracle")
+    assert_close(t2n(terms), ref["loss_terms"], 2e-3, 1e-3, "loss terms")
+    den = sum(float((ref["raw_grads"][k].astype(np.float64) ** 2).sum()) for k in grads)
+    num = sum(float(((grads[k].astype(np.float64) - ref["raw_grads"][k]) ** 2).sum()) for k in grads)
+    per = sorted(((float(np.sqrt(((grads[k].astype(np.float64) - ref["raw_grads"][k]) ** 2).sum() / max((ref["raw_grads"][k].astype(np.float64) ** 2).sum(), 1e-30))), k)
+                  for k in grads if (ref["raw_grads"][k].astype(np.float64) ** 2).sum() > 1e-6 * den), reverse=True)
+    total = float(np.sqrt(num / den))
+    print(f"nrs={nrs[:6]} nk={nk} pseed={pseed}: global relative gradient error vs the bf16-operand oracle {total:.5f}; worst {per[0][1]} {per[0][0]:.4f}")
+    assert total < 2e-3, (total, per[:4])
+    assert per[0][0] < 1e-2, per[:4]
 
 
 @pytest.mark.parametrize("B,ncls", [(1, 2), (17, 2), (32, 2), (33, 3), (100, 2)])

@@ -42,19 +42,25 @@ def test_benchmarked_mode_bf16_dropout_b16_matches_oracle(kg_real):
     dseed = 0x5EEDC0FFEE123457
     m = make_model(cfg, 0, "bf16").train()
     tr = NativeTrainer(m, keep_grads=True)
-    orc = FO.FusionOracle(cfg, OP.make_params(cfg, 0))
+    # the oracle in its bf16-operand mode: it rounds the tensors the kernels round (oracle/fusion_oracle.py), so what is left
+    # between the two is summation order and the one rounding the oracle models statistically (the KG->RG exponentials);
+    # the reference-exact f32 oracle bounds the logits (north_star: 1e-3)
+    orc32 = FO.FusionOracle(cfg, OP.make_params(cfg, 0))
+    ref32, _ = orc32.forward_list(rg, kg, training=True, seed=dseed)
+    orc = FO.FusionOracle(cfg, OP.make_params(cfg, 0), bf16_operands=True)
     ref = FO.train_step(orc, FO.AdamW(orc.p), rg, kg, y, e, s, training=True, seed=dseed)
     terms, pred = tr.step(torch.from_numpy(np.concatenate(rg)).cuda(), nrs, torch.from_numpy(kg).cuda(), torch.from_numpy(y),
                           torch.from_numpy(e), torch.from_numpy(s), seed=dseed)
-    assert_close(t2n(terms), ref["loss_terms"], 2e-3, 2e-3, "bf16 + dropout loss terms")
+    assert_close(t2n(terms), ref["loss_terms"], 5e-4, 5e-4, "bf16 + dropout loss terms")
     assert (t2n(pred) == outs6(ref["outs"])[:, :2].argmax(1)).all()
-    assert_close(t2n(tr.opt.grad_norm())[0], ref["grad_norm"], 0, 2e-2, "grad norm")
+    assert (t2n(pred) == outs6(ref32)[:, :2].argmax(1)).all()
+    assert_close(t2n(tr.opt.grad_norm())[0], ref["grad_norm"], 0, 5e-3, "grad norm")
     coef = min(1.0, 1.0 / (float(ref["grad_norm"]) + 1e-6))
     tr.engine.ensure_flat_grads(attach=True)
     total, gn, rels = _grad_errors(m, ref, coef)
-    print("bf16+dropout B=16: global relative gradient error", total, "worst tensors", [(f"{r:.3f}", f"{n:.2e}", k) for r, n, k in rels[:5]])
-    assert total < 5e-2
-    assert all(r < 0.10 for r, n, _ in rels if n > 1e-3 * gn)
+    print("bf16+dropout B=16: global relative gradient error vs the bf16-operand oracle", total, "worst tensors", [(f"{r:.3f}", f"{n:.2e}", k) for r, n, k in rels[:5]])
+    assert total < 2e-3                                                # (measured 4.5e-4; worst tensor ffn_kg.0.weight 0.7 %)
+    assert all(r < 1.5e-2 for r, n, _ in rels if n > 1e-3 * gn)
 
 
 def test_long_sequence_config_nr2048(kg_real):
@@ -334,3 +340,33 @@ def test_inference_calls_reuse_the_weight_shadows(kg_real):
             assert eng.shadows_current() and eng._shadows_full
             assert_close(va, vb, 5e-3, 5e-3, "validation outputs in the middle of training")
             m.train(); m2.train()
+
+
+def test_tail_timeout_is_not_applied(kg_real):
+    """A one-launch tail whose arrival wait gives up (co-residency lost: GPU shared with another process) must not become a
+    parameter update.  The developer hook makes one block skip its arrival, so the other 63 time out deterministically: the
+    step's loss terms are NaN, the gradient norm is NaN, parameters and Adam moments are untouched, the sticky counter moved;
+    the next step is a normal one."""
+    from camouflage_multimodal_amd import NativeTrainer, _lib
+    cfg = OP.full_cfg()
+    m = make_model(cfg, 0, "bf16").train()
+    tr = NativeTrainer(m)
+    nrs = [40, 33, 70, 12]
+    rg = torch.from_numpy(np.concatenate([OP.make_rg(n, 128, seed=40 + i) for i, n in enumerate(nrs)])).cuda()
+    kg = torch.from_numpy(np.stack([kg_real] * 4)).cuda()
+    y, e, s = (torch.from_numpy(x) for x in OP.make_labels(4, seed=3))
+    tr.step(rg, nrs, kg, y, e, s)                                    # a normal step first (Adam moments non-zero)
+    torch.cuda.synchronize()
+    before = m._engine.flat_params.clone()
+    t0 = _lib.tail_timeouts()
+    _lib.check(_lib.lib().camo_debug_set_option(b"tail_skip_arrival", 6), "hook")
+    terms, _ = tr.step(rg, nrs, kg, y, e, s)
+    torch.cuda.synchronize()
+    assert _lib.tail_timeouts() > t0
+    assert torch.isnan(terms).all()
+    assert not np.isfinite(t2n(tr.opt.grad_norm())[0])
+    assert torch.equal(m._engine.flat_params, before), "a timed-out step changed the parameters"
+    terms, _ = tr.step(rg, nrs, kg, y, e, s)                         # and the next step is applied again
+    torch.cuda.synchronize()
+    assert torch.isfinite(terms).all() and not torch.equal(m._engine.flat_params, before)
+    assert torch.isfinite(m._engine.flat_params).all()

@@ -62,6 +62,9 @@ def test_argument_validation_without_a_gpu():
                                  0, 0, 1, 1, None, 1, ctypes.byref(st), None) == -1 and b"shadows_valid" in L.camo_last_error() and st.value == 0
     assert L.camo_forward_cached(ctypes.byref(d), None, None, None, None, None, 4, 100, 13, 50, None, 0, None, None, None,
                                  0, 0, 1, 1, ctypes.c_void_p(0x1010), 0, None, None) == -1 and b"256-byte" in L.camo_last_error()
+    # ... and a call that would save for camo_backward (no CAMO_FWD_INFERENCE): the backward could not find the transposed shadows
+    assert L.camo_forward_cached(ctypes.byref(d), None, None, None, None, None, 4, 100, 13, 50, None, 0, None, None, None,
+                                 1, 0, 1, 0, ctypes.c_void_p(0x1000), 0, None, None) == -2 and b"inference calls only" in L.camo_last_error()
     assert L.camo_shadow_bytes(ctypes.byref(d)) % 256 == 0 and L.camo_shadow_bytes(ctypes.byref(d)) > 3e6 and L.camo_shadow_bytes(ctypes.byref(bad)) == 0
     assert L.camo_batch_desc_bytes(16, 7700) >= 4 * (7700 + 16 + 17) and L.camo_batch_desc_bytes(0, 5) == 0
     assert L.camo_loss(None, None, None, None, 4, 2, None, None, None, None, None) == -1
