@@ -168,10 +168,20 @@ def main():
     torch.manual_seed(0)
     model = build_multimodal_model({}).to(dev).set_precision(args.precision).train()   # reference defaults, dropout 0.3
     if world > 1:
-        broadcast_parameters(model._engine.flat_params)
+        broadcast_parameters(model._engine)
     trainer = NativeTrainer(model, lr=5e-4, weight_decay=1e-4, grad_allreduce={"bucketed": BucketedGradAllReducer, "single": GradAllReducer, "oneshot": OneShotGradAllReducer}[args.allreduce]() if world > 1 else None)
 
-    host = make_batches(8, args.batch, rank)
+    if world > 1:
+        # weak scaling: global minibatches of world x batch samples, the same on every rank (common seed), each rank taking the share
+        # shard_by_rows assigns it -- balanced by the number of RG rows (Nr varies 303..530), not by the sample count
+        from camouflage_multimodal_amd.ddp import shard_by_rows
+        host = []
+        for rg, nrs, kg, y, e, s_ in make_batches(8, args.batch * world, 0):
+            mine = shard_by_rows(nrs, world, rank)
+            off = np.concatenate([[0], np.cumsum(nrs)])
+            host.append((np.concatenate([rg[off[i]:off[i + 1]] for i in mine]), [nrs[i] for i in mine], kg[mine], y[mine], e[mine], s_[mine]))
+    else:
+        host = make_batches(8, args.batch, rank)
     batches = [(torch.from_numpy(rg).to(dev), nrs, torch.from_numpy(kg).to(dev), torch.from_numpy(y).to(dev),
                 torch.from_numpy(e).to(dev), torch.from_numpy(s).to(dev)) for rg, nrs, kg, y, e, s in host]
 
@@ -208,10 +218,40 @@ def main():
     blocks = timed_blocks(train_step, args.steps, args.warmup)
     elapsed = float(np.median(blocks))
 
+    # ---- multi-GPU diagnostics (every rank runs the steps; rank 0 reports): what the communicator says the world is, event-timed
+    # all-reduce per bucket, how much of the overlapped bucket hid behind the backward kernels, and the same steps with ONE plain
+    # all-reduce behind the backward for comparison
+    ddp_info = None
+    if world > 1:
+        ar = trainer.grad_allreduce
+        ar.enable_timing(True)
+        for i in range(args.warmup, args.warmup + min(args.steps, 30)):
+            train_step(i)
+        tsum = ar.timing_summary()
+        ar.enable_timing(False)
+        single = GradAllReducer()
+        trainer.grad_allreduce = single
+        sb = timed_blocks(train_step, min(args.steps, 30), 3, min_seconds=0.2)
+        single.enable_timing(True)
+        for i in range(10):
+            train_step(i)
+        ssum = single.timing_summary()
+        trainer.grad_allreduce = ar
+        ddp_info = {"world_from_communicator": dist.get_world_size(), "backend": dist.get_backend(), "allreduce": args.allreduce,
+                    "samples_per_rank": [len(b[1]) for b in host][:4], "rows_per_rank": [int(sum(b[1])) for b in host][:4],
+                    "gradient_bytes": int(model._engine.flat_params.numel() * 4), "timing": tsum,
+                    "single_allreduce": {"ms_per_step": round(float(np.median(sb)) / min(args.steps, 30) * 1e3, 4), "timing": ssum},
+                    "note": "bucket a = the per-sample tail's gradients, reduced on a side stream beside the node-level backward; "
+                            "overlap_fraction = share of its duration elapsed when the backward kernels were done"}
+
     # ---- roofline leg: K steps again with HIP events around every launch of the dominant kernel
     # (every rank runs these steps -- they contain the gradient all-reduce -- only rank 0 records events)
     roof = None
     alg_step = float(np.mean([algorithmic_flops(b[1]) for b in host]))
+    if world > 1:                                               # (whole job: the shares of all ranks)
+        t = torch.tensor([alg_step], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        alg_step = float(t.item()) / world                      # per-rank mean, as the single-GPU figure
     if not args.no_kernel_timing:
         L = _lib.lib()
         k = min(args.steps, 50)
@@ -260,6 +300,10 @@ def main():
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
                     "traffic": None, "kernel": dom["kernel"], "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["us_per_launch"],
                     "algorithmic_gflop_per_launch": round(dfl / 1e9, 3), "empty_event_pair_us": round(ev_us, 2),
+                    # what the MFMA pipes really run: the pooled second FFN layer is algebraically removed, so the
+                    # kernel is credited above with work it makes unnecessary; this is the executed rate
+                    "achieved_executed": dom["executed_tflops"], "frac_executed": round((dom["executed_tflops"] or 0.0) / peak, 5),
+                    "executed_gflop_per_launch": round(dom["executed_gflop_per_step"] / max(dom["launches_per_step"], 1e-9), 3),
                     "note": "achieved = algorithmic FLOPs of one launch / its HIP-event duration on the launch stream; at B = 16 a launch is one "
                             "32-row tile per CU, bound by streaming each layer's weights from L2 (DESIGN.md 6), not by the MFMA pipe"}
             pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -295,23 +339,72 @@ def main():
                              "mode": f"eval-mode camo_forward_cached (weight shadows kept across calls), B = {args.batch} packed, {args.precision}, algorithmic forward FLOPs / call time"}
         # (b) batch sweep of the training step: where the per-step floor stops dominating
         sweep = []
-        for Bs in (1, 4, 16, 64, 256):
+        for Bs in (1, 4, 16, 64, 256, 1024, 4096):
+            if Bs >= 1024 and args.steps < 20:
+                continue                                        # (the two large sizes take a few seconds: skipped in short profiling runs)
             hb = make_batches(2, Bs, rank, seed=100 + Bs)
             db = [(torch.from_numpy(rg).to(dev), nrs, torch.from_numpy(kg).to(dev), torch.from_numpy(y).to(dev),
                    torch.from_numpy(e).to(dev), torch.from_numpy(s_).to(dev)) for rg, nrs, kg, y, e, s_ in hb]
-            ks = max(4, min(args.steps, 20))
-            tb = timed_blocks(lambda i: trainer.step(*db[i % 2]), ks, 3, min_seconds=0.25)
+            ks = max(4, min(args.steps, 20)) if Bs < 1024 else 4
+            tb = timed_blocks(lambda i: trainer.step(*db[i % 2]), ks, 3 if Bs < 1024 else 1, min_seconds=0.25 if Bs < 1024 else 0.0)
             st = float(np.median(tb)) / ks
             fl = float(np.mean([algorithmic_flops(b[1]) for b in hb]))
             # the same batches forward-only (eval mode, weight shadows kept across calls): where the forward's MFMA fraction goes with B
-            fb2 = timed_blocks(lambda i: trainer.evaluate(*db[i % 2][:3]), ks, 3, min_seconds=0.15)
+            fb2 = timed_blocks(lambda i: trainer.evaluate(*db[i % 2][:3]), ks, 3 if Bs < 1024 else 1, min_seconds=0.15 if Bs < 1024 else 0.0)
             ft = float(np.median(fb2)) / ks
             sweep.append({"batch": Bs, "ms_per_step": round(st * 1e3, 4), "images_per_s": round(Bs / st, 1),
                           "whole_step_tflops": round(fl / st / 1e12, 2), "frac": round(fl / st / 1e12 / peak, 5),
                           "forward_ms": round(ft * 1e3, 4), "forward_images_per_s": round(Bs / ft, 1),
                           "forward_tflops": round(fl / FWDBWD_OVER_FWD / ft / 1e12, 2), "forward_frac": round(fl / FWDBWD_OVER_FWD / ft / 1e12 / peak, 5)})
             del db
+            if Bs >= 1024:
+                model._engine._ws = None                        # (tens of GB of workspace: give it back before the next leg)
+                torch.cuda.empty_cache()
         extras["sweep"] = sweep
+        # (b2) BASELINE configs[3] stand-in: Nr = 2048 nodes per sample, B = 4 -- the KG->RG softmax spans 2048 keys
+        rs3 = np.random.RandomState(77)
+        kg1 = host[0][2][0]
+        c3 = [((np.abs(rs3.standard_normal((4 * 2048, 128))) * 0.3).astype(np.float32), [2048] * 4, np.broadcast_to(kg1, (4, 13, 128)).copy(),
+               (rs3.uniform(size=4) < 0.5).astype(np.int64), (rs3.uniform(size=4) < 0.5).astype(np.float32), rs3.uniform(size=4).astype(np.float32)) for _ in range(2)]
+        d3 = [tuple(torch.from_numpy(x).to(dev) if isinstance(x, np.ndarray) else x for x in b) for b in c3]
+        ks = max(4, min(args.steps, 20))
+        t3 = float(np.median(timed_blocks(lambda i: trainer.step(*d3[i % 2]), ks, 3, min_seconds=0.25))) / ks
+        f3 = float(np.median(timed_blocks(lambda i: trainer.evaluate(*d3[i % 2][:3]), ks, 3, min_seconds=0.15))) / ks
+        fl3 = algorithmic_flops([2048] * 4)
+        extras["config3"] = {"workload": "Nr = 2048 nodes per sample, B = 4 (BASELINE configs[3] stand-in, SURVEY 8d)", "ms_per_step": round(t3 * 1e3, 4),
+                             "images_per_s": round(4 / t3, 1), "whole_step_tflops": round(fl3 / t3 / 1e12, 2), "frac": round(fl3 / t3 / 1e12 / peak, 5),
+                             "forward_ms": round(f3 * 1e3, 4), "forward_frac": round(fl3 / FWDBWD_OVER_FWD / f3 / 1e12 / peak, 5)}
+        del d3
+        # (b3) what a real epoch delivers (train_multimodal.py:238-279, :385-395): a device-resident dataset of 2048 synthetic samples,
+        # WeightedRandomSampler-style draws, minibatches of the headline size -- a fresh Nr tuple, gather and batch descriptor every
+        # step, the reference's augmentation on -- through the same train_epoch_fixed the product's fit() runs
+        from camouflage_multimodal_amd import DeviceResidentDataset
+        from camouflage_multimodal_amd.ddp import sharded_weighted_sampler
+        from camouflage_multimodal_amd.train_multimodal import train_epoch_fixed
+        rs4 = np.random.RandomState(5)
+        hist = load_fixture("nr_histogram.npz")
+        nr_all = rs4.choice(hist["values"], size=2048, p=hist["counts"] / hist["counts"].sum()) if hist is not None else rs4.randint(303, 531, size=2048)
+        samples = [dict(rg_node_emb=torch.from_numpy((np.abs(rs4.standard_normal((int(n), 128))) * 0.3).astype(np.float32)), kg_emb=torch.from_numpy(kg1)[:, None, :],
+                        mask_label=int(rs4.uniform() < 0.5), edge_label=float(rs4.uniform() < 0.5), score_label=float(rs4.uniform())) for n in nr_all]
+        ds = DeviceResidentDataset(samples, dev, augment=True, seed=0)
+        del samples
+        wts = [5.0 if int(l) else 1.0 for l in ds.mask_label.tolist()]
+        def epoch_loader(ep):
+            draw = sharded_weighted_sampler(wts, len(ds), ep, 1, 0, seed=0)
+            draw_dev = torch.tensor(draw, device=dev)           # (as train_multimodal_fixed does: the epoch's indices go over once)
+            return (ds.batch(draw[i:i + args.batch], idx_dev=draw_dev[i:i + args.batch]) for i in range(0, len(draw), args.batch))
+        train_epoch_fixed(model, epoch_loader(0), trainer, dev, 1)             # warm-up epoch (allocator, descriptor buffers)
+        fence()
+        t0 = time.perf_counter()
+        train_epoch_fixed(model, epoch_loader(1), trainer, dev, 2)
+        fence()
+        ep_s = time.perf_counter() - t0
+        extras["epoch"] = {"images_per_s": round(len(ds) / ep_s, 1), "seconds": round(ep_s, 4), "samples": len(ds), "batch": args.batch,
+                           "steps": (len(ds) + args.batch - 1) // args.batch, "vs_value": None,
+                           "what": "one epoch of train_epoch_fixed over a DeviceResidentDataset: weighted draw with replacement, a fresh Nr tuple "
+                                   "per step (camo_gather_batch: rows, offsets, labels and augmentation in one launch; one descriptor launch), augmentation on, the "
+                                   "epoch's loss / F1 read back once at its end"}
+        del ds
         # (c) the exact-f32 mode (f32-input MFMA, general schedule) on the headline batch
         if args.precision == "bf16":
             torch.manual_seed(0)
@@ -347,6 +440,10 @@ def main():
         }
         if roof is not None:
             line["roofline"] = roof
+        if "epoch" in extras:
+            extras["epoch"]["vs_value"] = round(extras["epoch"]["images_per_s"] / line["value"], 4)
+        if ddp_info is not None:
+            line["ddp"] = ddp_info
         line.update(extras)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(host)

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcamo_fusion.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 FWD_INFERENCE = 1
 FLAG_ATTN_MAPS = 2
 SUMSQ_FLOATS = 257
@@ -21,7 +21,7 @@ PREC_F32, PREC_BF16 = 0, 1
 NPARAMS_CROSS, NPARAMS_LATE = 44, 22
 
 # every symbol include/camo_fusion.h declares
-SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_batch_desc_bytes", "camo_prepare_batch", "camo_forward", "camo_forward_cached", "camo_backward", "camo_forward_loss_backward",
+SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_batch_desc_bytes", "camo_prepare_batch", "camo_gather_batch", "camo_forward", "camo_forward_cached", "camo_backward", "camo_forward_loss_backward",
            "camo_loss", "camo_grad_sumsq", "camo_clip_adamw", "camo_shadow_bytes", "camo_clip_adamw_shadows", "camo_debug_gemm", "camo_debug_gemm16", "camo_debug_ws_offset",
            "camo_debug_set_option", "camo_debug_set_stamps", "camo_prof_begin", "camo_prof_end", "camo_prof_kind", "camo_tail_timeouts")
 
@@ -70,6 +70,8 @@ def lib():
     L.camo_batch_desc_bytes.argtypes = [i32, i32]
     L.camo_prepare_batch.restype = C.c_int
     L.camo_prepare_batch.argtypes = [vp, i32, i32, i32, vp, sz, vp]
+    L.camo_gather_batch.restype = C.c_int
+    L.camo_gather_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, u64, vp]
     L.camo_forward.restype = C.c_int
     L.camo_forward.argtypes = [C.POINTER(CamoDims), vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, vp, vp, i32, u64, i32, i32, vp]
     L.camo_backward.restype = C.c_int

@@ -830,6 +830,20 @@ int camo_prepare_batch(const int32_t* rg_offsets, int32_t B, int32_t T, int32_t 
   return 0;
 }
 
+int camo_gather_batch(const float* rg_all, const int64_t* sample_offsets, const float* kg_all, const int64_t* y_all, const float* e_all, const float* s_all,
+                      const int64_t* idx, int32_t B, int32_t T, int32_t rg_dim, int32_t kg_floats, float* rg_out, float* kg_out, int32_t* offsets_out,
+                      int64_t* y_out, float* e_out, float* s_out, float noise_std, uint64_t seed, void* stream) {
+  if (!rg_all || !sample_offsets || !kg_all || !y_all || !e_all || !s_all || !idx || !rg_out || !kg_out || !offsets_out || !y_out || !e_out || !s_out)
+    return fail(CAMO_E_ARG, "null pointer argument");
+  if (B < 1 || T < B) return fail(CAMO_E_ARG, "need B >= 1 and T >= B");
+  if (B > 4096 || rg_dim < 4 || (rg_dim & 3) || rg_dim > 1024 || kg_floats < 2 || (kg_floats & 1) || noise_std < 0.f)
+    return fail(CAMO_E_UNSUPPORTED, "camo_gather_batch: B <= 4096, rg_dim a multiple of 4 (<= 1024), an even number of KG floats per sample");
+  CK(launch_gather_batch(rg_all, reinterpret_cast<const long long*>(sample_offsets), kg_all, reinterpret_cast<const long long*>(y_all), e_all, s_all,
+                         reinterpret_cast<const long long*>(idx), B, T, rg_dim, kg_floats, rg_out, kg_out, offsets_out, reinterpret_cast<long long*>(y_out),
+                         e_out, s_out, noise_std, seed, static_cast<hipStream_t>(stream)), "gather batch");
+  return 0;
+}
+
 static int forward_impl(const camo_dims_t* dims, const float* const* params, const float* rg, const int32_t* rg_offsets,
                         const void* desc,
                         const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace,

@@ -29,6 +29,9 @@ int launch_prep(PrepBatch& pb, hipStream_t stream);
 
 int ln_supported(int H);
 int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int* tile_off, int4* tile_desc, int B, int ntile_max, int max_nr, hipStream_t stream);
+int launch_gather_batch(const float* rg_all, const long long* sample_off, const float* kg_all, const long long* y_all, const float* e_all, const float* s_all,
+                        const long long* idx, int B, int T, int D, int KG, float* rg_out, float* kg_out, int* off_out, long long* y_out, float* e_out,
+                        float* s_out, float noise_std, unsigned long long seed, hipStream_t stream);
 int launch_ln_fwd(const LnSeg& s0, const LnSeg& s1, int H, hipStream_t stream);
 int launch_ln_bwd(const LnBwdSeg& s0, const LnBwdSeg& s1, int H, hipStream_t stream);
 int launch_seg_mean(const SegMean* segs, int nseg, int B, int max_rows, hipStream_t stream);

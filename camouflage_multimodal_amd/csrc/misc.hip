@@ -8,20 +8,18 @@
 
 namespace {
 
-// ---------------------------------------------------------------- row -> sample map
-__global__ void rowmap_kernel(const int* __restrict__ offs, int* __restrict__ row_sample,
-                              float* __restrict__ inv_nr) {
-  const int b = blockIdx.y;
-  const int r0 = offs[b], nr = offs[b + 1] - r0;
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < nr) row_sample[r0 + r] = b;
-  if (r == 0) inv_nr[b] = 1.0f / (float)nr;
-}
-
-// first 32-row tile of every sample (fused_rows.hip tiles a sample's rows in 32s): exclusive scan of ceil(Nr / 32)
-__global__ __launch_bounds__(256) void tileoff_kernel(const int* __restrict__ offs, int* __restrict__ tile_off, int B) {
+// ---------------------------------------------------------------- batch descriptor
+// row -> sample map, 1 / Nr per sample, first 32-row tile of every sample (fused_rows.hip tiles a sample's rows in 32s: exclusive scan
+// of ceil(Nr / 32)) and, per 32-row tile, {sample, first packed row, rows in the tile, 1 / Nr}; sample = -1 for the unused tail of
+// the table (the launches size their tile range by the bound T / 32 + B).
+// One launch: block k covers packed rows [256 k, 256 k + 256) and tiles [8 k', ...).  The scan of the B
+// tile counts is repeated by every block (B values, 256 threads: cheaper than a second launch behind a single-block scan).
+__global__ __launch_bounds__(256) void batchdesc_kernel(const int* __restrict__ offs, int* __restrict__ row_sample, float* __restrict__ inv_nr,
+                                                        int* __restrict__ tile_off, int4* __restrict__ tile_desc, int B, int ntile_max) {
   __shared__ int part[256];
+  __shared__ int total_s;
   const int t = threadIdx.x, per = (B + 255) / 256, b0 = min(B, t * per), b1 = min(B, b0 + per);
+  const int T = offs[B];
   int s = 0;
   for (int b = b0; b < b1; ++b) s += (offs[b + 1] - offs[b] + 31) >> 5;
   part[t] = s;
@@ -29,27 +27,109 @@ __global__ __launch_bounds__(256) void tileoff_kernel(const int* __restrict__ of
   if (t == 0) {
     int acc = 0;
     for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = acc; acc += v; }
-    tile_off[B] = acc;
+    total_s = acc;
   }
   __syncthreads();
-  int acc = part[t];
-  for (int b = b0; b < b1; ++b) { tile_off[b] = acc; acc += (offs[b + 1] - offs[b] + 31) >> 5; }
+  const int ntiles = total_s;
+  if (blockIdx.x == 0) {
+    int acc = part[t];
+    for (int b = b0; b < b1; ++b) { tile_off[b] = acc; acc += (offs[b + 1] - offs[b] + 31) >> 5; }
+    if (t == 0) tile_off[B] = ntiles;
+    for (int b = t; b < B; b += 256) inv_nr[b] = 1.0f / (float)(offs[b + 1] - offs[b]);
+  }
+  // rows: sample of packed row r by binary search over the offsets
+  const int r = blockIdx.x * 256 + t;
+  if (r < T) {
+    int lo = 0, hi = B - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (offs[mid] <= r) lo = mid; else hi = mid - 1; }
+    row_sample[r] = lo;
+  }
+  // tiles: the grid has >= ntile_max / 8 blocks (32 ntile_max rows), so 8 tiles per block cover the table; thread t < 8 takes one
+  if (t < 8) {
+    const int tl = blockIdx.x * 8 + t;
+    if (tl < ntile_max) {
+      int4 d = make_int4(-1, 0, 0, 0);
+      if (tl < ntiles) {
+        // sample of tile tl: the scan gives tile offsets per thread chunk; search the chunk starts, then walk the chunk
+        int c = 0;
+        for (int i = 1; i < 256; ++i) if (part[i] <= tl && min(B, i * per) < B) c = i;      // (last chunk whose first tile is <= tl)
+        int b = min(B - 1, c * per), acc = part[c];
+        while (b + 1 < B) { const int n = (offs[b + 1] - offs[b] + 31) >> 5; if (acc + n > tl) break; acc += n; ++b; }
+        const int r0 = offs[b] + 32 * (tl - acc), nr = offs[b + 1] - offs[b];
+        d = make_int4(b, r0, min(32, offs[b + 1] - r0), __float_as_int(1.0f / (float)nr));
+      }
+      tile_desc[tl] = d;
+    }
+  }
 }
 
-// per 32-row tile of the fused kernels: {sample, first packed row, rows in the tile, 1 / Nr}; sample = -1 for the unused tail
-// of the table (the launches size their tile range by the bound T / 32 + B)
-__global__ __launch_bounds__(256) void tiledesc_kernel(const int* __restrict__ offs, const int* __restrict__ tile_off, int4* __restrict__ tile_desc,
-                                                       int B, int ntile_max) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= ntile_max) return;
-  int4 d = make_int4(-1, 0, 0, 0);
-  if (t < tile_off[B]) {
-    int lo = 0, hi = B - 1;
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_off[mid] <= t) lo = mid; else hi = mid - 1; }
-    const int r0 = offs[lo] + 32 * (t - tile_off[lo]), nr = offs[lo + 1] - offs[lo];
-    d = make_int4(lo, r0, min(32, offs[lo + 1] - r0), __float_as_int(1.0f / (float)nr));
+// ---------------------------------------------------------------- minibatch gather out of a device-resident dataset
+// The reference's DataLoader step (train_multimodal.py:385-395: WeightedRandomSampler indices -> samples) plus its training-time
+// augmentation (:173-175: with probability 1/2 per sample, N(0, 0.01^2) noise on both streams) as ONE launch: the packed row
+// offsets of the minibatch, its RG rows, KG rows and labels.  Row blocks take 64 packed rows each (every block scans the B row
+// counts itself); one further block per sample copies the KG rows and the labels.
+constexpr int GATHER_ROWS = 64;
+constexpr int GATHER_MAXB = 4096;
+__device__ __forceinline__ float2 gather_noise(uint32_t a, uint32_t b, float std) {       // two N(0, std^2) values (Box-Muller)
+  const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+  const float r = std * sqrtf(-2.0f * __logf(u1));
+  float sn, cs;
+  __sincosf(6.28318530718f * u2, &sn, &cs);
+  return make_float2(r * cs, r * sn);
+}
+__global__ __launch_bounds__(256) void gather_batch_kernel(const float* __restrict__ rg_all, const long long* __restrict__ sample_off, const float* __restrict__ kg_all,
+                                                          const long long* __restrict__ y_all, const float* __restrict__ e_all, const float* __restrict__ s_all,
+                                                          const long long* __restrict__ idx, int B, int T, int D, int KG, int row_blocks,
+                                                          float* __restrict__ rg_out, float* __restrict__ kg_out, int* __restrict__ off_out,
+                                                          long long* __restrict__ y_out, float* __restrict__ e_out, float* __restrict__ s_out,
+                                                          float noise_std, uint32_t seed_lo, uint32_t seed_hi) {
+  __shared__ int off[GATHER_MAXB + 1];
+  __shared__ int part[256];
+  const int t = threadIdx.x;
+  if ((int)blockIdx.x >= row_blocks) {                       // one block per sample: KG rows, labels
+    const int b = (int)blockIdx.x - row_blocks;
+    const long long src = idx[b];
+    const bool aug = noise_std > 0.f && (fmix32((uint32_t)b * 0x9E3779B9u + seed_lo) ^ seed_hi) >> 31;
+    for (int c = t; c < KG / 2; c += 256) {
+      float2 v = *reinterpret_cast<const float2*>(kg_all + src * KG + 2 * c);
+      if (aug) { const float2 n = gather_noise(fmix32(0x51ED270Bu + (uint32_t)(b * KG + 2 * c) + seed_lo) ^ seed_hi, fmix32(0x2545F491u + (uint32_t)(b * KG + 2 * c) + seed_hi) ^ seed_lo, noise_std); v.x += n.x; v.y += n.y; }
+      *reinterpret_cast<float2*>(kg_out + (size_t)b * KG + 2 * c) = v;
+    }
+    if (t == 0) { y_out[b] = y_all[src]; e_out[b] = e_all[src]; s_out[b] = s_all[src]; }
+    return;
   }
-  tile_desc[t] = d;
+  // packed offsets: exclusive scan of the samples' row counts
+  const int per = (B + 255) / 256, b0 = min(B, t * per), b1 = min(B, b0 + per);
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) { const long long i = idx[b]; sum += (int)(sample_off[i + 1] - sample_off[i]); }
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = acc; acc += v; } off[B] = acc; }
+  __syncthreads();
+  {
+    int acc = part[t];
+    for (int b = b0; b < b1; ++b) { off[b] = acc; const long long i = idx[b]; acc += (int)(sample_off[i + 1] - sample_off[i]); }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) for (int b = t; b <= B; b += 256) off_out[b] = off[b];
+  const int lanes = D / 4, rpp = 256 / lanes;                // float4 lanes per row, rows per pass
+  const int lr = t / lanes, lc = t % lanes;
+  if (lr >= rpp) return;
+  for (int r0 = 0; r0 < GATHER_ROWS; r0 += rpp) {
+    const int r = (int)blockIdx.x * GATHER_ROWS + r0 + lr;
+    if (r >= T || r >= off[B]) break;
+    int lo = 0, hi = B - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (off[mid] <= r) lo = mid; else hi = mid - 1; }
+    const long long srow = sample_off[idx[lo]] + (r - off[lo]);
+    float4 v = *reinterpret_cast<const float4*>(rg_all + srow * D + 4 * lc);
+    if (noise_std > 0.f && ((fmix32((uint32_t)lo * 0x9E3779B9u + seed_lo) ^ seed_hi) >> 31)) {
+      const uint32_t e0 = (uint32_t)r * (uint32_t)D + 4u * (uint32_t)lc;
+      const float2 n0 = gather_noise(fmix32(e0 + seed_lo) ^ seed_hi, fmix32(e0 + 0x68E31DA4u + seed_hi) ^ seed_lo, noise_std);
+      const float2 n1 = gather_noise(fmix32(e0 + 2u + seed_lo) ^ seed_hi, fmix32(e0 + 2u + 0x68E31DA4u + seed_hi) ^ seed_lo, noise_std);
+      v.x += n0.x; v.y += n0.y; v.z += n1.x; v.w += n1.y;
+    }
+    *reinterpret_cast<float4*>(rg_out + (size_t)r * D + 4 * lc) = v;
+  }
 }
 
 // ---------------------------------------------------------------- LayerNorm forward
@@ -1035,6 +1115,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   }
 }
 
+// One element of clip + AdamW (torch semantics: decoupled decay first, denom = sqrt(v)/sqrt(bc2) + eps, p -= lr/bc1 * m/denom).
+// Shared by both optimizer kernels and compiled WITHOUT floating-point contraction: the two kernels must produce bit-identical
+// parameters (a test holds them to it), and whether hipcc fuses a multiply-add depends on the code around it.
+__device__ __forceinline__ void adamw_update(float& pi, float& gi, float& mi, float& vi, bool skip_step, float coef, float decay, float b1, float omb1,
+                                             float b2, float omb2, float step, float inv_sqrt_bc2, float eps, int zero_grads) {
+#pragma clang fp contract(off)
+  if (skip_step) { if (zero_grads) gi = 0.f; return; }
+  gi *= coef;
+  pi *= decay;
+  mi = mi * b1 + gi * omb1;
+  vi = vi * b2 + gi * gi * omb2;
+  pi -= step * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  if (zero_grads) gi = 0.f;
+}
+
 // clip_grad_norm_(max_norm) then AdamW (torch semantics: decoupled decay first,
 // denom = sqrt(v)/sqrt(bc2) + eps, p -= lr/bc1 * m/denom)
 __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, float* __restrict__ g,
@@ -1062,13 +1157,7 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
   float4* p4 = reinterpret_cast<float4*>(p); float4* g4 = reinterpret_cast<float4*>(g);
   float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
   auto upd = [&](float& pi, float& gi, float& mi, float& vi) {
-    if (skip_step) { if (zero_grads) gi = 0.f; return; }
-    gi *= coef;
-    pi *= decay;
-    mi = mi * b1 + gi * omb1;
-    vi = vi * b2 + gi * gi * omb2;
-    pi -= step * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
-    if (zero_grads) gi = 0.f;
+    adamw_update(pi, gi, mi, vi, skip_step, coef, decay, b1, omb1, b2, omb2, step, inv_sqrt_bc2, eps, zero_grads);
   };
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
@@ -1127,6 +1216,15 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepBatch pb) {
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
+int launch_gather_batch(const float* rg_all, const long long* sample_off, const float* kg_all, const long long* y_all, const float* e_all, const float* s_all,
+                        const long long* idx, int B, int T, int D, int KG, float* rg_out, float* kg_out, int* off_out, long long* y_out, float* e_out,
+                        float* s_out, float noise_std, unsigned long long seed, hipStream_t stream) {
+  if (B < 1 || B > GATHER_MAXB || T < B || D < 4 || (D & 3) || D > 1024 || KG < 2 || (KG & 1)) return (int)hipErrorInvalidValue;
+  const int row_blocks = (T + GATHER_ROWS - 1) / GATHER_ROWS;
+  hipLaunchKernelGGL(gather_batch_kernel, dim3(row_blocks + B), dim3(256), 0, stream, rg_all, sample_off, kg_all, y_all, e_all, s_all, idx, B, T, D, KG, row_blocks,
+                     rg_out, kg_out, off_out, y_out, e_out, s_out, noise_std, (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32));
+  return (int)hipGetLastError();
+}
 int launch_prep(PrepBatch& pb, hipStream_t stream) {
   int total = 0;
   for (int i = 0; i < pb.n; ++i) {
@@ -1142,9 +1240,12 @@ int launch_prep(PrepBatch& pb, hipStream_t stream) {
 }
 
 int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int* tile_off, int4* tile_desc, int B, int ntile_max, int max_nr, hipStream_t stream) {
-  hipLaunchKernelGGL(rowmap_kernel, dim3((max_nr + 255) / 256, B), dim3(256), 0, stream, offs, row_sample, inv_nr);
-  hipLaunchKernelGGL(tileoff_kernel, dim3(1), dim3(256), 0, stream, offs, tile_off, B);
-  hipLaunchKernelGGL(tiledesc_kernel, dim3((ntile_max + 255) / 256), dim3(256), 0, stream, offs, tile_off, tile_desc, B, ntile_max);
+  (void)max_nr;
+  // ONE launch (a fresh descriptor per training step when every minibatch has its own Nr tuple): every block scans the B tile
+  // counts itself, then writes its 256 rows' sample ids and its share of the tile table
+  const int T_upper = 32 * ntile_max;                                   // >= T (ntile_max = T / 32 + B)
+  const int blocks = (T_upper + 255) / 256;
+  hipLaunchKernelGGL(batchdesc_kernel, dim3(blocks), dim3(256), 0, stream, offs, row_sample, inv_nr, tile_off, tile_desc, B, ntile_max);
   return (int)hipGetLastError();
 }
 
@@ -1308,13 +1409,7 @@ __global__ __launch_bounds__(256) void adamw_shadow_kernel(float* __restrict__ p
   const bool skip_step = !(total < __builtin_huge_valf());
   const float decay = 1.0f - lr * wd, step = lr * inv_bc1, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   auto upd = [&](float& pi, float& gi, float& mi, float& vi) {
-    if (skip_step) { if (zero_grads) gi = 0.f; return; }
-    gi *= coef;
-    pi *= decay;
-    mi = mi * b1 + gi * omb1;
-    vi = vi * b2 + gi * gi * omb2;
-    pi -= step * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
-    if (zero_grads) gi = 0.f;
+    adamw_update(pi, gi, mi, vi, skip_step, coef, decay, b1, omb1, b2, omb2, step, inv_sqrt_bc2, eps, zero_grads);
   };
   if (is_tile) {
     const AdamShadowBlock& B = a.blk[bi];

@@ -26,10 +26,42 @@ class GradAllReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._timing = None                     # list of per-call event tuples while timing is on (bench.py's ddp diagnostics)
+
+    def enable_timing(self, on=True):
+        """Record device events around every all-reduce from now on (``timing_summary`` reads them).  Costs a few event records
+        per step; off in product runs."""
+        self._timing = [] if on else None
+
+    @staticmethod
+    def _ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def timing_summary(self):
+        """Mean microseconds per all-reduce over the timed calls (synchronises).  Buckets: ``a`` = the overlapped tail bucket
+        (BucketedGradAllReducer), ``b`` = the rest / the single all-reduce.  ``overlap_fraction``: share of bucket a's duration that
+        had elapsed when the backward kernels of the step were done (1.0 = fully hidden behind them)."""
+        if not self._timing:
+            return None
+        torch.cuda.synchronize()
+        out = {"calls": len(self._timing)}
+        a = [t for t in self._timing if t[0] is not None]
+        if a:
+            dur = [t[0].elapsed_time(t[1]) * 1e3 for t in a]
+            hid = [min(max(t[0].elapsed_time(t[2]) * 1e3, 0.0), d) / max(d, 1e-9) for t, d in zip(a, dur)]
+            out["bucket_a_us"] = round(sum(dur) / len(dur), 2); out["overlap_fraction"] = round(sum(hid) / len(hid), 4)
+        b = [t[3].elapsed_time(t[4]) * 1e3 for t in self._timing]
+        out["bucket_b_us"] = round(sum(b) / len(b), 2)
+        return out
 
     def __call__(self, flat_grads: torch.Tensor):
         if self.world > 1:
+            t0 = self._ev() if self._timing is not None and flat_grads.is_cuda else None
             dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+            if t0 is not None:
+                self._timing.append((None, None, None, t0, self._ev()))
         return flat_grads
 
 
@@ -68,11 +100,19 @@ class BucketedGradAllReducer(GradAllReducer):
             return super().__call__(flat_grads)
         head, tail = flat_grads[:split], flat_grads[split:]
         if flat_grads.is_cuda and self._event is not None:
+            timed = self._timing is not None
             self._side.wait_event(self._event)
             with torch.cuda.stream(self._side):
+                a0 = self._ev() if timed else None
                 wa = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if timed:
+                    wa.wait()                                # (orders the side stream behind the collective: its end event)
+                    a1 = self._ev()
+            bwd_done = self._ev() if timed else None         # launch stream: every backward kernel of the step is in front of this
             wb = dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             wa.wait(); wb.wait()
+            if timed:
+                self._timing.append((a0, a1, bwd_done, bwd_done, self._ev()))
         else:
             dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group)
@@ -108,10 +148,17 @@ class OneShotGradAllReducer(GradAllReducer):
         return flat_grads
 
 
-def broadcast_parameters(flat_params: torch.Tensor, src=0, group=None):
-    """Make every rank start from rank ``src``'s parameters (one flat broadcast)."""
+def broadcast_parameters(flat_params, src=0, group=None):
+    """Make every rank start from rank ``src``'s parameters (one flat broadcast).  ``flat_params``: the flat buffer, or the
+    ``FusionEngine`` that owns it -- pass the engine whenever weight shadows may exist: a collective that fills the buffer in place
+    is not guaranteed to bump torch's version counter on the receiving ranks, so the shadows are invalidated explicitly."""
+    eng = None
+    if not isinstance(flat_params, torch.Tensor):
+        eng, flat_params = flat_params, flat_params.flat_params
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat_params, src=src, group=group)
+    if eng is not None:
+        eng.invalidate_shadows()
     return flat_params
 
 
@@ -135,7 +182,10 @@ def sharded_weighted_sampler(weights, num_samples, epoch, world, rank, seed=0):
     a common seed and keeps its strided share, so the union over ranks is one reference epoch."""
     g = torch.Generator()
     g.manual_seed(seed * 1000003 + epoch)
-    idx = torch.multinomial(torch.as_tensor(weights, dtype=torch.double), num_samples, replacement=True, generator=g)
+    # every rank must cut the SAME number of minibatches (each optimizer step is a collective): the draw is rounded up to a
+    # multiple of the world size, so the strided shares have equal length
+    total = -(-int(num_samples) // world) * world
+    idx = torch.multinomial(torch.as_tensor(weights, dtype=torch.double), total, replacement=True, generator=g)
     return idx[rank::world].tolist()
 
 

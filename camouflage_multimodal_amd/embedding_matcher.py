@@ -94,6 +94,7 @@ class DeviceResidentDataset:
         off = torch.zeros(len(samples) + 1, dtype=torch.int64)
         off[1:] = torch.tensor(self.nrs).cumsum(0)
         self.offsets = off
+        self.offsets_dev = off.to(device)
         self.mask_label = torch.tensor([int(s["mask_label"]) for s in samples], dtype=torch.int64, device=device)
         self.edge_label = torch.tensor([float(s["edge_label"]) for s in samples], dtype=torch.float32, device=device)
         self.score_label = torch.tensor([float(s["score_label"]) for s in samples], dtype=torch.float32, device=device)
@@ -101,21 +102,66 @@ class DeviceResidentDataset:
         self.device = device
         self._gen = torch.Generator(device=device if str(device).startswith("cuda") else "cpu")
         self._gen.manual_seed(seed)
+        self._seed, self._calls = int(seed), 0
 
     def __len__(self):
         return len(self.nrs)
 
-    def batch(self, indices):
-        """-> (rg_packed, nrs, kg, mask_label, edge_label, score_label) for NativeTrainer.step."""
+    def batch(self, indices, idx_dev=None):
+        """-> (rg_packed, nrs, kg, mask_label, edge_label, score_label) for NativeTrainer.step.  On a HIP device the whole
+        gather -- packed rows, KG rows, labels, the minibatch's packed offsets and the augmentation -- is ONE launch
+        (``camo_gather_batch``); the only host->device traffic is the index vector, and not even that when the caller hands
+        the indices as a device tensor too (``idx_dev``: e.g. a slice of an epoch's draw copied over once).  ``nrs`` carries
+        the offsets as ``nrs.offsets_dev`` for ``FusionEngine.make_batch``."""
         indices = [int(i) for i in indices]
-        nrs = [self.nrs[i] for i in indices]
-        rows = torch.cat([torch.arange(int(self.offsets[i]), int(self.offsets[i + 1])) for i in indices]).to(self.device)
-        idx = torch.tensor(indices, device=self.device)
+        nrs = NrList(self.nrs[i] for i in indices)
+        T, B = sum(nrs), len(indices)
+        idx = idx_dev if idx_dev is not None else torch.tensor(indices, device=self.device)
+        if self.rg.is_cuda and B <= 4096:
+            from . import _lib
+            from .engine import _stream_ptr
+            dev = self.rg.device
+            rg = torch.empty(T, self.rg.shape[1], dtype=torch.float32, device=dev)
+            kg = torch.empty(B, self.kg.shape[1], self.kg.shape[2], dtype=torch.float32, device=dev)
+            offs = torch.empty(B + 1, dtype=torch.int32, device=dev)
+            y = torch.empty(B, dtype=torch.int64, device=dev); e = torch.empty(B, dtype=torch.float32, device=dev); s = torch.empty_like(e)
+            self._calls += 1
+            with (torch.cuda.device(dev) if torch.cuda.current_device() != dev.index else _NULLCTX):
+                _lib.check(_lib.lib().camo_gather_batch(self.rg.data_ptr(), self.offsets_dev.data_ptr(), self.kg.data_ptr(), self.mask_label.data_ptr(),
+                                                        self.edge_label.data_ptr(), self.score_label.data_ptr(), idx.data_ptr(), B, T, self.rg.shape[1],
+                                                        self.kg.shape[1] * self.kg.shape[2], rg.data_ptr(), kg.data_ptr(), offs.data_ptr(), y.data_ptr(),
+                                                        e.data_ptr(), s.data_ptr(), 0.01 if self.augment else 0.0,
+                                                        (self._seed * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF,
+                                                        _stream_ptr(dev)), "camo_gather_batch")
+            nrs.offsets_dev = offs
+            return rg, nrs, kg, y, e, s
+        # host-side datasets (tests on CPU): the same gather with torch index ops
+        starts = self.offsets_dev[idx]
+        lens = self.offsets_dev[idx + 1] - starts
+        offs = torch.zeros(B + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(lens, 0, out=offs[1:])
+        # packed row r of the minibatch = dataset row starts[b] + (r - offs[b]) for the sample b it belongs to
+        rows = torch.arange(T, device=self.device) + torch.repeat_interleave(starts - offs[:-1], lens, output_size=T)
+        nrs.offsets_dev = offs.to(torch.int32)
         rg = self.rg.index_select(0, rows)
         kg = self.kg.index_select(0, idx)
         if self.augment:
-            coin = torch.rand(len(indices), generator=self._gen, device=self.device) > 0.5
-            per_row = torch.repeat_interleave(coin, torch.tensor(nrs, device=self.device))
+            coin = torch.rand(B, generator=self._gen, device=self.device) > 0.5
+            per_row = torch.repeat_interleave(coin, lens, output_size=T)
             rg = rg + torch.randn(rg.shape, generator=self._gen, device=self.device) * 0.01 * per_row[:, None]
             kg = kg + torch.randn(kg.shape, generator=self._gen, device=self.device) * 0.01 * coin[:, None, None]
         return rg, nrs, kg, self.mask_label[idx], self.edge_label[idx], self.score_label[idx]
+
+
+class _NullCtx:
+    def __enter__(self): return None
+    def __exit__(self, *a): return False
+
+
+_NULLCTX = _NullCtx()
+
+
+class NrList(list):
+    """The per-sample node counts of a packed minibatch (host ints) plus, as ``offsets_dev``, their packed row offsets as an
+    int32 device tensor [B + 1] when the producer already has them there."""
+    offsets_dev = None

@@ -228,7 +228,7 @@ def train_epoch_fixed(model, dataloader, optimizer, device, epoch):
     for batch in dataloader:
         rg, nrs, kg, y, e, s = batch if isinstance(batch, tuple) else pack_samples(batch, device)
         terms, pred = trainer.step(rg, nrs, kg, y, e, s)
-        terms_all.append(terms.sum(dim=1)); preds.append(pred); labels.append(y)
+        terms_all.append(terms); preds.append(pred); labels.append(y)          # (nothing is reduced or read back inside the loop)
     losses = torch.cat(terms_all); preds = torch.cat(preds).cpu().long(); labels = torch.cat(labels).cpu()
     return float(losses.sum().item()) / max(len(preds), 1), calculate_f1_score(preds, labels)
 
@@ -279,6 +279,13 @@ def fit(config, train_loader, val_loader, device="cuda", grad_allreduce=None, lo
     model.set_precision(config.get("precision", model.precision))     # not a reference key: "f32" (default) or "bf16"
     trainer = NativeTrainer(model, lr=config["learning_rate"], weight_decay=config["weight_decay"],
                             grad_allreduce=grad_allreduce)
+    world = getattr(grad_allreduce, "world", 1) if grad_allreduce is not None else 1
+    rank = getattr(grad_allreduce, "rank", 0) if grad_allreduce is not None else 0
+    if world > 1:
+        # replicas start from rank 0's parameters (after that the redundant, deterministic clip + AdamW keeps them bit-identical);
+        # only rank 0 writes the checkpoint and the history file
+        from .ddp import broadcast_parameters
+        broadcast_parameters(model._engine, group=getattr(grad_allreduce, "group", None))
     history = {k: [] for k in ("train_loss", "val_loss", "train_f1_class_0", "train_f1_class_1", "train_f1_avg",
                                "val_f1_class_0", "val_f1_class_1", "val_f1_avg", "val_acc_0", "val_acc_1")}
     best, patience, max_patience = 0.0, 0, 15
@@ -301,14 +308,16 @@ def fit(config, train_loader, val_loader, device="cuda", grad_allreduce=None, lo
             f"val loss {vl:.4f} F1_C1 {float(vf1['f1_class_1']):.3f} acc0 {a0:.1f}% acc1 {a1:.1f}%")
         if float(vf1["f1_class_1"]) > best:
             best, patience = float(vf1["f1_class_1"]), 0
-            save_best_checkpoint(os.path.join(config["checkpoint_dir"], "multimodal_best_fixed.pth"), model, trainer,
-                                 epoch, vl, vf1, a0, a1, config)
+            if rank == 0:
+                save_best_checkpoint(os.path.join(config["checkpoint_dir"], "multimodal_best_fixed.pth"), model, trainer,
+                                     epoch, vl, vf1, a0, a1, config)
         else:
             patience += 1
             if patience >= max_patience:
                 break
-    with open(os.path.join(config["checkpoint_dir"], "training_history_fixed.json"), "w") as f:
-        json.dump(history, f, indent=2)
+    if rank == 0:
+        with open(os.path.join(config["checkpoint_dir"], "training_history_fixed.json"), "w") as f:
+            json.dump(history, f, indent=2)
     return model, history
 
 
@@ -336,8 +345,10 @@ def train_multimodal_fixed(config, device="cuda", seed=0, grad_allreduce=None, w
     bs = int(config["batch_size"])
 
     def train_loader(epoch):
+        # (a generator: one gathered minibatch alive at a time, not a whole epoch of copies; equal share lengths on every rank)
         draw = sharded_weighted_sampler(train_w, len(train_w), epoch, world, rank, seed=seed)
-        return [train_ds.batch(draw[i:i + bs]) for i in range(0, len(draw), bs)]
+        draw_dev = torch.tensor(draw, device=device)          # the epoch's indices go over once
+        return (train_ds.batch(draw[i:i + bs], idx_dev=draw_dev[i:i + bs]) for i in range(0, len(draw), bs))
 
     val_loader = [val_ds.batch(list(range(i, min(i + bs, len(val_ds))))) for i in range(0, len(val_ds), bs)]
     log(f"Train: {train_size} | Val: {n - train_size} | aggressive oversampling (5x minority class)")

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CAMO_ABI_VERSION 7
+#define CAMO_ABI_VERSION 8
 
 enum {
   CAMO_OK = 0,
@@ -114,6 +114,22 @@ size_t camo_workspace_bytes(const camo_dims_t* dims, int32_t B, int32_t T, int32
 size_t camo_batch_desc_bytes(int32_t B, int32_t T);
 int camo_prepare_batch(const int32_t* rg_offsets, int32_t B, int32_t T, int32_t max_nr,
                        void* batch_desc, size_t batch_desc_bytes, void* stream);
+
+/* ---- minibatch out of a device-resident dataset ---------------------------
+ * Stands behind one DataLoader step of the reference's training loop (train_multimodal.py:385-395: WeightedRandomSampler
+ * indices -> collate) plus SmartMultimodalDataset.__getitem__'s augmentation (:173-175: with probability 1/2 per sample,
+ * N(0, noise_std^2) noise on both streams; the reference uses 0.01), for a dataset that lives in HBM: ONE launch, no host copy.
+ *   rg_all [rows, rg_dim], sample_offsets int64 [N+1] (first row of every sample), kg_all [N, kg_floats], y/e/s_all [N]: the dataset;
+ *   idx int64 [B] (device): the minibatch's samples; T = sum of their row counts (the host knows the counts: output sizing).
+ * Writes the packed rows rg_out [T, rg_dim], kg_out [B, kg_floats], the packed row offsets offsets_out int32 [B+1] (what
+ * camo_prepare_batch takes) and the gathered labels.  noise_std = 0: no augmentation.  The noise is a counter hash of
+ * (seed, element): like the reference's unseeded draws it is not reproducible against torch's generator, only in distribution.
+ * B <= 4096. */
+int camo_gather_batch(const float* rg_all, const int64_t* sample_offsets, const float* kg_all,
+                      const int64_t* y_all, const float* e_all, const float* s_all,
+                      const int64_t* idx, int32_t B, int32_t T, int32_t rg_dim, int32_t kg_floats,
+                      float* rg_out, float* kg_out, int32_t* offsets_out, int64_t* y_out, float* e_out, float* s_out,
+                      float noise_std, uint64_t seed, void* stream);
 
 int camo_forward(const camo_dims_t* dims, const float* const* params,
                  const float* rg, const int32_t* rg_offsets, const void* batch_desc,

@@ -76,6 +76,13 @@ def _worker(rank, world, port, q):
         gathered = [torch.zeros_like(flat_after) for _ in range(world)]
         dist.all_gather(gathered, flat_after)
         idx = sharded_weighted_sampler([1.0, 5.0, 1.0, 2.0, 1.0, 3.0, 1.0, 1.0], 12, epoch=3, world=world, rank=rank, seed=7)
+        # an epoch whose length is NOT a multiple of the world size (65 draws, 2 ranks, minibatches of 16): every rank must cut the same
+        # number of minibatches -- each optimizer step is a collective, a rank with one step more would wait forever
+        odd = sharded_weighted_sampler([1.0] * 9, 65, epoch=1, world=world, rank=rank, seed=7)
+        steps = torch.tensor([len(range(0, len(odd), 16)), len(odd)], dtype=torch.int64)
+        all_steps = [torch.zeros_like(steps) for _ in range(world)]
+        dist.all_gather(all_steps, steps)
+        assert all(torch.equal(a, all_steps[0]) for a in all_steps), all_steps
         q.put((rank, mine, flat_after.numpy(), float(norm), m.tolist(), bool(torch.equal(gathered[0], gathered[1])), idx))
     finally:
         dist.destroy_process_group()

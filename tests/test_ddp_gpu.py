@@ -59,7 +59,7 @@ def _worker(rank, world, port, q, precision, reducer="single"):
         from camouflage_multimodal_amd.ddp import BucketedGradAllReducer, GradAllReducer, broadcast_parameters, shard_by_rows
         torch.cuda.set_device(0)
         m = _build(precision)
-        broadcast_parameters(m._engine.flat_params)
+        broadcast_parameters(m._engine)
         tr = NativeTrainer(m, grad_allreduce=BucketedGradAllReducer() if reducer == "bucketed" else GradAllReducer())
         seed_folded = tr.engine._seed_base
         mine = shard_by_rows(NRS, world, rank)

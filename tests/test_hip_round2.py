@@ -370,3 +370,79 @@ def test_tail_timeout_is_not_applied(kg_real):
     torch.cuda.synchronize()
     assert torch.isfinite(terms).all() and not torch.equal(m._engine.flat_params, before)
     assert torch.isfinite(m._engine.flat_params).all()
+
+
+def test_train_multimodal_fixed_end_to_end_on_disk(tmp_path, kg_real):
+    """The reference's training driver (train_multimodal.py:347-492) from files on disk: an RG embedding dict and a KG embedding
+    dict saved with torch.save (the reference's .pt formats), three directories of ground-truth PNGs, the YAML's keys -- two
+    epochs through EmbeddingMatcher -> SmartMultimodalDataset -> 80/20 split -> weighted sampling -> device-resident minibatches
+    (a fresh Nr tuple per step) -> NativeTrainer, then the checkpoint it wrote loads into the inference path."""
+    from PIL import Image
+    from camouflage_multimodal_amd import load_multimodal_model, train_multimodal_fixed
+    names = [str(n) for n in load_golden("kg_embeddings")["names"]]
+    torch.save({n: torch.from_numpy(kg_real[i:i + 1].copy()) for i, n in enumerate(names)}, tmp_path / "kg.pt")
+    rs = np.random.RandomState(5)
+    rg, dirs = {}, {k: tmp_path / k for k in ("gt_object", "gt_instance", "gt_edge")}
+    for d in dirs.values():
+        d.mkdir()
+    for i in range(30):
+        name = f"COD10K-CAM-1-Aquatic-{i}-{'Fish' if i % 2 else 'Bird'}-{i}"
+        n = int(rs.randint(20, 90))
+        rg[name + ".jpg"] = {"node_embeddings": torch.from_numpy(OP.make_rg(n, 128, seed=700 + i)), "graph_embedding": torch.zeros(1, 128), "num_nodes": n}
+        m = np.zeros((64, 80), np.uint8)
+        if i % 3:                                                            # two thirds camouflaged (a blob), one third empty
+            m[8:8 + 30 + i % 7, 10:60] = 255
+        for k in ("gt_object", "gt_instance"):
+            Image.fromarray(m, mode="L").save(dirs[k] / f"{name}.png")
+        Image.fromarray(np.full((64, 80), 30 if i % 2 else 0, np.uint8), mode="L").save(dirs["gt_edge"] / f"{name}.png")
+    torch.save(rg, tmp_path / "rg.pt")
+    ck = tmp_path / "ckpt"
+    cfg = {"rg_embeddings_path": str(tmp_path / "rg.pt"), "kg_embeddings_path": str(tmp_path / "kg.pt"), "use_all_kg_categories": True,
+           "mask_dir": str(dirs["gt_object"]), "instance_dir": str(dirs["gt_instance"]), "edge_dir": str(dirs["gt_edge"]),
+           "model": dict(rg_dim=128, kg_dim=128, hidden_dim=256, num_heads=8, fusion_type="cross_attention", num_classes=2, dropout=0.3),
+           "epochs": 2, "batch_size": 4, "learning_rate": 5e-4, "weight_decay": 1e-4, "checkpoint_dir": str(ck), "precision": "bf16"}
+    logs = []
+    model, hist = train_multimodal_fixed(cfg, device="cuda", seed=1, log=logs.append)
+    assert len(hist["train_loss"]) == 2 and all(np.isfinite(v) for k in hist for v in hist[k])
+    assert "Train: 24 | Val: 6" in logs[0]
+    with open(ck / "training_history_fixed.json") as f:
+        assert json.load(f) == hist
+    if os.path.exists(ck / "multimodal_best_fixed.pth"):                       # (written when an epoch's validation F1 of class 1 is > 0)
+        m2, c2 = load_multimodal_model(str(ck / "multimodal_best_fixed.pth"), device="cuda")
+        assert set(model.state_dict()) == set(m2.state_dict()) and c2["model"] == cfg["model"]
+
+
+def test_gather_batch_kernel_matches_index_ops_and_augments_in_distribution():
+    """camo_gather_batch (one launch: packed rows, KG rows, labels, packed offsets, augmentation) against torch index ops on the
+    same device-resident dataset; the augmentation's statistics: about half the samples get noise, N(0, 0.01^2), on both streams."""
+    from camouflage_multimodal_amd import DeviceResidentDataset
+    rs = np.random.RandomState(2)
+    nrs_all = [int(x) for x in rs.randint(1, 200, size=300)]
+    samples = [dict(rg_node_emb=torch.from_numpy(rs.standard_normal((n, 128)).astype(np.float32)), kg_emb=torch.from_numpy(rs.standard_normal((13, 1, 128)).astype(np.float32)),
+                    mask_label=i % 2, edge_label=float(i % 3 == 0), score_label=0.01 * i) for i, n in enumerate(nrs_all)]
+    ds = DeviceResidentDataset(samples, "cuda")
+    for idx in ([5], [299, 0, 0, 17, 123, 7], [int(x) for x in rs.randint(0, 300, size=257)]):
+        rg, nrs, kg, y, e, s = ds.batch(idx)
+        torch.cuda.synchronize()
+        assert list(nrs) == [nrs_all[i] for i in idx]
+        assert nrs.offsets_dev.cpu().tolist() == [0] + list(np.cumsum(nrs))
+        assert torch.equal(rg.cpu(), torch.cat([samples[i]["rg_node_emb"] for i in idx]))
+        assert torch.equal(kg.cpu(), torch.stack([samples[i]["kg_emb"].reshape(13, 128) for i in idx]))
+        assert y.cpu().tolist() == [i % 2 for i in idx] and torch.equal(s.cpu(), torch.tensor([0.01 * i for i in idx], dtype=torch.float32))
+        dev_idx = torch.tensor(idx, device="cuda")
+        rg2, nrs2, *_ = ds.batch(idx, idx_dev=dev_idx)                          # indices handed over as a device tensor
+        assert torch.equal(rg, rg2) and list(nrs2) == list(nrs)
+    aug = DeviceResidentDataset(samples, "cuda", augment=True, seed=3)
+    idx = list(range(300))
+    rg, nrs, kg, *_ = aug.batch(idx)
+    d = (rg.cpu() - torch.cat([s_["rg_node_emb"] for s_ in samples])).numpy()
+    off = np.concatenate([[0], np.cumsum(nrs)])
+    noisy = np.array([np.abs(d[off[i]:off[i + 1]]).max() > 0 for i in range(300)])
+    assert 0.35 < noisy.mean() < 0.65                                        # a fair coin per sample
+    dk = (kg.cpu() - torch.stack([s_["kg_emb"].reshape(13, 128) for s_ in samples])).numpy()
+    assert np.array_equal(noisy, np.abs(dk).reshape(300, -1).max(1) > 0)     # the same coin for both streams
+    z = np.concatenate([d[off[i]:off[i + 1]].ravel() for i in range(300) if noisy[i]])
+    assert abs(z.mean()) < 2e-4 and abs(z.std() - 0.01) < 3e-4 and abs((np.abs(z) < 0.01).mean() - 0.6827) < 0.01
+    assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 0.01
+    rg_b, *_ = aug.batch(idx)                                                # a second draw: other noise
+    assert not torch.equal(rg, rg_b)

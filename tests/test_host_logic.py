@@ -307,3 +307,20 @@ def test_device_and_label_checks_run_before_the_abi(monkeypatch):
     m._engine.fold_rank(0); s0 = m._engine._seed_base
     m._engine.fold_rank(1); s1 = m._engine._seed_base
     assert len({b0, s0, s1}) == 3                                            # ranks draw different dropout streams
+
+
+def test_device_resident_dataset_batch_index_is_built_without_host_loops():
+    """DeviceResidentDataset.batch gathers a minibatch with index arithmetic on the dataset's device (here: the CPU) and hands
+    the packed offsets on as ``nrs.offsets_dev``: same rows as the per-sample slices, int32 offsets = cumsum of the counts."""
+    import torch
+    from camouflage_multimodal_amd import DeviceResidentDataset
+    rs = np.random.RandomState(0)
+    samples = [dict(rg_node_emb=torch.from_numpy(rs.standard_normal((n, 8)).astype(np.float32)), kg_emb=torch.from_numpy(rs.standard_normal((3, 1, 8)).astype(np.float32)),
+                    mask_label=i % 2, edge_label=float(i % 3 == 0), score_label=0.1 * i) for i, n in enumerate([5, 1, 7, 3, 4, 2])]
+    ds = DeviceResidentDataset(samples, "cpu")
+    idx = [4, 1, 1, 5, 0]
+    rg, nrs, kg, y, e, s = ds.batch(idx)
+    assert list(nrs) == [4, 1, 1, 2, 5] and nrs.offsets_dev.dtype == torch.int32 and nrs.offsets_dev.tolist() == [0, 4, 5, 6, 8, 13]
+    assert torch.equal(rg, torch.cat([samples[i]["rg_node_emb"] for i in idx]))
+    assert torch.equal(kg, torch.stack([samples[i]["kg_emb"].reshape(3, 8) for i in idx]))
+    assert y.tolist() == [0, 1, 1, 1, 0]
