@@ -41,6 +41,7 @@ struct FrontArgs {
   void* zero_ptr[FUSED_FRONT_MAXZ]; unsigned zero_bytes[FUSED_FRONT_MAXZ]; int nzero;
   // wide tiles only: weight-shadow jobs that ride in extra blocks behind the tile blocks (the per-sample tail's hi / lo planes,
   // tail_wide.h: rebuilt by every call that takes the wide tail, so they need no validity tracking)
+  int split3;                                  // wide tiles only: three blocks per tile, one in-projection pass each
   ShadowJob xjob[FUSED_FRONT_MAXX]; int nxjob; int xchunks; int xblock0;       // (xchunks, xblock0: filled by the launcher)
 };
 int launch_fused_front(FrontArgs& a, int variant, hipStream_t stream);   // variant: 0 <depth 12>, 1 <depth 12, rotated k order> (default), 2 <depth 16, rotated>

@@ -163,10 +163,15 @@ __global__ __launch_bounds__(NTH, 2) void front8_kernel(const FrontArgs a) {
     shadow_chunk(a.xjob[ji], gid - a.xjob[ji].chunk_begin);
     return;
   }
-  const FrontStream& S = a.s[(int)blockIdx.x >= a.s[1].tile_begin ? 1 : 0];
+  // split3 (the KG rows' launch in front of the one-launch RG forward): three blocks per tile, one in-projection pass each (the
+  // projection is repeated) -- a third of the serial chain per block for rows that are few and on the critical path
+  const int blk = a.split3 ? (int)blockIdx.x / 3 : (int)blockIdx.x;
+  const int mypass = a.split3 ? (int)blockIdx.x - 3 * blk : 0;
+  const int p_begin = a.split3 ? mypass : 0, p_end = a.split3 ? mypass + 1 : 3;
+  const FrontStream& S = a.s[blk >= a.s[1].tile_begin ? 1 : 0];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row0 = ((int)blockIdx.x - S.tile_begin) * (32 * RT);
+  const int row0 = (blk - S.tile_begin) * (32 * RT);
   const int nrows = min(32 * RT, S.M - row0);
   char* bufR = smem + Cfg::BUFR; char* bufS = smem + Cfg::BUFS; char* bufX = bufS;
   float* cst = reinterpret_cast<float*>(smem + Cfg::CONSTS);
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(NTH, 2) void front8_kernel(const FrontArgs a) {
       if (!ok) { p0 = u32x4{0u, 0u, 0u, 0u}; p1 = p0; }
       *reinterpret_cast<u32x4*>(bufX + r * PX + 32 * c) = p0;
       *reinterpret_cast<u32x4*>(bufX + r * PX + 32 * c + 16) = p1;
-      if (a.save && ok) {
+      if (a.save && ok && mypass == 0) {
         u32x4* d = reinterpret_cast<u32x4*>(S.X16 + (size_t)(row0 + r) * 128 + 16 * c);
         d[0] = p0; d[1] = p1;
       }
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(NTH, 2) void front8_kernel(const FrontArgs a) {
     f32x16 acc[RT][1];
     clear_acc(acc);
     st0.template run<true>(bufX + l31 * PX + 16 * h, 32 * PX, acc);
-    st1.prefetch(w1base);
+    st1.prefetch(w1base + 64 * p_begin);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int c0 = 32 * w8 + 8 * g + 4 * h;
@@ -230,10 +235,11 @@ __global__ __launch_bounds__(NTH, 2) void front8_kernel(const FrontArgs a) {
   char* strip = bufS + w8 * (32 * RT * PS);
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
+    if (p < p_begin || p >= p_end) continue;                     // (block-uniform)
     f32x16 acc[RT][1];
     clear_acc(acc);
     st1.template run<true>(bufR + l31 * PR + 16 * h, 32 * PR, acc);
-    if (p + 1 < 3) st1.prefetch(w1base + 64 * (p + 1));
+    if (p + 1 < p_end) st1.prefetch(w1base + 64 * (p + 1));
     const int tg = 3 * w8 + p;                                   // wave-uniform
     const float sc = tg < 8 ? a.qscale : 1.0f;
 #pragma unroll
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(NTH, 2) void front8_kernel(const FrontArgs a) {
     if (p == 1) stamp(a.stamps, 4);
   }
   stamp(a.stamps, 5);
-  copy_out<5, true>(bufR, PR, 0, S.R16, 256, row0, nrows, 32 * RT);
+  if (mypass == 0) copy_out<5, true>(bufR, PR, 0, S.R16, 256, row0, nrows, 32 * RT);
   for (int zi = 0; zi < a.nzero; ++zi) {                    // (behind the tile's own stores: nothing of this block waits for them)
     u32x4* z = static_cast<u32x4*>(a.zero_ptr[zi]);
     const unsigned n16 = a.zero_bytes[zi] >> 4;
@@ -1213,6 +1219,7 @@ int launch_wide_front(FrontArgs& a, int rt, hipStream_t stream, int kg_only) {
     J.chunk_begin = a.xchunks;
     a.xchunks += J.N * J.K / 8;
   }
+  if (a.split3) total *= 3;
   a.xblock0 = total;
   total += (a.xchunks + NTH - 1) / NTH;
   const int prof = gemm_prof_open(stream, 2.0 * ((kg_only ? 0.0 : (double)a.s[0].M) + a.s[1].M) * (128.0 * 256.0 + 256.0 * 768.0), PROF_FRONT);

@@ -628,7 +628,8 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
       for (int x = 0; x < 4; ++x) { J.src[x] = hsrc[x]; J.rows[x] = H / 2; J.ld[x] = H; }
     }
   }
-  if (rt) CK(launch_wide_front(fa, rt, st, one ? 1 : 0), one ? "fused forward, KG rows' front half (wide tiles)" : "fused forward, front half (wide tiles)");
+  if (one) { fa.split3 = 1; CK(launch_wide_front(fa, 1, st, 1), "fused forward, KG rows' front half (32-row tiles, one in-projection pass per block)"); }
+  else if (rt) CK(launch_wide_front(fa, rt, st, one ? 1 : 0), one ? "fused forward, KG rows' front half (wide tiles)" : "fused forward, front half (wide tiles)");
   else CK(launch_fused_front(fa, g_opt_fused_variant, st), "fused forward, front half");
   BackArgs ba; std::memset(&ba, 0, sizeof(ba));
   ba.s[0] = BackStream{f.Wo1, P[CAMO_P_A1_OUT_B], f.W1, P[CAMO_P_F1_B0], P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], f.R16,
