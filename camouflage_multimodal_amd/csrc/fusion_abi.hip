@@ -82,6 +82,9 @@ Desc desc_carve(int B, int T, void* base) {
   return d;
 }
 
+// arrival-counter words of the one-launch tail behind its all-reduce buffers: 4 per group of 16 samples (misc.hip, tail_fused_kernel)
+static inline size_t tail_counter_words(int B) { return (size_t)4 * ((B + 15) / 16 > 0 ? (B + 15) / 16 : 1); }
+
 struct Ws {
   // zeroed once per forward: [ means | dfused | dKV ] (accumulated into by atomics)
   float* zero_base; size_t zero_bytes;
@@ -117,7 +120,7 @@ struct Ws {
   } f;
   int* tickets;         // [2][B] arrival counters (forward: KG->RG attention splits; backward: a sample's RG tiles), in the zero block
   float* dQ2acc;        // [TK][H] fp32 sums of the KG->RG query gradient (in the zero block, fused backward)
-  float* tailsum;       // [B][4H] all-reduce buffers of the one-launch tail (F1 | hidden | dF1) + 4 counter words (in the zero block)
+  float* tailsum;       // [B][4H] all-reduce buffers of the one-launch tail (F1 | hidden | dF1) + 4 counter words per 16 samples (in the zero block)
   size_t bytes;
 };
 
@@ -144,7 +147,7 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
     w.means_n = (size_t)B * 6 * H;
     {   // one contiguous block so a single memset clears every atomically-accumulated buffer
       const size_t nzt = ((size_t)2 * B + 3) & ~size_t(3);                   // tickets: padded to 16 bytes
-      const size_t nz = w.means_n + (size_t)B * H + nzt + TK * 2 * H + TK * H + (size_t)B * 4 * H + 4;
+      const size_t nz = w.means_n + (size_t)B * H + nzt + TK * 2 * H + TK * H + (size_t)B * 4 * H + tail_counter_words(B);
       float* z = c.take<float>(nz);
       w.zero_base = z; w.zero_bytes = nz * sizeof(float);
       w.means = z; w.dfused = z ? z + w.means_n : nullptr;
@@ -574,7 +577,7 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
       zero(w.dHm1, (size_t)B * 2 * H * sizeof(float)); zero(w.dHm2, (size_t)B * 2 * H * sizeof(float));   // atomically summed by the one-launch tail
     } else {
       zero(w.zero_base, (size_t)(reinterpret_cast<char*>(w.dKV) - reinterpret_cast<char*>(w.zero_base)));
-      zero(w.tailsum, ((size_t)B * 4 * H + 4) * sizeof(float));
+      zero(w.tailsum, ((size_t)B * 4 * H + tail_counter_words(B)) * sizeof(float));
     }
     if (build) {
       CK(launch_weight_shadows(sb, st), "weight shadows");
@@ -759,7 +762,21 @@ int tail17(const camo_dims_t& d, const float* const* P, float* const* Gr, const 
   a.counters = reinterpret_cast<unsigned int*>(w.tailsum + (size_t)B * 4 * H);
   a.B = B; a.C = d.num_classes; a.mode = fl ? 1 : 0; a.drop = drop;
   a.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)4 * g_dbg_stamp_blocks * 8 : nullptr;
+  const bool groups = fl && B > 16;
+  if (groups) { a.comb_out = w.comb; a.F1_out = w.F1; a.fused_out = w.fused; a.dhid_out = w.dhid; a.dfused_out = w.dfused; a.dF1_out = w.dF1; }
   CK(launch_tail_fused(a, st), "per-sample tail (one launch)");
+  if (groups) {
+    // more than one group of 16 samples: the big weight gradients of the tail are sums over every group -- one batched launch
+    // (contraction over the B samples), operands = the copies the tail kernel left in the workspace
+    const int Fh = H / 2;
+    GB g(drop, 0, st);
+    for (int x = 0; x < 4; ++x) g.tn(w.dhid + x * Fh, 4 * Fh, w.fused, H, a.gWh0[x], H, a.gbh0[x], Fh, H, B);
+    g.tn(w.dfused, H, w.F1, H, a.gWfu3, H, a.gbfu3, H, H, B);
+    g.tn(w.dF1, H, w.comb, 2 * H, a.gWfu0, 2 * H, a.gbfu0, H, 2 * H, B);
+    g.tn(w.dcomb, 2 * H, w.H1mean, 2 * H, a.gW13, 2 * H, a.gb13, H, 2 * H, B);
+    g.tn(w.dcomb + H, 2 * H, w.H2mean, 2 * H, a.gW23, 2 * H, a.gb23, H, 2 * H, B);
+    CK(g.run(), "per-sample tail, weight gradients");
+  }
   return 0;
 }
 

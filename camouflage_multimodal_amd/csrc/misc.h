@@ -59,6 +59,9 @@ struct TailFusedArgs {
   float* outs; float* terms; int* pred;                     // [B][2C+2]; mode 1: [B][4], [B] (may be null)
   float *F1sum, *hidsum, *dF1sum; unsigned int* counters;   // ZEROED exchange buffers [B][256], [B][512], [B][256]; 4 words (3 arrival counters + timeout flag)
   float *dcomb, *dHm1, *dHm2;                               // mode 1 out: d(mean Z) [B][512]; d(mean H) [B][512] x 2, ZEROED (accumulated with atomics)
+  // B > 16 (more than one group of samples), mode 1: the four big weight gradients are sums over ALL groups -- left to ONE batched
+  // GEMM launch behind this one (fusion_abi.hip, tail17), which reads these copies of the per-sample operands
+  float *comb_out, *F1_out, *fused_out, *dhid_out, *dfused_out, *dF1_out;       // [B][512], [B][256], [B][256], [B][512], [B][256], [B][256]
   int B, C, mode; DropCfg drop;
   unsigned long long* stamps;                               // developer timeline (null in product calls)
   int debug_skip;                                           // (launcher) developer hook: block id + 1 that skips its first arrival

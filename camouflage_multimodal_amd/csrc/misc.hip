@@ -640,7 +640,9 @@ __device__ __forceinline__ void tail_arrive_wait(unsigned int* counter, unsigned
   __syncthreads();
 }
 
-constexpr int TF_MAXB = 16;
+constexpr int TF_MAXB = 16;           // samples per group
+constexpr int TF_MAXGROUPS = 3;       // 64 co-resident blocks each.  Measured (MI355X, training step): B = 24 -7 %, 32 -5 %, 48 -2 %, 64 +-0 against
+                                      // the separate launches -- every group adds its 64-way atomic all-reduces to the same L2 atomic units
 constexpr int TF_MAXW = 18;           // 2 * num_classes + 2 (num_classes <= 8)
 constexpr int TF_LDS_FLOATS = 2 * TF_MAXB * 512 + 2 * TF_MAXB * 256 + 2048 + 2048 + 3 * 128 + 64 + 64 + 2 * TF_MAXB * TF_MAXW + TF_MAXW * 129 + 2 +
                              8 * 512 + 4 * 256;      // (148 KB)
@@ -663,7 +665,32 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ int s_timed_out;                                // a wait of this block gave up (tail_arrive_wait)
   if (threadIdx.x == 0) s_timed_out = 0;                     // (ordered before its first use by the barriers of the first wait)
-  const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x, B = a.B, C = a.C, Wd = 2 * C + 2;
+  // Sample groups: block (g, sg) = column slice g of samples [16 sg, 16 sg + 16).  Groups never wait for each other (their own
+  // arrival counters), so a batch of up to 16 * groups samples costs one group's latency while the chip has 64 CUs per group;
+  // blocks are numbered group by group, so the blocks a group waits for are never queued behind blocks that wait for them.
+  // With more than one group the four big weight gradients (sums over every group's samples) are left to one batched GEMM launch
+  // behind this kernel, which gets the per-sample operands from the *_out copies; the small output-layer gradients use atomics.
+  const bool wg = a.mode && gridDim.x > TG;               // (write the copies, skip the big weight gradients)
+  const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x & (TG - 1), sg = blockIdx.x >> 6, C = a.C, Wd = 2 * C + 2;
+  const bool multi = gridDim.x > TG;
+  const int sb = TF_MAXB * sg, B = min(TF_MAXB, a.B - sb);
+  // (the group's views of the per-sample arrays: locals -- a modified copy of the argument struct would leave the scalar registers)
+  const float* const gYmean = a.Ymean + (size_t)sb * 256; const float* const gY2mean = a.Y2mean + (size_t)sb * 256;
+  const float* const gH1mean = a.H1mean + (size_t)sb * 512; const float* const gH2mean = a.H2mean + (size_t)sb * 512;
+  float* const gF1sum = a.F1sum + (size_t)sb * 256; float* const ghidsum = a.hidsum + (size_t)sb * 512; float* const gdF1sum = a.dF1sum + (size_t)sb * 256;
+  float* const gouts = a.outs + (size_t)sb * Wd;
+  const bool md = a.mode != 0;
+  const long long* const gy = md ? a.y + sb : nullptr; const float* const ge = md ? a.e + sb : nullptr; const float* const gs = md ? a.s + sb : nullptr;
+  float* const gterms = md ? a.terms + 4 * sb : nullptr; int* const gpred = md && a.pred ? a.pred + sb : nullptr;
+  float* const gdcomb = md ? a.dcomb + (size_t)sb * 512 : nullptr;
+  float* const gdHm1 = md ? a.dHm1 + (size_t)sb * 512 : nullptr; float* const gdHm2 = md ? a.dHm2 + (size_t)sb * 512 : nullptr;
+  float* const gcomb_out = wg ? a.comb_out + (size_t)sb * 512 : nullptr; float* const gF1_out = wg ? a.F1_out + (size_t)sb * 256 : nullptr;
+  float* const gfused_out = wg ? a.fused_out + (size_t)sb * 256 : nullptr; float* const gdhid_out = wg ? a.dhid_out + (size_t)sb * 512 : nullptr;
+  float* const gdfused_out = wg ? a.dfused_out + (size_t)sb * 256 : nullptr; float* const gdF1_out = wg ? a.dF1_out + (size_t)sb * 256 : nullptr;
+  unsigned int* const cnt = a.counters + 4 * sg;            // arrivals: words 4 sg .. 4 sg + 2 (word 3: the launch's gave-up flag)
+  unsigned int* const gaveup = a.counters + 3;
+  auto put = [&](float* p, float v) { if (multi) atomicAdd(p, v); else *p = v; };
+  auto put2 = [&](float2* p, float2 v) { if (multi) { atomicAdd(&p->x, v.x); atomicAdd(&p->y, v.y); } else *p = v; };
   const int q = __builtin_amdgcn_readfirstlane(tid >> 8), t = tid & 255, wv = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
   const int b0 = 4 * q, B4 = (B + 3) & ~3;
   const bool active = b0 < B;                               // (wave-uniform)
@@ -680,9 +707,9 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
   float* WfL = W3L + 8 * 512;                                // [4][256] this block's rows of fusion layer 3 (L3, and d F1)
   const bool kgs = g >= 32;                                 // comb columns 256.. are the KG stream's
   const int c0 = 8 * (g & 31), ccol = (kgs ? 256 : 0) + c0;
-  const float* Hmean = kgs ? a.H2mean : a.H1mean; const float* Ymean = kgs ? a.Y2mean : a.Ymean;
+  const float* Hmean = kgs ? gH2mean : gH1mean; const float* Ymean = kgs ? gY2mean : gYmean;
   const float* W3s = kgs ? a.W23 : a.W13; const float* b3s = kgs ? a.b23 : a.b13;
-  float* gW3s = kgs ? a.gW23 : a.gW13; float* gb3s = kgs ? a.gb23 : a.gb13; float* dHm = kgs ? a.dHm2 : a.dHm1;
+  float* gW3s = kgs ? a.gW23 : a.gW13; float* gb3s = kgs ? a.gb23 : a.gb13; float* dHm = kgs ? gdHm2 : gdHm1;
   const bool dodrop = a.drop.p > 0.f;
   const float dscale = a.drop.scale;
   auto headW0 = [&](int x) { return x == 0 ? a.Wh0[0] : (x == 1 ? a.Wh0[1] : (x == 2 ? a.Wh0[2] : a.Wh0[3])); };
@@ -741,7 +768,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
   float2* dstfu0 = reinterpret_cast<float2*>(a.gWfu0 + (size_t)t * 512 + ccol + 2 * q);
   float oW3h = 0.f, ob3h = 0.f, ob0h = 0.f, obfu3 = 0.f, obfu0 = 0.f, ob3s = 0.f, ofu3 = 0.f, ogw3[4] = {0.f, 0.f, 0.f, 0.f};
   float2 oW0 = make_float2(0.f, 0.f), ofu0 = make_float2(0.f, 0.f);
-  if (a.mode) {
+  if (a.mode && !multi) {
     if (tid < hnout * 8) oW3h = *dW3h;
     if (g == 0 && tid >= 128 && tid < 128 + Wd) { int xx, oo; head_of(tid - 128, xx, oo); ob3h = gheadB3(xx)[oo]; }
     oW0 = *dstW0; ofu3 = *dstfu3; ofu0 = *dstfu0;
@@ -768,7 +795,11 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
       wave_sum4(acc);
       if (lane == 63) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) combS[(b0 + j) * 8 + 2 * wv + cc] = acc[j] + ymS[(b0 + j) * 8 + 2 * wv + cc];
+        for (int j = 0; j < 4; ++j) {
+          const float cv = acc[j] + ymS[(b0 + j) * 8 + 2 * wv + cc];
+          combS[(b0 + j) * 8 + 2 * wv + cc] = cv;
+          if (wg && b0 + j < B) gcomb_out[(size_t)(b0 + j) * 512 + ccol + 2 * wv + cc] = cv;
+        }
       }
     }
   }
@@ -789,21 +820,22 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
     for (int j = 0; j < 4; ++j) {
       const float4 ca = reinterpret_cast<const float4*>(combS)[(b0 + j) * 2], cb = reinterpret_cast<const float4*>(combS)[(b0 + j) * 2 + 1];
       const float acc = bias2 + w8[0] * ca.x + w8[1] * ca.y + w8[2] * ca.z + w8[3] * ca.w + w8[4] * cb.x + w8[5] * cb.y + w8[6] * cb.z + w8[7] * cb.w;
-      if (b0 + j < B) atomicAdd(a.F1sum + (b0 + j) * 256 + t, acc);
+      if (b0 + j < B) atomicAdd(gF1sum + (b0 + j) * 256 + t, acc);
     }
   }
   tstamp(a.stamps, 3);
-  tail_arrive_wait(a.counters + 0, a.counters + 3, &s_timed_out, a.debug_skip == (int)blockIdx.x + 1);
+  tail_arrive_wait(cnt + 0, gaveup, &s_timed_out, a.debug_skip == (int)blockIdx.x + 1);
   tstamp(a.stamps, 4);
   {
-    const float4 v4 = tid < B * 64 ? reinterpret_cast<const float4*>(a.F1sum)[tid] : z4;
+    const float4 v4 = tid < B * 64 ? reinterpret_cast<const float4*>(gF1sum)[tid] : z4;
     if (tid < B4 * 64) {
       float v[4] = {fmaxf(v4.x, 0.f), fmaxf(v4.y, 0.f), fmaxf(v4.z, 0.f), fmaxf(v4.w, 0.f)};
       if (dodrop) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= drop_mult(a.drop, SITE_FUSE, (uint32_t)(4 * tid + e));        // (element index b * 256 + n)
+        for (int e = 0; e < 4; ++e) v[e] *= drop_mult(a.drop, SITE_FUSE, (uint32_t)(sb * 256 + 4 * tid + e));        // (element index b * 256 + n)
       }
       reinterpret_cast<float4*>(F1)[tid] = make_float4(v[0], v[1], v[2], v[3]);
+      if (wg && g == 0 && tid < B * 64) reinterpret_cast<float4*>(gF1_out)[tid] = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
   __syncthreads();
@@ -818,7 +850,10 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
     wave_sum4(acc);
     if (lane == 63) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fusedS[(b0 + j) * 4 + wv] = acc[j] + bias3;
+      for (int j = 0; j < 4; ++j) {
+        fusedS[(b0 + j) * 4 + wv] = acc[j] + bias3;
+        if (wg && b0 + j < B) gfused_out[(size_t)(b0 + j) * 256 + 4 * g + wv] = acc[j] + bias3;
+      }
     }
   }
   __syncthreads();
@@ -830,25 +865,25 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
     for (int j = 0; j < 4; ++j) {
       const float4 f = reinterpret_cast<const float4*>(fusedS)[b0 + j];
       if (b0 + j < B) {
-        atomicAdd(a.hidsum + (b0 + j) * 512 + t, bias4a + wa0.x * f.x + wa0.y * f.y + wa0.z * f.z + wa0.w * f.w);
-        atomicAdd(a.hidsum + (b0 + j) * 512 + t + 256, bias4b + wa1.x * f.x + wa1.y * f.y + wa1.z * f.z + wa1.w * f.w);
+        atomicAdd(ghidsum + (b0 + j) * 512 + t, bias4a + wa0.x * f.x + wa0.y * f.y + wa0.z * f.z + wa0.w * f.w);
+        atomicAdd(ghidsum + (b0 + j) * 512 + t + 256, bias4b + wa1.x * f.x + wa1.y * f.y + wa1.z * f.z + wa1.w * f.w);
       }
     }
   }
   tstamp(a.stamps, 7);
-  tail_arrive_wait(a.counters + 1, a.counters + 3, &s_timed_out);
+  tail_arrive_wait(cnt + 1, gaveup, &s_timed_out);
   tstamp(a.stamps, 8);
   {
     float4 v4[2];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) { const int i = tid + TF_THREADS * it; v4[it] = i < B * 128 ? reinterpret_cast<const float4*>(a.hidsum)[i] : z4; }
+    for (int it = 0; it < 2; ++it) { const int i = tid + TF_THREADS * it; v4[it] = i < B * 128 ? reinterpret_cast<const float4*>(ghidsum)[i] : z4; }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int i = tid + TF_THREADS * it;
       if (i < B4 * 128) {
         float v[4] = {fmaxf(v4[it].x, 0.f), fmaxf(v4[it].y, 0.f), fmaxf(v4[it].z, 0.f), fmaxf(v4[it].w, 0.f)};
         if (dodrop) {
-          const int b = i >> 7, m = (4 * i) & 511;
+          const int b = sb + (i >> 7), m = (4 * i) & 511;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= drop_mult(a.drop, SITE_HEAD0 + (uint32_t)(m >> 7), (uint32_t)(b * 128 + (m & 127) + e));
         }
@@ -882,7 +917,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
     if (x == 3) acc = 1.0f / (1.0f + __expf(-acc));
     if (kq == 0) {
       outsS[b * TF_MAXW + o] = acc;
-      if (g == 0) a.outs[p] = s_timed_out ? __uint_as_float(0x7FC00000u) : acc;
+      if (g == 0) gouts[p] = s_timed_out ? __uint_as_float(0x7FC00000u) : acc;
     }
   }
   __syncthreads();
@@ -890,11 +925,11 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
   if (!a.mode) { tstamp(a.stamps, 20); return; }
   if (tid < B) {
     float t4[4]; int pr = 0;
-    loss_sample<true>(outsS + tid * TF_MAXW, (int)a.y[tid], a.e[tid], a.s[tid], C, t4, nullptr, dpre + tid * TF_MAXW, &pr);
+    loss_sample<true>(outsS + tid * TF_MAXW, (int)gy[tid], ge[tid], gs[tid], C, t4, nullptr, dpre + tid * TF_MAXW, &pr);
     if (g == 0) {
       if (s_timed_out) t4[0] = t4[1] = t4[2] = t4[3] = __uint_as_float(0x7FC00000u);
-      a.terms[4 * tid] = t4[0]; a.terms[4 * tid + 1] = t4[1]; a.terms[4 * tid + 2] = t4[2]; a.terms[4 * tid + 3] = t4[3];
-      if (a.pred) a.pred[tid] = pr;
+      gterms[4 * tid] = t4[0]; gterms[4 * tid + 1] = t4[1]; gterms[4 * tid + 2] = t4[2]; gterms[4 * tid + 3] = t4[3];
+      if (gpred) gpred[tid] = pr;
     }
   }
   __syncthreads();
@@ -908,7 +943,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
     for (int bb = 0; bb < B; bb += 4)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = fmaf(dpre[(bb + j) * TF_MAXW + hcoff + o], R2[(bb + j) * 512 + 8 * g + mi], acc);
-    *dW3h = acc;
+    put(dW3h, acc);
   }
   if (g == 0 && tid >= 128 && tid < 128 + Wd) {
     const int o = tid - 128;
@@ -916,7 +951,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
     float acc = ob3h;
 #pragma unroll 1
     for (int b = 0; b < B; ++b) acc += dpre[b * TF_MAXW + o];
-    gheadB3(xx)[oo] = acc;
+    put(gheadB3(xx) + oo, acc);
   }
   __syncthreads();
   tstamp(a.stamps, 12);
@@ -934,7 +969,12 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
         for (int j = 0; j < 4; ++j) d[j] = fmaf(dpre[(b0 + j) * TF_MAXW + coff + o], wv3, d[j]);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const float hcur = R2[(b0 + j) * 512 + m]; R2[(b0 + j) * 512 + m] = hcur > 0.f ? d[j] * dscale : 0.f; }
+      for (int j = 0; j < 4; ++j) {
+        const float hcur = R2[(b0 + j) * 512 + m];
+        const float dv = hcur > 0.f ? d[j] * dscale : 0.f;
+        R2[(b0 + j) * 512 + m] = dv;
+        if (wg && g == 0 && b0 + j < B) gdhid_out[(size_t)(b0 + j) * 512 + m] = dv;
+      }
     }
   }
   __syncthreads();
@@ -952,10 +992,13 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
     wave_sum4(acc);
     if (lane == 63) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dfusedS[(b0 + j) * 4 + wv] = acc[j];
+      for (int j = 0; j < 4; ++j) {
+        dfusedS[(b0 + j) * 4 + wv] = acc[j];
+        if (wg && b0 + j < B) gdfused_out[(size_t)(b0 + j) * 256 + 4 * g + wv] = acc[j];
+      }
     }
   }
-  {
+  if (!wg) {
     float2 gacc = oW0;
 #pragma unroll 1
     for (int bb = 0; bb < B; bb += 4)
@@ -965,13 +1008,13 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
         const float2 f = reinterpret_cast<const float2*>(fusedS)[(bb + j) * 2 + qh];
         gacc.x = fmaf(d, f.x, gacc.x); gacc.y = fmaf(d, f.y, gacc.y);
       }
-    *dstW0 = gacc;
+    put2(dstW0, gacc);
     if (tid < 8) {
       const int m = 8 * g + tid;
       float s = ob0h;
 #pragma unroll 1
       for (int b = 0; b < B; ++b) s += R2[b * 512 + m];
-      gheadB0(m >> 7)[m & 127] = s;
+      put(gheadB0(m >> 7) + (m & 127), s);
     }
   }
   __syncthreads();
@@ -981,32 +1024,34 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 df = reinterpret_cast<const float4*>(dfusedS)[b0 + j];
-      if (b0 + j < B) atomicAdd(a.dF1sum + (b0 + j) * 256 + t, df.x * WfL[t] + df.y * WfL[256 + t] + df.z * WfL[512 + t] + df.w * WfL[768 + t]);
+      if (b0 + j < B) atomicAdd(gdF1sum + (b0 + j) * 256 + t, df.x * WfL[t] + df.y * WfL[256 + t] + df.z * WfL[512 + t] + df.w * WfL[768 + t]);
     }
   }
-  {
+  if (!wg) {
     float gw = ofu3;
 #pragma unroll 1
     for (int bb = 0; bb < B; bb += 4)
 #pragma unroll
       for (int j = 0; j < 4; ++j) gw = fmaf(dfusedS[(bb + j) * 4 + q], F1[(bb + j) * 256 + t], gw);
-    *dstfu3 = gw;
+    put(dstfu3, gw);
     if (tid < 4) {
       float s = obfu3;
 #pragma unroll 1
       for (int b = 0; b < B; ++b) s += dfusedS[b * 4 + tid];
-      a.gbfu3[4 * g + tid] = s;
+      put(a.gbfu3 + 4 * g + tid, s);
     }
   }
   tstamp(a.stamps, 15);
-  tail_arrive_wait(a.counters + 2, a.counters + 3, &s_timed_out);
+  tail_arrive_wait(cnt + 2, gaveup, &s_timed_out);
   tstamp(a.stamps, 16);
   {
-    const float4 v4 = tid < B * 64 ? reinterpret_cast<const float4*>(a.dF1sum)[tid] : z4;
+    const float4 v4 = tid < B * 64 ? reinterpret_cast<const float4*>(gdF1sum)[tid] : z4;
     if (tid < B4 * 64) {
       const float4 f = reinterpret_cast<const float4*>(F1)[tid];
-      reinterpret_cast<float4*>(DF)[tid] = make_float4(f.x > 0.f ? v4.x * dscale : 0.f, f.y > 0.f ? v4.y * dscale : 0.f,
-                                                       f.z > 0.f ? v4.z * dscale : 0.f, f.w > 0.f ? v4.w * dscale : 0.f);
+      const float4 dfv = make_float4(f.x > 0.f ? v4.x * dscale : 0.f, f.y > 0.f ? v4.y * dscale : 0.f,
+                                     f.z > 0.f ? v4.z * dscale : 0.f, f.w > 0.f ? v4.w * dscale : 0.f);
+      reinterpret_cast<float4*>(DF)[tid] = dfv;
+      if (wg && g == 0 && tid < B * 64) reinterpret_cast<float4*>(gdF1_out)[tid] = dfv;
     }
   }
   __syncthreads();
@@ -1029,13 +1074,13 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           dcombS[(b0 + j) * 8 + c] = acc[j];
-          if (b0 + j < B) a.dcomb[(b0 + j) * 512 + ccol + c] = acc[j];
+          if (b0 + j < B) gdcomb[(b0 + j) * 512 + ccol + c] = acc[j];
         }
       }
     }
   }
   tstamp(a.stamps, 18);
-  {
+  if (!wg) {
     float2 gw = ofu0;
 #pragma unroll 1
     for (int bb = 0; bb < B; bb += 4)
@@ -1045,12 +1090,12 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
         const float2 cv = reinterpret_cast<const float2*>(combS)[(bb + j) * 4 + q];
         gw.x = fmaf(d, cv.x, gw.x); gw.y = fmaf(d, cv.y, gw.y);
       }
-    *dstfu0 = gw;
+    put2(dstfu0, gw);
     if (tid < 4) {
       float s = obfu0;
 #pragma unroll 1
       for (int b = 0; b < B; ++b) s += DF[b * 256 + 4 * g + tid];
-      a.gbfu0[4 * g + tid] = s;
+      put(a.gbfu0 + 4 * g + tid, s);
     }
   }
   __syncthreads();
@@ -1069,7 +1114,7 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
       }
     }
   }
-  {
+  if (!wg) {
     float gw[4] = {ogw3[0], ogw3[1], ogw3[2], ogw3[3]};
 #pragma unroll 1
     for (int bb = 0; bb < B; bb += 4)
@@ -1080,13 +1125,13 @@ __global__ __launch_bounds__(TF_THREADS) void tail_fused_kernel(const TailFusedA
         gw[0] = fmaf(dc.x, hm, gw[0]); gw[1] = fmaf(dc.y, hm, gw[1]); gw[2] = fmaf(dc.z, hm, gw[2]); gw[3] = fmaf(dc.w, hm, gw[3]);
       }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) gW3s[(size_t)(c0 + 4 * qh + c) * 512 + qm] = gw[c];
+    for (int c = 0; c < 4; ++c) put(gW3s + (size_t)(c0 + 4 * qh + c) * 512 + qm, gw[c]);
   }
-  if (tid < 8) {
+  if (!wg && tid < 8) {
     float s = ob3s;
 #pragma unroll 1
     for (int b = 0; b < B; ++b) s += dcombS[b * 8 + tid];
-    gb3s[c0 + tid] = s;
+    put(gb3s + c0 + tid, s);
   }
   tstamp(a.stamps, 20);
 }
@@ -1330,7 +1375,7 @@ int tail_fused_ok(int B, int C) {
   // every block of the launch waits for the other 63: all of them must be resident at once, one per CU (1024 threads, 148 KB of
   // LDS), so the device (or the partition this process sees) must have at least that many CUs
   static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
-  return B >= 1 && B <= TF_MAXB && C >= 1 && 2 * C + 2 <= TF_MAXW && cus >= TG;
+  return B >= 1 && B <= TF_MAXGROUPS * TF_MAXB && C >= 1 && 2 * C + 2 <= TF_MAXW && cus >= TG * ((B + TF_MAXB - 1) / TF_MAXB);
 }
 int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream) {
   if (!tail_fused_ok(a.B, a.C)) return (int)hipErrorInvalidValue;
@@ -1342,7 +1387,7 @@ int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream) {
   TailFusedArgs aa = a;
   aa.debug_skip = g_tail_debug_skip; g_tail_debug_skip = 0;
   const int prof = gemm_prof_open(stream, 0.0, PROF_TAIL);
-  hipLaunchKernelGGL(tail_fused_kernel, dim3(TG), dim3(TF_THREADS), TF_LDS_FLOATS * 4, stream, aa);
+  hipLaunchKernelGGL(tail_fused_kernel, dim3(TG * ((a.B + TF_MAXB - 1) / TF_MAXB)), dim3(TF_THREADS), TF_LDS_FLOATS * 4, stream, aa);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }

@@ -1,4 +1,4 @@
-"""Developer aid: HIP-event time per kernel family of an eval forward / training step.   python tests/dev_kinds.py B rt [train]"""
+"""Developer aid: HIP-event time per kernel family of an eval forward / training step.   python tests/dev_kinds.py B rt [train] [option=value ...]"""
 import ctypes as C, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +9,9 @@ model = build_multimodal_model({}).cuda().set_precision("bf16"); model.train(tra
 tr = NativeTrainer(model)
 L = _lib.lib()
 _lib.check(L.camo_debug_set_option(b"fused_rt", rt), "opt")
+for kv in sys.argv[3:]:
+    if "=" in kv:
+        _lib.check(L.camo_debug_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1])), kv)
 hb = make_batches(2, B, 0, seed=100 + B)
 db = [tuple(torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else x for x in b) for b in hb]
 fn = (lambda i: tr.step(*db[i % 2])) if train else (lambda i: tr.evaluate(*db[i % 2][:3]))

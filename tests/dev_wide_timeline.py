@@ -16,6 +16,8 @@ b0 = make_batches(1, B, 0)[0]
 rg, nrs, kg = torch.from_numpy(b0[0]).cuda(), b0[1], torch.from_numpy(b0[2]).cuda()
 NB = 32768
 _lib.lib().camo_debug_set_option(b"fused_rt", rt)
+if "--two" in sys.argv:
+    _lib.lib().camo_debug_set_option(b"fused_one", 0)
 buf = torch.zeros(5 * NB * 8, dtype=torch.int64, device="cuda")
 if train:
     model.train()
