@@ -291,11 +291,12 @@ def fit(config, train_loader, val_loader, device="cuda", grad_allreduce=None, lo
     best, patience, max_patience = 0.0, 0, 15
     os.makedirs(config["checkpoint_dir"], exist_ok=True)
     trainer.opt.set_epoch(0)                                 # CosineAnnealingWarmRestarts(T_0=10, T_mult=2) [:409-411]
+    timeouts0 = _lib.tail_timeouts(device)                   # (sticky since the library was loaded: this run answers for its own)
     for epoch in range(config["epochs"]):
         loader = train_loader(epoch) if callable(train_loader) else train_loader
         tl, tf1 = train_epoch_fixed(model, loader, trainer, device, epoch + 1)
         vl, vf1, a0, a1 = validate_fixed(model, val_loader, device)
-        if _lib.tail_timeouts(device):
+        if _lib.tail_timeouts(device) != timeouts0:
             raise _lib.CamoError("the one-launch tail kernel timed out waiting for its own blocks (GPU shared with another process?): "
                                  "this epoch's results are invalid")
         trainer.opt.set_epoch(epoch + 1)                     # scheduler.step() [:439]: a checkpoint carries the NEXT epoch's lr
