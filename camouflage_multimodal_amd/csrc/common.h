@@ -81,4 +81,12 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
   __bf16 b = (__bf16)f;     // round-to-nearest-even, NaN stays NaN
   return __builtin_bit_cast(unsigned short, b);
 }
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// two floats -> one dword of two bf16 (lo in bits 0..15): ONE v_cvt_pk_bf16_f32.  Written as a vector conversion: two scalar
+// conversions + shift + or let the SLP vectoriser pair elements of DIFFERENT dwords and then shuffle halves back with
+// v_and / v_lshl / v_or_sdwa / v_mov (13 instructions per 4 values instead of 4 in every bf16 epilogue).
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}

@@ -78,7 +78,8 @@ struct StageW {
 #pragma unroll
     for (int i = 0; i < D; ++i) buf[i] = *wptr(i);
   }
-  template <bool W_IS_A, class F>
+  // ZERO: acc = the products alone (the first k step's MFMAs take the constant 0 as their addend: no accumulator clears)
+  template <bool W_IS_A, bool ZERO = false, class F>
   __device__ __forceinline__ void run_f(F&& frag, f32x16 (&acc)[RT][NT]) {
     bf16x8 x[RT], xn[RT];
 #pragma unroll
@@ -101,17 +102,18 @@ struct StageW {
       }
 #pragma unroll
       for (int s = 0; s < RT; ++s) {
-        if constexpr (W_IS_A) acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, x[s], acc[s][t], 0, 0, 0);
-        else                  acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[s], wf, acc[s][t], 0, 0, 0);
+        const f32x16 c = (ZERO && ks == 0) ? zero16() : acc[s][t];
+        if constexpr (W_IS_A) acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, x[s], c, 0, 0, 0);
+        else                  acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[s], wf, c, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   // activation tiles in LDS: `act` = address of this lane's first fragment of sub-tile 0 (row lane & 31, byte 16 (lane >> 5)),
   // sub-tile s is `sub` bytes further, k step ks 32 bytes further
-  template <bool W_IS_A>
+  template <bool W_IS_A, bool ZERO = false>
   __device__ __forceinline__ void run(const char* act, int sub, f32x16 (&acc)[RT][NT]) {
-    run_f<W_IS_A>([&](int s, int ks) { return *reinterpret_cast<const bf16x8*>(act + s * sub + 32 * ks); }, acc);
+    run_f<W_IS_A, ZERO>([&](int s, int ks) { return *reinterpret_cast<const bf16x8*>(act + s * sub + 32 * ks); }, acc);
   }
 };
 
@@ -216,8 +218,7 @@ __global__ __launch_bounds__(NTH, 2) void front8_kernel(const FrontArgs a) {
   const u32x4* w1base = reinterpret_cast<const u32x4*>(S.W1) + (size_t)((w8 >> 1) * (16 * 6) + 3 * (w8 & 1)) * 64 + lane;
   {
     f32x16 acc[RT][1];
-    clear_acc(acc);
-    st0.template run<true>(bufX + l31 * PX + 16 * h, 32 * PX, acc);
+    st0.template run<true, true>(bufX + l31 * PX + 16 * h, 32 * PX, acc);
     st1.prefetch(w1base + 64 * p_begin);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -237,8 +238,7 @@ __global__ __launch_bounds__(NTH, 2) void front8_kernel(const FrontArgs a) {
   for (int p = 0; p < 3; ++p) {
     if (p < p_begin || p >= p_end) continue;                     // (block-uniform)
     f32x16 acc[RT][1];
-    clear_acc(acc);
-    st1.template run<true>(bufR + l31 * PR + 16 * h, 32 * PR, acc);
+    st1.template run<true, true>(bufR + l31 * PR + 16 * h, 32 * PR, acc);
     if (p + 1 < p_end) st1.prefetch(w1base + 64 * (p + 1));
     const int tg = 3 * w8 + p;                                   // wave-uniform
     const float sc = tg < 8 ? a.qscale : 1.0f;
@@ -335,11 +335,10 @@ __device__ __forceinline__ void chain_tiles(const BackArgs& a, const BackStream&
         if (!FUSEDIN) rv[s][g] = *reinterpret_cast<const u32x2*>(S.R16 + rrow * 256 + 32 * w8 + 8 * g + 4 * h);
     }
     f32x16 acc[RTC][1];
-    clear_acc(acc);
     if (FUSEDIN)
-      sto.template run_f<true>([&](int s, int ks) { return *reinterpret_cast<const bf16x8*>(bufO + (ks >> 1) * (32 * RTC * PS) + (32 * s + l31) * PS + 32 * (ks & 1) + 16 * h); }, acc);
+      sto.template run_f<true, true>([&](int s, int ks) { return *reinterpret_cast<const bf16x8*>(bufO + (ks >> 1) * (32 * RTC * PS) + (32 * s + l31) * PS + 32 * (ks & 1) + 16 * h); }, acc);
     else
-      sto.template run<true>(bufO + l31 * PR + 16 * h, 32 * PR, acc);
+      sto.template run<true, true>(bufO + l31 * PR + 16 * h, 32 * PR, acc);
     if (STAMPS) stamp(a.stamps, 5);
     if (FUSEDIN) {
 #pragma unroll
@@ -439,8 +438,7 @@ __device__ __forceinline__ void chain_tiles(const BackArgs& a, const BackStream&
   // ---- FFN layer 0 + ReLU + dropout, pooled over the rows (lane = feature; wave w8: features 64 w8 .. + 63)
   {
     f32x16 acc[RTC][2];
-    clear_acc(acc);
-    stf.template run<false>(bufY + l31 * PR + 16 * h, 32 * PR, acc);
+    stf.template run<false, true>(bufY + l31 * PR + 16 * h, 32 * PR, acc);
     if (STAMPS) stamp(a.stamps, 10);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -882,8 +880,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd_kernel(const RgFwdArgs g) {
   auto w1tile = [&](int tg) { return reinterpret_cast<const u32x4*>(F.W1) + (size_t)((tg / 6) * (16 * 6) + tg % 6) * 64 + lane; };
   {
     f32x16 acc[RT][1];
-    clear_acc(acc);
-    st0.template run<true>(bufX + l31 * PX + 16 * h, 32 * PX, acc);
+    st0.template run<true, true>(bufX + l31 * PX + 16 * h, 32 * PX, acc);
     st1.prefetch(w1tile(8 + w8));
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
@@ -922,8 +919,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd_kernel(const RgFwdArgs g) {
         }
       }
       f32x16 acc[RT][1];
-      clear_acc(acc);
-      st1.template run<true>(bufR + l31 * PR + 16 * h, 32 * PR, acc);
+      st1.template run<true, true>(bufR + l31 * PR + 16 * h, 32 * PR, acc);
       st1.prefetch(w1tile(16 + w8));
       stamp(a.stamps, 3);
       f32x16 S2[RT];
@@ -974,8 +970,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd_kernel(const RgFwdArgs g) {
       }
     }
     f32x16 vacc[RT][1];
-    clear_acc(vacc);
-    st1.template run<false>(bufR + l31 * PR + 16 * h, 32 * PR, vacc);      // same fragments, operands swapped
+    st1.template run<false, true>(bufR + l31 * PR + 16 * h, 32 * PR, vacc);      // same fragments, operands swapped
     st1.prefetch(w1tile(w8));
     stamp(a.stamps, 4);
     const float vbias = cst[768 + 32 * w8 + l31];
@@ -1039,8 +1034,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd_kernel(const RgFwdArgs g) {
       if (j < Nk) vkg[s] = *reinterpret_cast<const u32x4*>(a.KV16 + ((size_t)sub[s].b * Nk + j) * 512 + 256 + 32 * w8 + 8 * c);
     }
     f32x16 acc[RT][1];
-    clear_acc(acc);
-    st1.template run<true>(bufR + l31 * PR + 16 * h, 32 * PR, acc);
+    st1.template run<true, true>(bufR + l31 * PR + 16 * h, 32 * PR, acc);
     // arrival, first half (see back8_kernel): this wave's partial stores are drained HERE -- they are a whole pass old, and nothing
     // younger is in flight yet -- rather than in front of the barrier below, where the wait would also sit out the next stream's prefetch
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
