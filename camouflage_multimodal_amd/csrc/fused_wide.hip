@@ -450,17 +450,30 @@ __device__ __forceinline__ void chain_tiles(const BackArgs& a, const BackStream&
         if (nrows <= 0) continue;                             // (wave-uniform)
         float colsum = 0.f;
         uint32_t wlo = 0u, whi = 0u;
+        if (nrows >= 32) {                                    // (wave-uniform) full sub-tiles -- the common case -- carry no row masks
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (8 * (i >> 2) >= nrows) continue;                // (block-uniform) a register group whose rows are all past the tile's end
-          const int row = acc_row(i, h);
-          float v = fmaxf(acc[s][t][i] + bias, 0.f);
-          if (DROP) v *= drop_mult(a.drop, S.site_ffn, (uint32_t)(sub[s].row0 + row) * 512u + (uint32_t)f);
-          if (row >= nrows) v = 0.f;
-          colsum += v;
-          if (SAVE) {
-            const unsigned long long bal = __ballot(v > 0.f);
-            if (lane == i) { wlo = (uint32_t)bal; whi = (uint32_t)(bal >> 32); }
+          for (int i = 0; i < 16; ++i) {
+            float v = fmaxf(acc[s][t][i] + bias, 0.f);
+            if (DROP) v *= drop_mult(a.drop, S.site_ffn, (uint32_t)(sub[s].row0 + acc_row(i, h)) * 512u + (uint32_t)f);
+            colsum += v;
+            if (SAVE) {
+              const unsigned long long bal = __ballot(v > 0.f);
+              if (lane == i) { wlo = (uint32_t)bal; whi = (uint32_t)(bal >> 32); }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (8 * (i >> 2) >= nrows) continue;              // (block-uniform) a register group whose rows are all past the tile's end
+            const int row = acc_row(i, h);
+            float v = fmaxf(acc[s][t][i] + bias, 0.f);
+            if (DROP) v *= drop_mult(a.drop, S.site_ffn, (uint32_t)(sub[s].row0 + row) * 512u + (uint32_t)f);
+            if (row >= nrows) v = 0.f;
+            colsum += v;
+            if (SAVE) {
+              const unsigned long long bal = __ballot(v > 0.f);
+              if (lane == i) { wlo = (uint32_t)bal; whi = (uint32_t)(bal >> 32); }
+            }
           }
         }
         colsum += __shfl_xor(colsum, 32, 64);
