@@ -632,7 +632,11 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
     }
   }
   if (one) { fa.split3 = 1; CK(launch_wide_front(fa, 1, st, 1), "fused forward, KG rows' front half (32-row tiles, one in-projection pass per block)"); }
-  else if (rt) CK(launch_wide_front(fa, rt, st, one ? 1 : 0), one ? "fused forward, KG rows' front half (wide tiles)" : "fused forward, front half (wide tiles)");
+  else if (rt) CK(launch_wide_front(fa, rt, st, 0), "fused forward, front half (wide tiles)");
+  // training calls at large batches: the front half alone on 128-row blocks (same outputs; measured B = 64: 37.5 -> 30.3 us, B = 256:
+  // 130 -> 104 us), the back half stays on the 32-row kernel, whose saving + dropout variant is the faster one (77 vs 94 us at B = 64)
+  else if (g_opt_fused_rt < 0 && save && T >= 4 * 32 * 224 && max_nr <= wide_max_rows(4) - 256)
+    CK(launch_wide_front(fa, 4, st, 0), "fused forward, front half (wide tiles)");
   else CK(launch_fused_front(fa, g_opt_fused_variant, st), "fused forward, front half");
   BackArgs ba; std::memset(&ba, 0, sizeof(ba));
   ba.s[0] = BackStream{f.Wo1, P[CAMO_P_A1_OUT_B], f.W1, P[CAMO_P_F1_B0], P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], f.R16,

@@ -350,3 +350,37 @@ def test_wide_tail_matches_separate_launches(B, ncls, kg_real, fused_opts):
     assert_close(res[0], res[1], 2e-5, 1e-5, "one-launch wide tail vs five launches")
     ref, _ = FO.FusionOracle(cfg, OP.make_params(cfg, 5)).forward_list(rg, kg)
     assert_close(res[0], outs6(ref), 1e-3, 0, "wide tail vs oracle")
+
+
+def test_large_batch_training_takes_the_wide_front_half(kg_real, fused_opts):
+    """Training calls with at least 4 * 32 * 224 rows run the front half on 128-row blocks (fused_wide.hip, front8_kernel) and keep the
+    32-row back half: the same bf16 tensors leave the front launch, so outputs and loss terms agree to rounding and every parameter
+    gradient to a few 1e-4 of its tensor against the all-32-row schedule (fused_rt = 0) on the same masks."""
+    cfg = OP.full_cfg()
+    m = make_model(cfg, 4, "bf16")
+    m.train()
+    eng = m._engine
+    B = 70
+    nrs = [380 + 3 * (i % 50) for i in range(B)]              # T = 31 k rows
+    rg = np.concatenate([OP.make_rg(n, 128, seed=900 + i) for i, n in enumerate(nrs)])
+    kg = np.stack([kg_real] * B)
+    y, e, s = OP.make_labels(B, seed=21)
+    batch = eng.make_batch(torch.from_numpy(rg).cuda(), nrs, torch.from_numpy(kg).cuda())
+    res = []
+    for rt in (-1, 0):
+        fused_opts("fused_rt", rt)
+        ws = eng.workspace(batch, private=True)
+        ws.zero_()
+        g = eng.ensure_flat_grads(attach=True)
+        g.zero_()
+        outs, terms, pred = eng.train_raw(batch, ws, torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s), True, 41, eng._gtab)
+        torch.cuda.synchronize()
+        res.append((t2n(outs), t2n(terms), {k: t2n(p.grad).copy() for k, p in m.named_parameters()}))
+    fused_opts("fused_rt", -1)
+    (oa, ta, ga), (ob, tb, gb) = res
+    assert np.isfinite(oa).all()
+    assert_close(oa, ob, 2e-4, 1e-4, "outputs")
+    assert_close(ta, tb, 2e-4, 1e-4, "loss terms")
+    num = sum(float(((ga[k].astype(np.float64) - gb[k]) ** 2).sum()) for k in ga)
+    den = sum(float((gb[k].astype(np.float64) ** 2).sum()) for k in gb)
+    assert np.sqrt(num / den) < 1e-3, np.sqrt(num / den)
