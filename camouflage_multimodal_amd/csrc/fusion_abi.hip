@@ -1319,6 +1319,8 @@ int camo_debug_set_option(const char* name, int32_t value) {
   if (std::strcmp(name, "back_lead") == 0) { g_back_lead_mode = value; return 0; }
   if (std::strcmp(name, "tn_balance") == 0) { g_gemm16_balance = value; return 0; }
   if (std::strcmp(name, "tn_kcap") == 0) { g_gemm16_tn_kcap = value; return 0; }
+  if (std::strcmp(name, "tn_exp") == 0) { g_gemm16_exp = value; return 0; }
+  if (std::strcmp(name, "tn_big") == 0) { g_gemm16_tn_big = value; return 0; }
   return fail(CAMO_E_ARG, std::string("unknown option ") + name);
 }
 

@@ -54,10 +54,13 @@ struct Gemm16Batch {
   Gemm16Prob p[GEMM16_MAXP];
   int n;
   DropCfg drop;
+  int exp;           // developer experiments (0 in product calls)
   int n_heavy;       // (filled by the launcher) > 0: tiles [0, n_heavy) are split-K blocks with long K loops, the rest short ones
 };
 
 // Returns hipError_t as int; hipErrorInvalidValue for an unsupported problem.
+extern int g_gemm16_exp;
+extern int g_gemm16_tn_big;          // developer A/B: -1 by size, 0 never, 1 always (weight-gradient-only launches)
 extern int g_gemm16_balance;         // developer A/B: 0 = plain contiguous XCD remap
 extern int g_gemm16_tn_kcap;         // developer A/B: > 0 pins the split-K depth (64-row tiles per block) of weight-gradient problems
 int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream);

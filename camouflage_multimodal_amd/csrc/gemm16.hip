@@ -232,7 +232,7 @@ __device__ __forceinline__ void body_nt(const Gemm16Batch& gb, const Gemm16Prob&
 
 // ------------------------------------------------------------------------------------------ TN
 template <int PIPE, bool VIRT>
-__device__ __forceinline__ void body_tn(const Gemm16Prob& P, int m0, int n0, int kt0, int nt, char* smem) {
+__device__ __forceinline__ void body_tn(const Gemm16Prob& P, int m0, int n0, int kt0, int nt, char* smem, int exp = 0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
   const int M = P.M, N = P.N;
@@ -334,6 +334,7 @@ __device__ __forceinline__ void body_tn(const Gemm16Prob& P, int m0, int n0, int
 
   // C orientation: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   const int rowb = m0 + wr * 32 + 4 * h;
+  if ((exp & 1) && acc[0][0] != 12345.f) return;            // (experiment: no epilogue)
   if (do_bsum && l31 == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -610,9 +611,138 @@ __global__ __launch_bounds__(256, ROWS ? 2 : 3) void gemm16_kernel(const Gemm16B
     if constexpr (ROWS) {
       if (P.flags & GF_A_VIRT) { body_tn<PIPE, true>(P, tm * BM, tn * BN, kt0, min(per, ktiles - kt0), smem_raw); return; }
     }
-    body_tn<PIPE, false>(P, tm * BM, tn * BN, kt0, min(per, ktiles - kt0), smem_raw);
+    body_tn<PIPE, false>(P, tm * BM, tn * BN, kt0, (gb.exp & 2) ? 2 : min(per, ktiles - kt0), smem_raw, gb.exp);
   } else {
     body_nt<PIPE>(gb, P, tm * BM, tn * BN, smem_raw);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ TN, 128 x 256 tiles on 8 waves
+// Weight gradients of long contractions (K = packed rows >= 40 000).  The 64 x 128 tile's K loop waits for operand bytes, not
+// for MFMA (0.75 us per 64-row step with two blocks per CU: 24 KB per 1.05 MFLOP); this tile moves 48 KB per 4.2 MFLOP --
+// half the bytes per FLOP at the same bytes in flight per CU (one block of 8 waves, two register stages of 2 + 4 chunks per
+// thread).  Waves 2 (M) x 4 (N), 64 x 64 each: two A and two B fragments feed four MFMAs per 16-deep step.  The price is
+// fewer output tiles, hence more K splits (more fp32 atomics) to fill the chip: taken only where the K loop dominates.
+constexpr int GM = 128, GN = 256;
+constexpr int GPA = 320, GPB = 576;                 // k-row pitches (bytes): 64 mod 256, like PKA / PKB
+constexpr int GA_BYTES = BK * GPA;                  // 20480
+constexpr int GBUF_BYTES = GA_BYTES + BK * GPB;     // 57344 per stage
+
+template <int PIPE>
+__global__ __launch_bounds__(512) void gemm16_tnbig_kernel(const Gemm16Batch gb, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bid = blockIdx.x;
+  {   // XCD-aware remap (see gemm16_kernel): an XCD takes a contiguous run of blocks = the output tiles of a few K slices
+    const int nwg = total_tiles, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    bid = xcd * q + min(xcd, r) + j;
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM16_MAXP; ++i)
+    if (i < gb.n && bid >= gb.p[i].tile_begin) pi = i;
+  const Gemm16Prob& P = gb.p[pi];
+  int t = bid - P.tile_begin;
+  const int tiles = ((P.M + GM - 1) / GM) * P.tiles_n;
+  const int ks = t / tiles; t -= ks * tiles;
+  const int n0 = (t % P.tiles_n) * GN, m0 = (t / P.tiles_n) * GM;
+  const int ktiles = (P.K + 127) / 128 * 2;                   // K rounded up to 128 rows (pad rows are zero), in 64-row tiles
+  const int per = P.kchunk / BK, kt0 = ks * per, nt = min(per, ktiles - kt0);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3, l31 = lane & 31, h = lane >> 5;
+  const int M = P.M, N = P.N;
+  uint32_t goa[2], gob[4];
+  int la[2], lb[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {                               // A tile = 64 k rows x 16 chunks (8 m each)
+    const int s = tid + 512 * i, kr = s >> 4, c = s & 15;
+    goa[i] = ((uint32_t)kr * (uint32_t)P.lda + (uint32_t)min(m0 + 8 * c, M - 8)) * 2u;
+    la[i] = kr * GPA + 16 * c;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                               // B tile = 64 k rows x 32 chunks (8 n each)
+    const int s = tid + 512 * i, kr = s >> 5, c = s & 31;
+    gob[i] = ((uint32_t)kr * (uint32_t)P.ldb + (uint32_t)min(n0 + 8 * c, N - 8)) * 2u;
+    lb[i] = GA_BYTES + kr * GPB + 16 * c;
+  }
+  const char* Ab = reinterpret_cast<const char*>(P.A);
+  const char* Bb = reinterpret_cast<const char*>(P.B);
+  const size_t astep = (size_t)BK * P.lda * 2, bstep = (size_t)BK * P.ldb * 2;
+
+  f32x16 acc[2][2], accb[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f; accb[0][r] = 0.f; accb[1][r] = 0.f; }
+  const bool do_bsum = P.bias_grad != nullptr && n0 == 0 && wc == 0;     // wave-uniform
+  const short one = (short)0x3F80;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
+  Stage st[PIPE];
+
+  auto gloadi = [&](int j, int kt) {
+    const int k = kt0 + min(kt, nt - 1);                      // (block-uniform; tiles past nt are reloads that are never multiplied)
+    const char* a = Ab + (size_t)k * astep;
+    const char* b = Bb + (size_t)k * bstep;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) st[j].a[i] = *reinterpret_cast<const u32x4*>(a + goa[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st[j].b[i] = *reinterpret_cast<const u32x4*>(b + gob[i]);
+  };
+  auto sstorei = [&](int j, int buf) {
+    char* base = smem + buf * GBUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(base + la[i]) = st[j].a[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(base + lb[i]) = st[j].b[i];
+  };
+  // transposing reads (see body_tn): lane = 16 g + 4 q + p of its half supplies (k row 8 h + q, columns 16 g + 4 p ..)
+  const int g = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+  const int fa = (8 * h + q) * GPA + 128 * wr + 32 * g + 8 * p;
+  const int fb = GA_BYTES + (8 * h + q) * GPB + 128 * wc + 32 * g + 8 * p;
+  auto frag = [&](const char* q0, int pitch) {
+    const s16x4 lo = lds_tr16(q0), hi = lds_tr16(q0 + 4 * pitch);
+    return bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  };
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * GBUF_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const char* pa = base + fa + 16 * s * GPA;
+      const char* pb = base + fb + 16 * s * GPB;
+      const bf16x8 a0 = frag(pa, GPA), a1 = frag(pa + 64, GPA);
+      const bf16x8 b0 = frag(pb, GPB), b1 = frag(pb + 64, GPB);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+      if (do_bsum) {                                          // row sums of dy^T
+        accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, ones, accb[0], 0, 0, 0);
+        accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ones, accb[1], 0, 0, 0);
+      }
+    }
+  };
+  G16_PIPELINE_LOOP
+
+  // C orientation: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rowb = m0 + 64 * wr + 32 * i + 4 * h;
+    if (do_bsum && l31 == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowb + (r & 3) + 8 * (r >> 2);
+        if (row < M) atomicAdd(P.bias_grad + row, accb[i][r]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + 64 * wc + 32 * j + l31;
+      if (col >= N) continue;
+      float* cp = P.C + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowb + (r & 3) + 8 * (r >> 2);
+        if (row < M) atomicAdd(cp + (size_t)row * P.ldc, acc[i][j][r]);
+      }
+    }
   }
 }
 
@@ -621,6 +751,45 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
+int g_gemm16_exp = 0;
+int g_gemm16_tn_big = -1;             // developer A/B ("tn_big"): -1 by size, 0 never, 1 whenever the launch is weight gradients only
+static int launch_tnbig(Gemm16Batch& gb, hipStream_t stream) {
+  int total = 0;
+  static const int kcaps[] = {512, 384, 256, 192, 128, 96, 64, 48, 32, 24, 16, 12, 8, 6, 4};
+  for (int ci = 0;; ++ci) {
+    const int kcap = g_gemm16_tn_kcap > 0 ? g_gemm16_tn_kcap : kcaps[ci];
+    total = 0;
+    for (int i = 0; i < gb.n; ++i) {
+      Gemm16Prob& p = gb.p[i];
+      if (p.M < 8 || p.N < 8 || p.K < 1 || !p.C || p.C16 || p.bias || p.res || !al16(p.A) || !al16(p.B) || (p.lda & 7) || (p.ldb & 7))
+        return (int)hipErrorInvalidValue;
+      if ((double)(p.K + 128) * p.lda * 2.0 >= 4.0e9 || (double)(p.K + 128) * p.ldb * 2.0 >= 4.0e9) return (int)hipErrorInvalidValue;
+      p.tiles_n = (p.N + GN - 1) / GN;
+      const int tiles = ((p.M + GM - 1) / GM) * p.tiles_n;
+      const int ktiles = (p.K + 127) / 128 * 2;
+      const int per = ktiles < kcap ? ktiles : kcap;                       // even
+      p.kchunk = per * BK;
+      p.ksplit = (ktiles + per - 1) / per;
+      p.tile_begin = total;
+      total += tiles * p.ksplit;
+    }
+    if (g_gemm16_tn_kcap > 0 || total >= 224 || kcap <= 4) break;         // ~ one block per CU
+  }
+  gb.n_heavy = 0; gb.exp = g_gemm16_exp;
+  static const bool attr_ok = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_tnbig_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GBUF_BYTES);
+    return true;
+  }();
+  (void)attr_ok;
+  double fl = 0.0;
+  for (int i = 0; i < gb.n; ++i) fl += 2.0 * gb.p[i].M * (double)gb.p[i].N * gb.p[i].K;
+  const int prof = gemm_prof_open(stream, fl);
+  // (four register stages measured the same as two: the K loop is bound by its LDS transposing reads -- SQ_ACTIVE_INST_LDS 80 % of
+  // the kernel's busy cycles, no bank conflicts -- not by load latency)
+  hipLaunchKernelGGL((gemm16_tnbig_kernel<2>), dim3(total), dim3(512), 2 * GBUF_BYTES, stream, gb, total);
+  gemm_prof_close(prof, stream);
+  return (int)hipGetLastError();
+}
 int g_gemm16_balance = 1;             // developer A/B ("tn_balance")
 int g_gemm16_tn_kcap = 0;             // developer A/B (camo_debug_set_option "tn_kcap"): > 0 pins the split-K depth
 int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
@@ -631,6 +800,17 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
   // are more blocks than that (measured, bf16 training step: B = 16 -> 16 tiles [8: +12 us, 32: +8 us]; B = 64 -> 64 tiles
   // [16: +18 us, 8: +56 us]); a launch that would leave most CUs idle even at 16 (the general schedule's lone dW_rg / dW_kg
   // launch) goes down to 8 to spread over the chip.
+  // long weight-gradient contractions: 128 x 256 tiles on 8 waves (gemm16_tnbig_kernel)
+  {
+    bool all_tn = true; int kmax = 0;
+    for (int i = 0; i < gb.n; ++i) {
+      const Gemm16Prob& p = gb.p[i];
+      all_tn = all_tn && (p.flags & GF_A_KMAJOR) && (p.flags & GF_B_KMAJOR) && !(p.flags & GF_A_VIRT) && !p.ln_mode && (p.M % 8) == 0 && (p.N % 8) == 0;
+      kmax = p.K > kmax ? p.K : kmax;
+    }
+    const bool big = g_gemm16_tn_big < 0 ? kmax >= 40000 : g_gemm16_tn_big > 0;    // (measured: B = 64 [27 k rows] +8 %, B = 128 [55 k] -7 %, B = 256 [125 k] -15 %)
+    if (all_tn && big) return launch_tnbig(gb, stream);
+  }
   int total = 0, kcap_used = 0;
   static const int kcaps[] = {512, 384, 256, 192, 128, 96, 64, 48, 32, 24, 16, 8};
   for (int ci = 0;; ++ci) {
@@ -678,7 +858,7 @@ int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
     }
     if (g_gemm16_tn_kcap > 0 || (kcap > 16 ? total >= 440 : total >= 200) || kcap <= KCAP_MIN) break;
   }
-  gb.n_heavy = 0;
+  gb.n_heavy = 0; gb.exp = g_gemm16_exp;
   // (measured on the training step: B = 4 -2.8 us, B = 16 +-0, B = 64 +0.7 us -- with long chunks the short blocks no longer
   // matter and the plain runs keep a K slice's tiles together; hence only up to 16-tile chunks)
   if (g_gemm16_balance && kcap_used <= 16) {                  // a prefix of split-K problems followed by single-slice ones only
