@@ -23,7 +23,7 @@ def table(path):
     for r in rows:
         name = short(r["Kernel_Name"])
         # a step starts with the shadow launch, or -- when the optimizer left the shadows ready -- with the front kernel
-        if name == "shadow_kernel" or (name.startswith("front_kernel") and prev != "shadow_kernel"):
+        if name == "shadow_kernel" or (name.startswith(("front_kernel", "front8_kernel")) and prev != "shadow_kernel"):
             if cur: steps.append(cur)
             cur = []
         if cur is not None: cur.append(r)
