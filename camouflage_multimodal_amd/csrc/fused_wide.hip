@@ -49,7 +49,12 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // Developer timeline (testing hook "stamps"): lane 0 of every wave records the 100 MHz wall clock at phase boundaries:
 // stamps[(block * 8 + wave) * 16 + k].  Product calls pass null and execute none of it.
 __device__ __forceinline__ void stamp(unsigned long long* stamps, int k) {
-  if (stamps && (threadIdx.x & 63) == 0) stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + k] = __builtin_amdgcn_s_memrealtime();
+  if (stamps && (threadIdx.x & 63) == 0) {
+    unsigned long long* p = stamps + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16;
+    p[k] = __builtin_amdgcn_s_memrealtime();
+    if (k == 0) p[11] = __builtin_amdgcn_s_memtime();        // shader-clock counter at the block's first and last stamp (slots 11, 15):
+    if (k == 12) p[15] = __builtin_amdgcn_s_memtime();       // the clock the CU actually ran at = their difference / the wall-clock interval
+  }
 }
 __device__ __forceinline__ void store16_wt(void* p, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");   // (s_nop: the data registers may be rewritten right behind an asm store)

@@ -16,6 +16,9 @@ b0 = make_batches(1, B, 0)[0]
 rg, nrs, kg = torch.from_numpy(b0[0]).cuda(), b0[1], torch.from_numpy(b0[2]).cuda()
 NB = 32768
 _lib.lib().camo_debug_set_option(b"fused_rt", rt)
+for kv in sys.argv[3:]:
+    if "=" in kv:
+        _lib.lib().camo_debug_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1]))
 if "--two" in sys.argv:
     _lib.lib().camo_debug_set_option(b"fused_one", 0)
 buf = torch.zeros(5 * NB * 8, dtype=torch.int64, device="cuda")
@@ -59,5 +62,9 @@ for k, name in enumerate(("front", "back")):
         rel = (sel[:, :, slot] - sel[:, :, 0].min(axis=1, keepdims=True)) / 100
         print(f"   {slot:2d} {names[name][slot]:26s} wave-median {np.median(d):6.2f}  max {d.max():6.2f} | reached at (from block start) median {np.median(rel):6.2f}, slowest wave median {np.median(rel.max(axis=1)):6.2f}; wave 0 vs wave 4: {np.median(rel[:, 0]):.2f} / {np.median(rel[:, 4]):.2f}")
         prev = slot if slot not in (9, 10) else prev
+    if name == "back" and one:
+        ok = (s[:, :, 15] > 0) & (s[:, :, 11] > 0) & (s[:, :, 12] > s[:, :, 0])
+        mhz = (s[:, :, 15] - s[:, :, 11])[ok] / ((s[:, :, 12] - s[:, :, 0])[ok] / 100.0)
+        print(f"   shader clock over a block (s_memtime ticks per us of s_memrealtime): median {np.median(mhz):.0f}, min {mhz.min():.0f}, max {mhz.max():.0f}")
     pts = np.linspace(t0, end.max(), 12)[1:-1]
     print("   running blocks over the span:", [int(((start <= p) & (end > p)).sum()) for p in pts])
