@@ -22,12 +22,20 @@ __global__ __launch_bounds__(256) void batchdesc_kernel(const int* __restrict__ 
   const int T = offs[B];
   int s = 0;
   for (int b = b0; b < b1; ++b) s += (offs[b + 1] - offs[b] + 31) >> 5;
-  part[t] = s;
-  __syncthreads();
-  if (t == 0) {
-    int acc = 0;
-    for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = acc; acc += v; }
-    total_s = acc;
+  // exclusive scan of the 256 chunk sums: in-wave by DPP-free shuffles, the four wave totals through LDS (a serial loop in one
+  // thread was 256 dependent LDS round trips: most of this launch's 13 us)
+  {
+    const int lane = t & 63, w = t >> 6;
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) part[w] = incl;
+    __syncthreads();
+    const int w0 = part[0], w1 = part[1], w2 = part[2], w3 = part[3];
+    __syncthreads();
+    const int base = w == 0 ? 0 : (w == 1 ? w0 : (w == 2 ? w0 + w1 : w0 + w1 + w2));
+    part[t] = base + incl - s;
+    if (t == 0) total_s = w0 + w1 + w2 + w3;
   }
   __syncthreads();
   const int ntiles = total_s;
@@ -51,8 +59,8 @@ __global__ __launch_bounds__(256) void batchdesc_kernel(const int* __restrict__ 
       int4 d = make_int4(-1, 0, 0, 0);
       if (tl < ntiles) {
         // sample of tile tl: the scan gives tile offsets per thread chunk; search the chunk starts, then walk the chunk
-        int c = 0;
-        for (int i = 1; i < 256; ++i) if (part[i] <= tl && min(B, i * per) < B) c = i;      // (last chunk whose first tile is <= tl)
+        int c = 0, hi = (B + per - 1) / per - 1;                 // last non-empty chunk whose first tile is <= tl (part[] is non-decreasing)
+        while (c < hi) { const int mid = (c + hi + 1) >> 1; if (part[mid] <= tl) c = mid; else hi = mid - 1; }
         int b = min(B - 1, c * per), acc = part[c];
         while (b + 1 < B) { const int n = (offs[b + 1] - offs[b] + 31) >> 5; if (acc + n > tl) break; acc += n; ++b; }
         const int r0 = offs[b] + 32 * (tl - acc), nr = offs[b + 1] - offs[b];

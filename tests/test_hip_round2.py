@@ -446,3 +446,44 @@ def test_gather_batch_kernel_matches_index_ops_and_augments_in_distribution():
     assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 0.01
     rg_b, *_ = aug.batch(idx)                                                # a second draw: other noise
     assert not torch.equal(rg, rg_b)
+
+
+@pytest.mark.parametrize("B,lo,hi", [(1, 5, 6), (17, 1, 200), (300, 1, 90), (1000, 1, 70), (64, 300, 531)])
+def test_batch_descriptor_tables(B, lo, hi):
+    """camo_prepare_batch (misc.hip, batchdesc_kernel: one launch) against a host restatement of the tables it builds: row -> sample,
+    1 / Nr, the first 32-row tile of every sample and the per-tile {sample, first packed row, rows, 1 / Nr} entries; -1 marks the unused
+    tail of the tile table.  B > 256 takes the several-samples-per-thread scan."""
+    import ctypes as C
+    from camouflage_multimodal_amd import _lib
+    rs = np.random.RandomState(B)
+    nrs = rs.randint(lo, hi, size=B).astype(np.int64)
+    offs = np.zeros(B + 1, np.int32); offs[1:] = np.cumsum(nrs)
+    T = int(offs[-1])
+    L = _lib.lib()
+    nbytes = L.camo_batch_desc_bytes(B, T)
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    offs_d = torch.from_numpy(offs).cuda()
+    _lib.check(L.camo_prepare_batch(C.c_void_p(offs_d.data_ptr()), B, T, int(nrs.max()), C.c_void_p(buf.data_ptr()), nbytes,
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "camo_prepare_batch")
+    raw = buf.cpu().numpy()
+    al = lambda x: (x + 255) & ~255
+    o = 0
+    row_sample = raw[o:o + 4 * T].view(np.int32); o = al(o + 4 * T)
+    inv_nr = raw[o:o + 4 * B].view(np.float32); o = al(o + 4 * B)
+    tile_off = raw[o:o + 4 * (B + 1)].view(np.int32); o = al(o + 4 * (B + 1))
+    ntab = T // 32 + B
+    tile_desc = raw[o:o + 16 * ntab].view(np.int32).reshape(ntab, 4)
+    assert np.array_equal(row_sample, np.repeat(np.arange(B), nrs))
+    assert np.array_equal(inv_nr, (1.0 / nrs.astype(np.float32)).astype(np.float32))
+    tiles = (nrs + 31) // 32
+    want_off = np.zeros(B + 1, np.int64); want_off[1:] = np.cumsum(tiles)
+    assert np.array_equal(tile_off, want_off)
+    want = np.full((ntab, 4), 0, np.int32); want[:, 0] = -1
+    k = 0
+    for b in range(B):
+        for j in range(int(tiles[b])):
+            r0 = int(offs[b]) + 32 * j
+            want[k] = (b, r0, min(32, int(offs[b + 1]) - r0), np.float32(1.0 / np.float32(nrs[b])).view(np.int32))
+            k += 1
+    assert np.array_equal(tile_desc[:k], want[:k])
+    assert (tile_desc[k:, 0] == -1).all()
