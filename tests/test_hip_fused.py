@@ -239,12 +239,13 @@ def test_fused_backward_stage_by_stage(training, kg_real, fused_opts):
     assert all(r < 1e-2 for r, n, _ in rels if n > 1e-3 * gn), rels[:6]
 
 
-@pytest.mark.parametrize("training,B", [(False, 9), (True, 16), (True, 1), (True, 6), (True, 13), (True, 3), (True, 17), (True, 40), (True, 48), (False, 33)])
-def test_one_launch_tail_matches_separate_launches(training, B, kg_real, fused_opts):
+@pytest.mark.parametrize("training,B,ncls", [(False, 9, 2), (True, 16, 2), (True, 1, 2), (True, 6, 2), (True, 13, 2), (True, 3, 2), (True, 17, 2), (True, 40, 2), (True, 48, 2),
+                                              (False, 33, 2), (True, 35, 5), (True, 11, 8)])
+def test_one_launch_tail_matches_separate_launches(training, B, ncls, kg_real, fused_opts):
     """The per-sample tail as ONE launch of 64 co-resident blocks per group of 16 samples (misc.hip, tail_fused_kernel: split weights,
-    three in-kernel all-reduces; B > 16: independent groups, weight gradients merged by atomics) against the ten separate launches it replaces, on the same fused node-level kernels: outputs, loss terms,
+    three in-kernel all-reduces; B > 16: independent groups, the big weight gradients in one batched launch behind it) against the ten separate launches it replaces, on the same fused node-level kernels: outputs, loss terms,
     predictions and every parameter gradient.  Both tails compute in exact fp32; they differ in summation order only."""
-    cfg = OP.full_cfg()
+    cfg = OP.full_cfg(dict(num_classes=ncls))
     m = make_model(cfg, 4, "bf16")
     m.train(training)
     eng = m._engine
