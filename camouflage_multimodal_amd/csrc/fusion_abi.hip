@@ -519,9 +519,10 @@ static void bind_shadows(Ws& w) {                 // (after every carve() of a c
 // per CU is all there is); 2 / 4 = that many tiles per block of 8 waves (fused_wide.hip), chosen so that the blocks still fill the chip.
 static int wide_rt(int T, int max_nr, bool save = false) {
   int rt = g_opt_fused_rt;
-  // by size: inference calls with at least ~one 128-row block per CU.  Calls that save for a backward stay on the 32-row kernels:
+  // by size: inference calls from about half a 128-row block per CU on (64-row blocks below that).  Calls that save for a backward stay on the 32-row kernels:
   // the saved-tensor stores of the one-launch kernel are not tuned yet (measured slower: B = 64 step 0.53 vs 0.40 ms)
-  if (rt < 0) rt = (!save && T >= 4 * 32 * 224) ? 4 : 0;
+  // (measured eval forward, us: B = 32 [13.5 k rows] 87 / 85 / 103 for 32-row / 2 / 4 tiles per block; B = 48 [20 k] 116 / 103 / 106; B = 56 [24 k] 131 / 112 / 108)
+  if (rt < 0) rt = save ? 0 : (T >= 22528 ? 4 : (T >= 13312 ? 2 : 0));
   if (rt != 0 && rt != 1 && rt != 2 && rt != 4) rt = 0;
   if (rt && max_nr > wide_max_rows(rt) - 64 * rt) rt = 0;
   return rt;
