@@ -529,7 +529,9 @@ static int wide_rt(int T, int max_nr, bool save = false) {
 }
 
 static bool tailw_taken(const camo_dims_t& d, int B, int T, int max_nr, bool save) {
-  return g_opt_tailw != 0 && g_opt_fused_one != 0 && wide_rt(T, max_nr, save) >= 2 && tail_wide_ok(B, d.num_classes);
+  // (B <= 32: the grouped fp32 tail, forward only, is the shorter one: 29.8 vs 33.5 us at B = 32; equal at 48)
+  return g_opt_tailw != 0 && g_opt_fused_one != 0 && wide_rt(T, max_nr, save) >= 2 && tail_wide_ok(B, d.num_classes) &&
+         (g_opt_tailw > 0 || B > 32 || !tail_fused_ok(B, d.num_classes));
 }
 
 int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg, const int32_t* rg_offsets, const Desc& bd,

@@ -343,7 +343,7 @@ def test_wide_tail_matches_separate_launches(B, ncls, kg_real, fused_opts):
     batch = eng.make_batch(torch.from_numpy(np.concatenate(rg)).cuda(), nrs, torch.from_numpy(kg).cuda())
     fused_opts("fused_rt", 4)
     res = []
-    for mode in (-1, 0):
+    for mode in (1, 0):                                     # (1: the two-plane tail also where the size rule prefers the grouped fp32 tail, B <= 32)
         fused_opts("tailw", mode)
         o, _ = eng.forward_raw(batch, eng.workspace(batch, private=True), False, 7, inference=True, cache_shadows=False)
         res.append(t2n(o))
