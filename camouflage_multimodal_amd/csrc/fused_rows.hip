@@ -1187,6 +1187,174 @@ __global__ __launch_bounds__(256, 2) void bwd2_kernel(const Bwd2Args a) {
   stamp(a.stamps, 3);
 }
 
+// ------------------------------------------------------------------------------------------------ backward, second half without the input-gradient products (Bwd2Args::param_space)
+// RG tiles: the KG->RG attention backward for the tile's 32 key/value rows (probabilities recomputed from the saved softmax
+// max / sum), i.e. dK2, dV2 per row -- the last columns of the weight-gradient operand [dQ | dK2 | dV2] -- and the tile's
+// contribution to the sample's dQ2 (fp32 atomics).  The last tile of a sample to finish (arrival counter, as in the forward) turns
+// the sample's dQ2 sums into the KG rows' operand columns; B early blocks do the same for the first half's dK | dV sums.
+// There is no input-gradient product here any more: nothing needs dR = dU + [dQ|dK2|dV2].W once the projection's weight gradient
+// is taken in parameter space (fusion_abi.hip, backward_nodes17):  dW_p = dU^T x + W_in^T (dQKV^T x),  dW_in = (dQKV^T x) W_p^T + db b_p^T.
+
+template <int DEPTH, bool ROT>
+__global__ __launch_bounds__(256, 2) void bwd2p_kernel(const Bwd2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Nk = a.Nk;
+  char* Q2s = smem + X_Q2S; char* dO2s = smem + X_DO2S; float* tabs = reinterpret_cast<float*>(smem + X_TABS);
+  char* bufT = smem + X_BUFT; char* imgs = smem + X_IMGS;
+  int* flag = reinterpret_cast<int*>(smem + X_RED);
+  stamp(a.stamps, 0);
+  const bool early = (int)blockIdx.x < a.B;          // the B early blocks: the part of dG that needs no RG tile of this launch
+  int b;
+  if (early) {
+    // the dK | dV columns of the KG rows' weight-gradient operand: fp32 sums of the first half -> bf16.  Counts as one arrival of its sample.
+    b = blockIdx.x;
+    const size_t krow0 = (size_t)b * Nk;
+    for (int c = tid; c < 32 * 64; c += 256) {
+      const int j = c >> 6, ch = c & 63;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (j < Nk) {
+        const float* src = a.dKV + (krow0 + j) * 512 + 8 * ch;
+        const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+        v = u32x4{pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w)};
+      }
+      *reinterpret_cast<u32x4*>(bufT + j * PQ + 512 + 16 * ch) = v;
+    }
+    __syncthreads();
+    copy_out<6>(bufT, PQ, 512, a.dQKVkg16 + 256, 768, krow0, Nk);
+  } else {
+  const int4 td = a.tile_desc[(int)blockIdx.x - a.B];
+  if (td.x < 0) return;
+  b = td.x;
+  const size_t rowg0 = td.y;
+  const int nrows = td.z;
+  const bool rok = l31 < nrows;
+  const size_t vrow = rowg0 + min(l31, nrows - 1);
+  // per-sample inputs: the Nk pre-scaled queries, the gradient of their attention output, softmax max / 1/sum, row-dots
+  for (int c = tid; c < 16 * 32; c += 256) {
+    const int j = c >> 5, ch = c & 31;
+    u32x4 q = u32x4{0u, 0u, 0u, 0u}, o = q;
+    if (j < Nk) {
+      q = *reinterpret_cast<const u32x4*>(a.Q2_16 + ((size_t)b * Nk + j) * 256 + 8 * ch);
+      o = *reinterpret_cast<const u32x4*>(a.dO2_16 + ((size_t)b * Nk + j) * 256 + 8 * ch);
+    }
+    *reinterpret_cast<u32x4*>(Q2s + j * PK + 16 * ch) = q;
+    *reinterpret_cast<u32x4*>(dO2s + j * PK + 16 * ch) = o;
+  }
+  if (tid < 128) {
+    const int j = tid & 15;
+    const size_t o = (size_t)b * 128 + tid;                  // [b][head][16]
+    const bool ok = j < Nk;
+    tabs[tid] = ok ? a.lse2[2 * o] : 0.f;
+    tabs[128 + tid] = ok ? 1.0f / a.lse2[2 * o + 1] : 0.f;
+    tabs[256 + tid] = ok ? a.delta2[o] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                              // slot id -> row id >> 5, 16-byte chunk id & 31: key tile into LDS
+    const int id = tid + 256 * i;
+    const size_t r = rowg0 + min(id >> 5, nrows - 1);
+    *reinterpret_cast<u32x4*>(bufT + (id >> 5) * PQ + 16 * (id & 31)) = *reinterpret_cast<const u32x4*>(a.KV2_16 + r * 512 + 8 * (id & 31));
+  }
+  bf16x8 kf[2][2], vf[2][2];
+  {
+    const us16* kp = a.KV2_16 + vrow * 512 + 64 * w + 8 * h;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        kf[t][s] = as_frag(*reinterpret_cast<const u32x4*>(kp + 32 * t + 16 * s));
+        vf[t][s] = as_frag(*reinterpret_cast<const u32x4*>(kp + 256 + 32 * t + 16 * s));
+      }
+  }
+  __syncthreads();
+  const bool dodrop = a.drop.p > 0.f;
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int head = 2 * w + t;
+    f32x16 S2 = zero16(), dP = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int co = (l31 & 15) * PK + 2 * (32 * head + 16 * s + 8 * h);
+      S2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Q2s + co), kf[t][s], S2, 0, 0, 0);     // [query j][row]
+      dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(dO2s + co), vf[t][s], dP, 0, 0, 0);    // dO2[j] . V2[row]
+    }
+    float ds[8], pd[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = acc_row(i, h);
+      const float p = (j < Nk && rok) ? __expf(S2[i] - tabs[head * 16 + j]) * tabs[128 + head * 16 + j] : 0.f;
+      const float mm = dodrop ? drop_mult(a.drop, SITE_ATTN_KG2RG, ((uint32_t)(rowg0 + l31) * 8u + (uint32_t)head) * (uint32_t)Nk + (uint32_t)j) : 1.0f;
+      ds[i] = p * (dP[i] * mm - tabs[256 + head * 16 + j]);
+      pd[i] = p * mm;
+    }
+    const u32x4 dsf = u32x4{pack2(ds[0], ds[1]), pack2(ds[2], ds[3]), pack2(ds[4], ds[5]), pack2(ds[6], ds[7])};
+    const u32x4 pdf = u32x4{pack2(pd[0], pd[1]), pack2(pd[2], pd[3]), pack2(pd[4], pd[5]), pack2(pd[6], pd[7])};
+    // dV2^T = dO2_h^T . P2d,  dK2^T = Q2s_h^T . dS2: lane = row, registers = the head's 32 features -> bf16 tile [dQ | dK2 | dV2]
+    const int tro = (4 * h + q4) * PK + 2 * (32 * head + 16 * g1 + 4 * p4);
+    const f32x16 dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join(lds_tr16(dO2s + tro), lds_tr16(dO2s + tro + 8 * PK)), as_frag(pdf), zero16(), 0, 0, 0);
+    const f32x16 dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join(lds_tr16(Q2s + tro), lds_tr16(Q2s + tro + 8 * PK)), as_frag(dsf), zero16(), 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * head + 8 * g + 4 * h;
+      *reinterpret_cast<u32x2*>(bufT + l31 * PQ + 2 * (256 + c)) = u32x2{pack2(dk[4 * g], dk[4 * g + 1]), pack2(dk[4 * g + 2], dk[4 * g + 3])};
+      *reinterpret_cast<u32x2*>(bufT + l31 * PQ + 2 * (512 + c)) = u32x2{pack2(dv[4 * g], dv[4 * g + 1]), pack2(dv[4 * g + 2], dv[4 * g + 3])};
+    }
+    // dQ2_h[j][f] += scale * sum_rows dS2[j][row] * K2[row][f]: dS2 image [row][16 queries] and the key tile read transposed
+    char* im = imgs + head * 1024;
+    *reinterpret_cast<u32x2*>(im + l31 * 32 + 8 * h) = u32x2{dsf.x, dsf.y};
+    *reinterpret_cast<u32x2*>(im + l31 * 32 + 16 + 8 * h) = u32x2{dsf.z, dsf.w};
+    f32x16 dq2 = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int r0 = 16 * s + 8 * h + q4;
+      const bf16x8 sA = join(lds_tr16(im + r0 * 32 + 8 * p4), lds_tr16(im + (r0 + 4) * 32 + 8 * p4));
+      const int co = 2 * (32 * head + 16 * g1 + 4 * p4);
+      const bf16x8 kB = join(lds_tr16(bufT + r0 * PQ + co), lds_tr16(bufT + (r0 + 4) * PQ + co));
+      dq2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sA, kB, dq2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = acc_row(i, h);
+      if (j < Nk) atomicAdd(a.dQ2acc + ((size_t)b * Nk + j) * 256 + 32 * head + l31, dq2[i] * a.qscale);
+    }
+  }
+  __syncthreads();                                           // key tile consumed by every wave; dK2 | dV2 tile complete
+  stamp(a.stamps, 1);
+  copy_out<6>(bufT, PQ, 512, a.dQKV16 + 256, 768, rowg0, nrows);     // the weight-gradient operand's dK2 | dV2 columns (dQ: the first half's)
+  stamp(a.stamps, 2);
+  }
+  // ---- arrival: the last block of the sample (its RG tiles and its early block) finishes the KG rows' product.  What it reads from the other
+  // tiles are the dQ2 sums, fp32 atomics that execute at the memory side (no L2 line to write back), so a tile only has
+  // to have its atomics acknowledged (vmcnt) before its ticket; everything else it reads is the previous launch's.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) flag[0] = __hip_atomic_fetch_add(a.tickets + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (flag[0] != a.tile_off[b + 1] - a.tile_off[b]) return;          // (tiles + the early block)
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  // dQ2 of the sample's Nk rows: fp32 sums -> bf16 tile (rows >= Nk cleared)
+  const size_t krow0 = (size_t)b * Nk;
+  for (int c = tid; c < 32 * 32; c += 256) {
+    const int j = c >> 5, ch = c & 31;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (j < Nk) {
+      const float* src = a.dQ2acc + (krow0 + j) * 256 + 8 * ch;
+      const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+      v = u32x4{pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w)};
+    }
+    *reinterpret_cast<u32x4*>(bufT + j * PQ + 16 * ch) = v;
+  }
+  __syncthreads();
+  copy_out<5>(bufT, PQ, 0, a.dQKVkg16, 768, krow0, Nk);
+  stamp(a.stamps, 3);
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -1325,13 +1493,16 @@ int launch_fused_bwd2(Bwd2Args& a, int variant, hipStream_t stream) {
   if (!al16(a.dQKV16) || !al16(a.dQKVkg16) || !al16(a.WcRgT) || !al16(a.WcKgT) || !al16(a.dQ2acc) || !al16(a.dKV)) return (int)hipErrorInvalidValue;
   static const bool attr = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd2_kernel<12, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd2p_kernel<12, false>), hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS);
     return true;
   }();
   (void)attr;
-  // executed FLOPs per row: dR / dG (768 -> 256); RG rows: the KG->RG attention backward (5 products of Nk x 256)
+  // executed FLOPs per row: dR / dG (768 -> 256) unless the caller takes those gradients in parameter space; RG rows: the KG->RG
+  // attention backward (5 products of Nk x 256)
   const double rows = (double)a.rows_rg + (double)a.B * a.Nk;
-  const int prof = gemm_prof_open(stream, 2.0 * rows * 768.0 * 256.0 + 10.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BWD2);
-  hipLaunchKernelGGL((bwd2_kernel<12, false>), dim3(a.B + a.rg_tiles_max), dim3(256), X_LDS, stream, a);
+  const int prof = gemm_prof_open(stream, (a.param_space ? 0.0 : 2.0 * rows * 768.0 * 256.0) + 10.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BWD2);
+  if (a.param_space) hipLaunchKernelGGL((bwd2p_kernel<12, false>), dim3(a.B + a.rg_tiles_max), dim3(256), X_LDS, stream, a);
+  else               hipLaunchKernelGGL((bwd2_kernel<12, false>), dim3(a.B + a.rg_tiles_max), dim3(256), X_LDS, stream, a);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }

@@ -39,6 +39,7 @@ int g_opt_sched16 = -1;
 int g_opt_fused = -1;      // likewise for the fused row-tile schedule (fused_rows.h): 0 = never take it
 unsigned long long* g_dbg_stamps = nullptr;   // testing hook: timeline buffer of the fused kernels ([2][blocks][8] 100 MHz ticks)
 int g_dbg_stamp_blocks = 0;
+int g_opt_param_space = -1;                   // -1 by size, 0 / 1: the fused backward's parameter-space weight gradients (backward_nodes17)
 int g_opt_tail17 = -1;                        // 0 = never take the one-launch tail (misc.hip, tail_fused_kernel)
 int g_opt_fused_variant = 1;                  // developer A/B of the fused kernels' weight streaming (fused_rows.h)
 int g_opt_fused_rt = -1;     // wide row tiles (fused_wide.hip): -1 = by batch size, 0 = never, 1 / 2 / 4 = that many 32-row tiles per block
@@ -120,6 +121,7 @@ struct Ws {
   } f;
   int* tickets;         // [2][B] arrival counters (forward: KG->RG attention splits; backward: a sample's RG tiles), in the zero block
   float* dQ2acc;        // [TK][H] fp32 sums of the KG->RG query gradient (in the zero block, fused backward)
+  float* parM;          // [2][3H][D] + [2][3H]: dQKV^T x and colsum(dQKV) of the two streams (in the zero block)
   float* tailsum;       // [B][4H] all-reduce buffers of the one-launch tail (F1 | hidden | dF1) + 4 counter words per 16 samples (in the zero block)
   size_t bytes;
 };
@@ -147,7 +149,8 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
     w.means_n = (size_t)B * 6 * H;
     {   // one contiguous block so a single memset clears every atomically-accumulated buffer
       const size_t nzt = ((size_t)2 * B + 3) & ~size_t(3);                   // tickets: padded to 16 bytes
-      const size_t nz = w.means_n + (size_t)B * H + nzt + TK * 2 * H + TK * H + (size_t)B * 4 * H + tail_counter_words(B);
+      const size_t npar = (size_t)2 * (3 * H * d.rg_dim + 3 * H) + 8;        // per stream: dQKV^T x [3H][D] and colsum(dQKV) [3H] (fused backward, parameter space)
+      const size_t nz = w.means_n + (size_t)B * H + nzt + TK * 2 * H + TK * H + (size_t)B * 4 * H + ((tail_counter_words(B) + 3) & ~size_t(3)) + npar;
       float* z = c.take<float>(nz);
       w.zero_base = z; w.zero_bytes = nz * sizeof(float);
       w.means = z; w.dfused = z ? z + w.means_n : nullptr;
@@ -155,6 +158,7 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
       w.dKV = z ? w.dfused + (size_t)B * H + nzt : nullptr;
       w.dQ2acc = z ? w.dKV + TK * 2 * H : nullptr;
       w.tailsum = z ? w.dQ2acc + TK * H : nullptr;
+      w.parM = z ? w.tailsum + (size_t)B * 4 * H + ((tail_counter_words(B) + 3) & ~size_t(3)) : nullptr;
     }
     if (w.means) { w.Ymean = w.means; w.H1mean = w.Ymean + B * H; w.Y2mean = w.H1mean + B * 2 * H; w.H2mean = w.Y2mean + B * H; }
     w.comb = c.take<float>(B * 2 * H); w.F1 = c.take<float>(B * H); w.fused = c.take<float>(B * H);
@@ -580,7 +584,7 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
       zero(w.dHm1, (size_t)B * 2 * H * sizeof(float)); zero(w.dHm2, (size_t)B * 2 * H * sizeof(float));   // atomically summed by the one-launch tail
     } else {
       zero(w.zero_base, (size_t)(reinterpret_cast<char*>(w.dKV) - reinterpret_cast<char*>(w.zero_base)));
-      zero(w.tailsum, ((size_t)B * 4 * H + tail_counter_words(B)) * sizeof(float));
+      zero(w.tailsum, ((size_t)B * 4 * H + ((tail_counter_words(B) + 3) & ~size_t(3)) + (size_t)2 * (3 * H * d.rg_dim + 3 * H) + 8) * sizeof(float));
     }
     if (build) {
       CK(launch_weight_shadows(sb, st), "weight shadows");
@@ -792,6 +796,10 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   const int H = 256, D = 128, TK = B * Nk;
   const size_t HH = (size_t)H * H;
   const Ws::F17& f = w.f;
+  // The projections' and in-projections' weight gradients in parameter space (no dR / dG product in the second kernel, 131 k instead
+  // of 427 k MACs per row, one small launch behind the weight gradients): from ~10 k packed rows on -- below that the extra launch
+  // (~10 us) costs what the second kernel saves (measured: B = 16 +10 us, B = 64 -22 us, B = 256 -105 us per step)
+  const bool param_space = g_opt_param_space < 0 ? T >= 10240 : g_opt_param_space > 0;
   Bwd1Args a1; std::memset(&a1, 0, sizeof(a1));
   a1.s[0] = Bwd1Stream{f.W1T, f.Wo1T, f.mask1, f.XH16, f.rstd1, P[CAMO_P_LN1_W], w.dHm1, 2 * H, w.dcomb, 2 * H, f.dH16, f.dU16,
                        Gr[CAMO_P_LN1_W], Gr[CAMO_P_LN1_B]};
@@ -813,20 +821,50 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   a2.tickets = w.tickets + B; a2.off = rg_offsets; a2.tile_off = bd.tile_off; a2.tile_desc = bd.tile_desc;
   a2.B = B; a2.Nk = Nk; a2.rows_rg = T; a2.rg_tiles_max = T / 32 + B; a2.qscale = a1.qscale; a2.drop = drop;
   a2.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)3 * g_dbg_stamp_blocks * 8 : nullptr;
+  a2.param_space = param_space ? 1 : 0;
   CK(launch_fused_bwd2(a2, g_opt_fused_variant, st), "fused backward, second half");
   // every node-level weight gradient: dW += dy^T . x over the rows of a stream (bf16 operands the fused kernels wrote)
+  if (!param_space) {
+    GB16 g(drop, st);
+    g.tn(f.dH16, 2 * H, f.Y16, H, Gr[CAMO_P_F1_W0], H, Gr[CAMO_P_F1_B0], 2 * H, H, T);
+    g.tn(f.dU16, H, f.O16, H, Gr[CAMO_P_A1_OUT_W], H, Gr[CAMO_P_A1_OUT_B], H, H, T);
+    g.tn(f.dQKV16, 3 * H, f.R16, H, Gr[CAMO_P_A1_IN_W], H, Gr[CAMO_P_A1_IN_B], H, H, T);
+    g.tn(f.dQKV16 + H, 3 * H, f.R16, H, Gr[CAMO_P_A2_IN_W] + HH, H, Gr[CAMO_P_A2_IN_B] + H, 2 * H, H, T);
+    g.tn(f.dR16, H, f.X16, D, Gr[CAMO_P_RG_PROJ_W], D, Gr[CAMO_P_RG_PROJ_B], H, D, T);
+    g.tn(f.dH2_16, 2 * H, f.Y2_16, H, Gr[CAMO_P_F2_W0], H, Gr[CAMO_P_F2_B0], 2 * H, H, TK);
+    g.tn(f.dU2_16, H, f.O2_16, H, Gr[CAMO_P_A2_OUT_W], H, Gr[CAMO_P_A2_OUT_B], H, H, TK);
+    g.tn(f.dQKVkg16, 3 * H, f.G16, H, Gr[CAMO_P_A2_IN_W], H, Gr[CAMO_P_A2_IN_B], H, H, TK);
+    g.tn(f.dQKVkg16 + H, 3 * H, f.G16, H, Gr[CAMO_P_A1_IN_W] + HH, H, Gr[CAMO_P_A1_IN_B] + H, 2 * H, H, TK);
+    g.tn(f.dG16, H, f.KG16, D, Gr[CAMO_P_KG_PROJ_W], D, Gr[CAMO_P_KG_PROJ_B], H, D, TK);
+    CK(g.run(), "node-level weight gradients");
+    return 0;
+  }
+  // Node-level weight gradients: dW += dy^T . x over the rows of a stream (bf16 operands the fused kernels wrote).  The input
+  // projection and the in-projections take theirs in PARAMETER space -- with R = x W_p^T + b_p and [q|k'|v'] = R W_in^T + b_in:
+  //   M = dQKV^T x  [3H][D],  db_in = colsum(dQKV);   dW_in = dQKV^T R = M W_p^T + db_in b_p^T;
+  //   dW_p = dR^T x = dU^T x + W_in^T M,  db_p = colsum(dU) + W_in^T db_in      (dR = dU + dQKV W_in never exists)
+  // -- 131 k MACs per row (M, dU^T x) instead of 427 k (dR, dQKV^T R, dR^T x), and one small fp32 launch behind them (misc.hip, unfold_kernel).
+  float* const Mrg = w.parM; float* const Mkg = Mrg + (size_t)3 * H * D;
+  float* const dbrg = Mkg + (size_t)3 * H * D; float* const dbkg = dbrg + 3 * H;
   GB16 g(drop, st);
   g.tn(f.dH16, 2 * H, f.Y16, H, Gr[CAMO_P_F1_W0], H, Gr[CAMO_P_F1_B0], 2 * H, H, T);
   g.tn(f.dU16, H, f.O16, H, Gr[CAMO_P_A1_OUT_W], H, Gr[CAMO_P_A1_OUT_B], H, H, T);
-  g.tn(f.dQKV16, 3 * H, f.R16, H, Gr[CAMO_P_A1_IN_W], H, Gr[CAMO_P_A1_IN_B], H, H, T);
-  g.tn(f.dQKV16 + H, 3 * H, f.R16, H, Gr[CAMO_P_A2_IN_W] + HH, H, Gr[CAMO_P_A2_IN_B] + H, 2 * H, H, T);
-  g.tn(f.dR16, H, f.X16, D, Gr[CAMO_P_RG_PROJ_W], D, Gr[CAMO_P_RG_PROJ_B], H, D, T);
+  g.tn(f.dQKV16, 3 * H, f.X16, D, Mrg, D, dbrg, H, D, T).bias_grad2 = Gr[CAMO_P_A1_IN_B];
+  g.tn(f.dQKV16 + H, 3 * H, f.X16, D, Mrg + (size_t)H * D, D, dbrg + H, 2 * H, D, T).bias_grad2 = Gr[CAMO_P_A2_IN_B] + H;
+  g.tn(f.dU16, H, f.X16, D, Gr[CAMO_P_RG_PROJ_W], D, Gr[CAMO_P_RG_PROJ_B], H, D, T);
   g.tn(f.dH2_16, 2 * H, f.Y2_16, H, Gr[CAMO_P_F2_W0], H, Gr[CAMO_P_F2_B0], 2 * H, H, TK);
   g.tn(f.dU2_16, H, f.O2_16, H, Gr[CAMO_P_A2_OUT_W], H, Gr[CAMO_P_A2_OUT_B], H, H, TK);
-  g.tn(f.dQKVkg16, 3 * H, f.G16, H, Gr[CAMO_P_A2_IN_W], H, Gr[CAMO_P_A2_IN_B], H, H, TK);
-  g.tn(f.dQKVkg16 + H, 3 * H, f.G16, H, Gr[CAMO_P_A1_IN_W] + HH, H, Gr[CAMO_P_A1_IN_B] + H, 2 * H, H, TK);
-  g.tn(f.dG16, H, f.KG16, D, Gr[CAMO_P_KG_PROJ_W], D, Gr[CAMO_P_KG_PROJ_B], H, D, TK);
+  g.tn(f.dQKVkg16, 3 * H, f.KG16, D, Mkg, D, dbkg, H, D, TK).bias_grad2 = Gr[CAMO_P_A2_IN_B];
+  g.tn(f.dQKVkg16 + H, 3 * H, f.KG16, D, Mkg + (size_t)H * D, D, dbkg + H, 2 * H, D, TK).bias_grad2 = Gr[CAMO_P_A1_IN_B] + H;
+  g.tn(f.dU2_16, H, f.KG16, D, Gr[CAMO_P_KG_PROJ_W], D, Gr[CAMO_P_KG_PROJ_B], H, D, TK);
   CK(g.run(), "node-level weight gradients");
+  {
+    const UnfoldStream urg{Mrg, dbrg, P[CAMO_P_A1_IN_W], P[CAMO_P_A2_IN_W] + HH, P[CAMO_P_RG_PROJ_W], P[CAMO_P_RG_PROJ_B], Gr[CAMO_P_A1_IN_W],
+                           Gr[CAMO_P_A2_IN_W] + HH, Gr[CAMO_P_RG_PROJ_W], Gr[CAMO_P_RG_PROJ_B]};
+    const UnfoldStream ukg{Mkg, dbkg, P[CAMO_P_A2_IN_W], P[CAMO_P_A1_IN_W] + HH, P[CAMO_P_KG_PROJ_W], P[CAMO_P_KG_PROJ_B], Gr[CAMO_P_A2_IN_W],
+                           Gr[CAMO_P_A1_IN_W] + HH, Gr[CAMO_P_KG_PROJ_W], Gr[CAMO_P_KG_PROJ_B]};
+    CK(launch_unfold(urg, ukg, st), "projection / in-projection weight gradients (parameter space)");
+  }
   return 0;
 }
 
@@ -1323,6 +1361,7 @@ int camo_debug_set_option(const char* name, int32_t value) {
   if (std::strcmp(name, "tn_balance") == 0) { g_gemm16_balance = value; return 0; }
   if (std::strcmp(name, "tn_kcap") == 0) { g_gemm16_tn_kcap = value; return 0; }
   if (std::strcmp(name, "tn_exp") == 0) { g_gemm16_exp = value; return 0; }
+  if (std::strcmp(name, "param_space") == 0) { g_opt_param_space = value; return 0; }
   if (std::strcmp(name, "tn_big") == 0) { g_gemm16_tn_big = value; return 0; }
   return fail(CAMO_E_ARG, std::string("unknown option ") + name);
 }

@@ -39,6 +39,7 @@ struct GemmBatch {
   GemmProb p[GEMM_MAXP];
   int n;
   DropCfg drop;
+  int kcap;          // > 0: split-K depth (32-deep tiles per block) of the dW problems of this launch, whatever their K (0: 12 tiles, only past 16)
 };
 
 // precision: CAMO_PREC_F32 / CAMO_PREC_BF16.  Returns hipError_t as int.

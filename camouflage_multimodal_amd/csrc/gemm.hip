@@ -748,7 +748,7 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
     }
     if (skinny) return launch_skinny(gb, stream);
   }
-  constexpr int kcap = 12;          // K tiles per split-K block of a weight-gradient problem (measured best on MI355X)
+  const int kcap = gb.kcap > 0 ? gb.kcap : 12;          // K tiles per split-K block of a weight-gradient problem (12: measured best on MI355X for long K)
   // tiles without split-K
   for (int i = 0; i < gb.n; ++i) {
     GemmProb& p = gb.p[i];
@@ -759,7 +759,7 @@ int launch_gemm_batch(GemmBatch& gb, int precision, hipStream_t stream) {
     GemmProb& p = gb.p[i];
     const int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
     int ksplit = 1;
-    if ((p.flags & GF_ATOMIC) && (p.flags & GF_A_KMAJOR) && p.K > 16 * BK) {
+    if ((p.flags & GF_ATOMIC) && (p.flags & GF_A_KMAJOR) && p.K > (gb.kcap > 0 ? kcap : 16) * BK) {
       // weight-gradient GEMM: small output, long contraction.  A block's K loop is serial
       // (~1 us per 32-deep tile), so cap it at ~12 tiles and let the fp32 atomics merge the splits.
       const int ktiles = (p.K + BK - 1) / BK;

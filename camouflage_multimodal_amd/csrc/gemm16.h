@@ -25,6 +25,7 @@ struct Gemm16Prob {
   const float* bias;        // [N] or null
   const float* res;         // fp32 residual / aux (ld = ldr) or null
   float* bias_grad;         // TN: [M] += sum_k A(k, m)
+  float* bias_grad2;        // TN: a second destination of the same sums (or null)
   int M, N, K;
   int lda, ldb, ldc, ldc16, ldr;
   int flags;                // GF_RELU | GF_DROPOUT | GF_RELU_BWD | GF_RES_BCAST; GF_A_KMAJOR|GF_B_KMAJOR together = TN

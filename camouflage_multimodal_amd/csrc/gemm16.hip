@@ -339,7 +339,7 @@ __device__ __forceinline__ void body_tn(const Gemm16Prob& P, int m0, int n0, int
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = rowb + (r & 3) + 8 * (r >> 2);
-      if (row < M) atomicAdd(P.bias_grad + row, accb[r]);
+      if (row < M) { atomicAdd(P.bias_grad + row, accb[r]); if (P.bias_grad2) atomicAdd(P.bias_grad2 + row, accb[r]); }
     }
   }
 #pragma unroll
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(512) void gemm16_tnbig_kernel(const Gemm16Batch gb,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rowb + (r & 3) + 8 * (r >> 2);
-        if (row < M) atomicAdd(P.bias_grad + row, accb[i][r]);
+        if (row < M) { atomicAdd(P.bias_grad + row, accb[i][r]); if (P.bias_grad2) atomicAdd(P.bias_grad2 + row, accb[i][r]); }
       }
     }
 #pragma unroll

@@ -29,6 +29,13 @@ int launch_prep(PrepBatch& pb, hipStream_t stream);
 
 int ln_supported(int H);
 int launch_rowmap(const int* offs, int* row_sample, float* inv_nr, int* tile_off, int4* tile_desc, int B, int ntile_max, int max_nr, hipStream_t stream);
+
+// ---- parameter-space weight gradients of an input projection + the in-projections that read it (fused backward, fusion_abi.hip):
+//   dW_in[i][c] += sum_k M[i][k] W_p[c][k] + db[i] b_p[c]      (i < 3H: rows 0..H-1 -> Gq, H..3H-1 -> Gkv)
+//   dW_p[c][k]  += sum_i W_in[i][c] M[i][k],   db_p[c] += sum_i W_in[i][c] db[i]      (W_in rows 0..H-1 = Wq, the rest = Wkv)
+// with M = dQKV^T x [3H][D] and db = colsum(dQKV) [3H]; H = 256, D = 128; exact fp32, one launch for both streams.
+struct UnfoldStream { const float *M, *db, *Wq, *Wkv, *Wp, *bp; float *Gq, *Gkv, *Gp, *Gbp; };
+int launch_unfold(const UnfoldStream& rg, const UnfoldStream& kg, hipStream_t stream);
 int launch_gather_batch(const float* rg_all, const long long* sample_off, const float* kg_all, const long long* y_all, const float* e_all, const float* s_all,
                         const long long* idx, int B, int T, int D, int KG, float* rg_out, float* kg_out, int* off_out, long long* y_out, float* e_out,
                         float* s_out, float noise_std, unsigned long long seed, hipStream_t stream);

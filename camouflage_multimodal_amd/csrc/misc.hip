@@ -1266,9 +1266,120 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepBatch pb) {
   }
 }
 
+// ---------------------------------------------------------------- parameter-space weight gradients (misc.h, UnfoldStream)
+// Plain fp32 FMA on 64 x 64 output tiles (256 threads, 4 x 4 outputs each, 16-deep LDS tiles): 200 MFLOP in all -- the point is a
+// short launch (every block walks 8 tiles of 16), not throughput.  Blocks: [0, 96) dW_in tiles (2 streams x 12 x 4),
+// [96, 192) dW_p tiles (2 streams x 4 x 2 tiles x 6 slices of 128 rows, merged by atomics), [192, 204) db_p (2 x 6 slices).
+constexpr int UF_H = 256, UF_D = 128;
+__global__ __launch_bounds__(256) void unfold_kernel(const UnfoldStream s0, const UnfoldStream s1) {
+  __shared__ __attribute__((aligned(16))) float As[16][68];
+  __shared__ __attribute__((aligned(16))) float Bs[16][68];
+  const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+  int blk = blockIdx.x;
+  if (blk >= 192) {                                          // db_p[c] += sum_i W_in[i][c] db[i]: 6 slices of 128 rows per stream, 4 row phases x 64 float4 columns per block
+    blk -= 192;
+    const UnfoldStream& S = blk < 6 ? s0 : s1;
+    const int r0 = 128 * (blk < 6 ? blk : blk - 6), ph = t >> 6, c4 = 4 * (t & 63);
+    const float* W = r0 < UF_H ? S.Wq + (size_t)r0 * UF_H : S.Wkv + (size_t)(r0 - UF_H) * UF_H;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+      const int i = ph + 4 * j;
+      const float4 wv = *reinterpret_cast<const float4*>(W + (size_t)i * UF_H + c4);
+      const float d = S.db[r0 + i];
+      acc.x = fmaf(wv.x, d, acc.x); acc.y = fmaf(wv.y, d, acc.y); acc.z = fmaf(wv.z, d, acc.z); acc.w = fmaf(wv.w, d, acc.w);
+    }
+    atomicAdd(S.Gbp + c4, acc.x); atomicAdd(S.Gbp + c4 + 1, acc.y); atomicAdd(S.Gbp + c4 + 2, acc.z); atomicAdd(S.Gbp + c4 + 3, acc.w);
+    return;
+  }
+  const bool win = blk < 96;
+  if (!win) blk -= 96;
+  const UnfoldStream& S = blk < 48 ? s0 : s1;
+  if (blk >= 48) blk -= 48;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  auto mac = [&]() {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[k][4 * ty]), b = *reinterpret_cast<const float4*>(&Bs[k][4 * tx]);
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+  };
+  if (win) {
+    // C[i][c] over i in [64 ti, +64), c in [64 tc, +64): A = M rows (k contiguous), B = W_p rows (k contiguous): transposed into LDS
+    const int ti = blk >> 2, tc = blk & 3, i0 = 64 * ti, c0 = 64 * tc;
+    const int r = t >> 2, k4 = 4 * (t & 3);
+    float4 av8[8], bv8[8];                                     // every operand of the block in flight at once: ONE memory round trip
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      av8[q] = *reinterpret_cast<const float4*>(S.M + (size_t)(i0 + r) * UF_D + 16 * q + k4);
+      bv8[q] = *reinterpret_cast<const float4*>(S.Wp + (size_t)(c0 + r) * UF_D + 16 * q + k4);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 a = av8[q], b = bv8[q];
+      __syncthreads();
+      As[k4][r] = a.x; As[k4 + 1][r] = a.y; As[k4 + 2][r] = a.z; As[k4 + 3][r] = a.w;
+      Bs[k4][r] = b.x; Bs[k4 + 1][r] = b.y; Bs[k4 + 2][r] = b.z; Bs[k4 + 3][r] = b.w;
+      __syncthreads();
+      mac();
+    }
+    float* G = i0 < UF_H ? S.Gq + (size_t)i0 * UF_H : S.Gkv + (size_t)(i0 - UF_H) * UF_H;
+    const float4 bp = *reinterpret_cast<const float4*>(S.bp + c0 + 4 * tx);
+    const float bpv[4] = {bp.x, bp.y, bp.z, bp.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                            // (one writer per element, and nothing else of the step adds to these gradients: plain +=)
+      const float dbi = S.db[i0 + 4 * ty + i];
+      float4* g4 = reinterpret_cast<float4*>(G + (size_t)(4 * ty + i) * UF_H + c0 + 4 * tx);
+      float4 o = *g4;
+      o.x += fmaf(dbi, bpv[0], acc[i][0]); o.y += fmaf(dbi, bpv[1], acc[i][1]); o.z += fmaf(dbi, bpv[2], acc[i][2]); o.w += fmaf(dbi, bpv[3], acc[i][3]);
+      *g4 = o;
+    }
+  } else {
+    // C[c][k] over c in [64 tc, +64), k in [64 tk, +64), rows [128 sl, +128) of W_in / M (both row-contiguous in the tile's direction)
+    const int sl = blk / 8, tc = (blk & 7) >> 1, tk = blk & 1, c0 = 64 * tc, kk0 = 64 * tk, r0 = 128 * sl;
+    const float* W = r0 < UF_H ? S.Wq + (size_t)r0 * UF_H : S.Wkv + (size_t)(r0 - UF_H) * UF_H;
+    const float* Mr = S.M + (size_t)r0 * UF_D;
+    const int r = t >> 4, c4 = 4 * (t & 15);
+    float4 av8[8], bv8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      av8[q] = *reinterpret_cast<const float4*>(W + (size_t)(16 * q + r) * UF_H + c0 + c4);
+      bv8[q] = *reinterpret_cast<const float4*>(Mr + (size_t)(16 * q + r) * UF_D + kk0 + c4);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 a = av8[q], b = bv8[q];
+      __syncthreads();
+      *reinterpret_cast<float4*>(&As[r][c4]) = a;
+      *reinterpret_cast<float4*>(&Bs[r][c4]) = b;
+      __syncthreads();
+      mac();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(S.Gp + (size_t)(c0 + 4 * ty + i) * UF_D + kk0 + 4 * tx + j, acc[i][j]);
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
+int launch_unfold(const UnfoldStream& rg, const UnfoldStream& kg, hipStream_t stream) {
+  const int prof = gemm_prof_open(stream, 2.0 * 2.0 * 2.0 * 768.0 * 256.0 * 128.0, PROF_GEMM);
+  hipLaunchKernelGGL(unfold_kernel, dim3(204), dim3(256), 0, stream, rg, kg);
+  gemm_prof_close(prof, stream);
+  return (int)hipGetLastError();
+}
+
 int launch_gather_batch(const float* rg_all, const long long* sample_off, const float* kg_all, const long long* y_all, const float* e_all, const float* s_all,
                         const long long* idx, int B, int T, int D, int KG, float* rg_out, float* kg_out, int* off_out, long long* y_out, float* e_out,
                         float* s_out, float noise_std, unsigned long long seed, hipStream_t stream) {

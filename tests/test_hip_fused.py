@@ -26,7 +26,7 @@ def _opt(name, value):
 @pytest.fixture
 def fused_opts():
     yield _opt
-    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1); _opt("fused_rt", -1); _opt("tailw", -1); _opt("fused_one", 1); _opt("tn_big", -1)
+    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1); _opt("fused_rt", -1); _opt("tailw", -1); _opt("fused_one", 1); _opt("tn_big", -1); _opt("param_space", -1)
 
 
 def bf16_round(x):
@@ -222,8 +222,8 @@ def test_fused_backward_stage_by_stage(training, kg_real, fused_opts):
     close_rel(ws_f32(eng, batch, ws, "dKV", B * Nk * 2 * H).reshape(B * Nk, 2 * H), np.concatenate([cat("dKk"), cat("dVk")], axis=1), R, "dK | dV sums", M, flips=F)
     close_rel(ws_f32(eng, batch, ws, "dQ2acc", B * Nk * H).reshape(B * Nk, H), cat("dQ2"), 5e-2, "dQ2 sums", 1e-2, flips=2e-2)
     close_rel(ws_bf16(eng, batch, ws, "dQKVkg16", B * Nk, 3 * H), np.concatenate([cat("dQ2"), cat("dKk"), cat("dVk")], axis=1), R, "dQKV (KG rows)", M, flips=F)
-    close_rel(ws_bf16(eng, batch, ws, "dR16", T, H), cat("dR"), R, "dR", M, flips=F)
-    close_rel(ws_bf16(eng, batch, ws, "dG16", B * Nk, H), cat("dG"), R, "dG", M, flips=F)
+    close_rel(ws_bf16(eng, batch, ws, "dR16", T, H), cat("dR"), R, "dR", M, flips=F)      # (formed below ~10 k packed rows only: above, the
+    close_rel(ws_bf16(eng, batch, ws, "dG16", B * Nk, H), cat("dG"), R, "dG", M, flips=F)  # projections' weight gradients are taken in parameter space)
     num = den = 0.0
     rels = []
     for k, p in m.named_parameters():
@@ -326,6 +326,21 @@ def test_fused_training_step_shape_envelope(nrs, nk, pseed, fused_opts):
     print(f"nrs={nrs[:6]} nk={nk} pseed={pseed}: global relative gradient error vs the bf16-operand oracle {total:.5f}; worst {per[0][1]} {per[0][0]:.4f}")
     assert total < 2e-3, (total, per[:4])
     assert per[0][0] < 1e-2, per[:4]
+    # the same step with the projections' / in-projections' weight gradients taken in parameter space (bwd2p_kernel + unfold_kernel;
+    # by size from 10 240 packed rows, forced here -- or forced OFF where the size rule took it above), against the same oracle step
+    fused_opts("param_space", 0 if sum(nrs) >= 10240 else 1)
+    g.zero_()
+    outs2, _, _ = eng.train_raw(batch, eng.workspace(batch, private=True), torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s), True, dseed, eng._gtab)
+    torch.cuda.synchronize()
+    fused_opts("param_space", -1)
+    grads2 = {k: t2n(p.grad).copy() for k, p in m.named_parameters()}
+    assert_close(t2n(outs2), t2n(outs), 1e-6, 1e-6, "outputs do not depend on the backward's form")
+    num2 = sum(float(((grads2[k].astype(np.float64) - ref["raw_grads"][k]) ** 2).sum()) for k in grads2)
+    per2 = sorted(((float(np.sqrt(((grads2[k].astype(np.float64) - ref["raw_grads"][k]) ** 2).sum() / max((ref["raw_grads"][k].astype(np.float64) ** 2).sum(), 1e-30))), k)
+                   for k in grads2 if (ref["raw_grads"][k].astype(np.float64) ** 2).sum() > 1e-6 * den), reverse=True)
+    print(f"   other form of the backward: global {float(np.sqrt(num2 / den)):.5f}; worst {per2[0][1]} {per2[0][0]:.4f}")
+    assert float(np.sqrt(num2 / den)) < 2e-3, per2[:4]
+    assert per2[0][0] < 1e-2, per2[:4]
 
 
 @pytest.mark.parametrize("B,ncls", [(1, 2), (17, 2), (32, 2), (33, 3), (100, 2)])
