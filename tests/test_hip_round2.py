@@ -487,3 +487,28 @@ def test_batch_descriptor_tables(B, lo, hi):
             k += 1
     assert np.array_equal(tile_desc[:k], want[:k])
     assert (tile_desc[k:, 0] == -1).all()
+
+
+def test_writers_torch_cannot_see_need_invalidate_shadows(kg_real):
+    """A write through ``flat_params.data`` (what an in-place collective such as a parameter broadcast amounts to) bumps no
+    version counter: the engine keeps believing its bf16 weight shadows.  ``invalidate_shadows()`` is the contract for such
+    writers (``ddp.broadcast_parameters`` calls it): after it the next call rebuilds the shadows and follows the new weights."""
+    from camouflage_multimodal_amd import NativeTrainer
+    cfg = OP.full_cfg()
+    nrs = [200, 77, 31]
+    rg = torch.from_numpy(np.concatenate([OP.make_rg(n, 128, seed=80 + i) for i, n in enumerate(nrs)])).cuda()
+    kg = torch.from_numpy(np.stack([kg_real] * len(nrs))).cuda()
+    m = make_model(cfg, 3, "bf16").eval()
+    other = make_model(cfg, 4, "bf16").eval()
+    tr = NativeTrainer(m)
+    eng = m._engine
+    o_old = t2n(tr.evaluate(rg, nrs, kg))
+    assert eng.shadows_current()
+    eng.flat_params.data.copy_(other._engine.flat_params.data)        # invisible to torch's version counters
+    assert eng.shadows_current()                                      # ... and so to the engine: the stale shadows would be used
+    eng.invalidate_shadows()
+    assert not eng.shadows_current()
+    o_new = t2n(tr.evaluate(rg, nrs, kg))
+    want = t2n(NativeTrainer(other).evaluate(rg, nrs, kg))
+    assert_close(o_new, want, 2e-6, 1e-5, "after invalidate_shadows the call follows the new parameters")
+    assert float(np.abs(o_new - o_old).max()) > 1e-3
