@@ -217,8 +217,17 @@ constexpr int PV = 576;      // RG tile: the sample's 16 value rows [16][256] (t
 constexpr int PVC = 192;     // KG block: a wave's 32-row x 64-feature value chunk (transposing reads)
 constexpr int PT = 260;      // fp32 tile pitch (floats)
 constexpr int B_VS = 16 * PK;                       // 8448
-constexpr int B_REGION_A = 32 * PT * 4;             // 33280 >= 8448 + 9216 (RG) and >= 4 * 32 * 192 (KG)
-constexpr int B_BUFO = B_REGION_A, B_BUFY = B_BUFO + 32 * PR, B_RED = B_BUFY + 32 * PR, B_LDS = B_RED + 1024;   // 33280, 50176, 67072, 68096
+// Two layouts.  OCC = 2 (launches of at most two blocks per CU: small batches, one tile per CU is the critical path): region A =
+// [0, 33280) is the attention scratch (8448 + 9216 bytes for an RG tile, 4 * 32 * 192 for a KG block) and, once the attention and the
+// out-projection are done with it, the fp32 tile of the LayerNorm output whose columns are summed for the mean pool (only the
+// tile's real rows are added: 13 for a KG chain); 68 KB.  OCC = 3 (larger launches): the pool is a halving butterfly in registers, the
+// LayerNorm output tile (bufY) and the normalised LayerNorm input of a saving call (bufXH) take region A's place; 51.7 KB, three
+// blocks per CU, 168 VGPRs.
+template <int OCC> struct BackL;
+template <> struct BackL<2> { static constexpr int XH = 0, O = 32 * PT * 4, Y = O + 32 * PR, RED = Y + 32 * PR, LDS = RED + 1024; };       // 0, 33280, 50176, 67072, 68096
+template <> struct BackL<3> { static constexpr int Y = 0, XH = 32 * PR, O = 2 * 32 * PR, RED = O + 32 * PR, LDS = RED + 1024; };             // 0, 16896, 33792, 50688, 51712
+constexpr int B_LDS = BackL<2>::LDS;
+static_assert(BackL<3>::O >= 4 * 32 * 192 && BackL<3>::O >= 8448 + 9216 && BackL<2>::O >= 4 * 32 * 192, "attention scratch inside region A");
 
 // Softmax over the <= 16 keys of one RG row: S holds the (pre-scaled) scores of keys acc_row(i, h), i < 8, in this lane
 // and the other 8 keys in lane ^ 32.  p = probabilities (0 for keys >= Nk).  Forward and backward run this same code.
@@ -238,9 +247,9 @@ __device__ __forceinline__ void rg_softmax(const f32x16& S, int h, int Nk, float
 
 // RG tile: rows [row0, row0 + nrows) of sample b against its Nk keys; wave w owns heads 2w, 2w+1.  Leaves the attention
 // output (bf16) in bufO.
-__device__ __forceinline__ void attn_rg_tile(const BackArgs& a, char* smem, int b, size_t row0, int nrows, int w, int lane) {
+__device__ __forceinline__ void attn_rg_tile(const BackArgs& a, char* smem, char* bufO, int b, size_t row0, int nrows, int w, int lane) {
   const int tid = threadIdx.x, l31 = lane & 31, h = lane >> 5, Nk = a.Nk;
-  char* Ks = smem; char* Vs = smem + B_VS; char* bufO = smem + B_BUFO;
+  char* Ks = smem; char* Vs = smem + B_VS;
   // the sample's key | value rows: [Nk][512] bf16 -> two images, rows Nk..15 cleared
   for (int c = tid; c < 16 * 64; c += 256) {
     const int j = c >> 6, ch = c & 63;
@@ -397,11 +406,10 @@ __device__ __forceinline__ void attn_kg_split(const BackArgs& a, char* smem, int
 // The last split of sample b: combine the partials into the attention output (bf16, rows j < Nk of bufO).  The partials
 // were written by other CUs a moment ago, so every read is a long-latency miss: all loops run in batches of independent,
 // unconditional loads (split index clamped, contribution masked) instead of one round trip per split.
-__device__ __forceinline__ void attn_kg_combine(const BackArgs& a, char* smem, int b, int nsplit) {
+__device__ __forceinline__ void attn_kg_combine(const BackArgs& a, char* smem, char* bufO, int b, int nsplit) {
   const int tid = threadIdx.x, Nk = a.Nk;
   float* sc = reinterpret_cast<float*>(smem);              // [nsplit][128] scale factors exp(m_s - M), then [128] 1 / L
   float* invL = sc + nsplit * 128;
-  char* bufO = smem + B_BUFO;
   const float* part = a.part + (size_t)a.tile_off[b] * 8 * PART_FLOATS;       // split s at + 2 s tiles
   constexpr size_t SS = (size_t)2 * 8 * PART_FLOATS;                          // floats between consecutive splits
   // the first batch of Z loads does not depend on the scale factors: it is issued together with the m / l loads, so the
@@ -478,8 +486,11 @@ __device__ __forceinline__ void attn_kg_combine(const BackArgs& a, char* smem, i
   }
 }
 
-template <int DEPTH, bool ROT>
-__global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
+// OCC: blocks per CU the register budget is sized for -- 3 (168 VGPRs, a few dwords of scratch) for launches of more than two
+// blocks per CU, where the third co-resident tile hides the others' waits (B = 64: 77 -> 68 us, B = 1024: 1.33 -> 1.16 ms);
+// 2 for the small batches whose one tile per CU is the critical path (B = 16: the tighter budget cost 1.7 us).
+template <int DEPTH, bool ROT, int OCC>
+__global__ __launch_bounds__(256, OCC) void back_kernel(const BackArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -491,9 +502,10 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
   const int vid = (int)blockIdx.x < a.lead_tiles ? nkg + (int)blockIdx.x : ((int)blockIdx.x < a.lead_tiles + nkg ? (int)blockIdx.x - a.lead_tiles : (int)blockIdx.x);
   const bool kg = vid < nkg;
   const int rot = ROT ? (int)(blockIdx.x >> 3) : 0;
-  char* bufO = smem + B_BUFO; char* bufY = smem + B_BUFY;
-  float* red = reinterpret_cast<float*>(smem + B_RED);
-  float* tile32 = reinterpret_cast<float*>(smem);
+  using L = BackL<OCC>;
+  char* bufO = smem + L::O; char* bufY = smem + L::Y;
+  float* red = reinterpret_cast<float*>(smem + L::RED);
+  float* tile32 = reinterpret_cast<float*>(smem);            // (OCC = 2 only)
   int b; size_t rowg0; int nrows; float inv_n;
   stamp(a.stamps, 0);
   const BackStream& S = a.s[kg ? 1 : 0];
@@ -523,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
     for (int c = tid; c < 32 * PR / 16; c += 256) reinterpret_cast<u32x4*>(bufO)[c] = u32x4{0u, 0u, 0u, 0u};   // rows >= Nk stay zero
     __syncthreads();
     sto.prefetch(reinterpret_cast<const u32x4*>(S.Wo) + (size_t)w * (16 * 2 * 64) + lane, rot);
-    attn_kg_combine(a, smem, b, nsplit);
+    attn_kg_combine(a, smem, bufO, b, nsplit);
     stamp(a.stamps, 6);
     rowg0 = (size_t)b * a.Nk; nrows = a.Nk; inv_n = 1.0f / (float)a.Nk;
   } else {
@@ -532,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
     const int4 td = a.tile_desc[vid - nkg];
     if (td.x < 0) return;
     b = td.x; rowg0 = td.y; nrows = td.z; inv_n = __int_as_float(td.w);
-    attn_rg_tile(a, smem, b, rowg0, nrows, w, lane);
+    attn_rg_tile(a, smem, bufO, b, rowg0, nrows, w, lane);
   }
   __syncthreads();
   stamp(a.stamps, 1);
@@ -571,9 +583,11 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
     for (int i = 0; i < 32; ++i) { u[i] -= mean; sq = fmaf(u[i], u[i], sq); }
     const float rstd = 1.0f / sqrtf(row_total(sq, 1) * (1.0f / 256.0f) + 1e-5f);
     rstd_keep = rstd;
-    // (both barriers of row_total are behind every wave's out-projection MFMAs: region A is free for the fp32 tile)
+    // (both barriers of row_total are behind every wave's out-projection MFMAs: region A is free for the LayerNorm output tile)
+    const bool rok = l31 < nrows;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      float ys[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c0 = 64 * w + 32 * t + 8 * g + 4 * h;
@@ -582,13 +596,39 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
         const float x0 = o[0] * rstd, x1 = o[1] * rstd, x2 = o[2] * rstd, x3 = o[3] * rstd;
         const float4 y = make_float4(x0 * gm.x + bt.x, x1 * gm.y + bt.y, x2 * gm.z + bt.z, x3 * gm.w + bt.w);
         *reinterpret_cast<u32x2*>(bufY + l31 * PR + 2 * c0) = u32x2{pack2(y.x, y.y), pack2(y.z, y.w)};
-        *reinterpret_cast<float4*>(tile32 + l31 * PT + c0) = y;
-        o[0] = x0; o[1] = x1; o[2] = x2; o[3] = x3;       // (kept for the save at the end of the kernel)
+        if constexpr (OCC == 3) {
+          ys[4 * g] = rok ? y.x : 0.f; ys[4 * g + 1] = rok ? y.y : 0.f; ys[4 * g + 2] = rok ? y.z : 0.f; ys[4 * g + 3] = rok ? y.w : 0.f;
+          // saved for the backward: the normalised LayerNorm input, parked in its own tile (leaves as whole rows at the end of the kernel)
+          if (a.save) *reinterpret_cast<u32x2*>(smem + L::XH + l31 * PR + 2 * c0) = u32x2{pack2(x0, x1), pack2(x2, x3)};
+        } else {
+          *reinterpret_cast<float4*>(tile32 + l31 * PT + c0) = y;
+          o[0] = x0; o[1] = x1; o[2] = x2; o[3] = x3;       // (kept for the save at the end of the kernel)
+        }
       }
+      if constexpr (OCC == 2) continue;
+      // mean pool of the LayerNorm output: column sums over the 32 lanes of a half by a halving butterfly -- after the steps
+      // 16, 8, 4, 2 a lane holds ONE column (index (l31 >> 1) & 15 of its 16), the last step adds the neighbour's half
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int n = 8 >> st, m = 16 >> st;                  // values kept, lane distance
+        const bool up = (l31 & m) != 0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          const float send = up ? ys[i] : ys[i + n];
+          const float keep = up ? ys[i + n] : ys[i];
+          ys[i] = keep + __shfl_xor(send, m, 64);
+        }
+      }
+      const float tot = ys[0] + __shfl_xor(ys[0], 1, 64);
+      if ((l31 & 1) == 0) {
+        const int i16 = (l31 >> 1) & 15;
+        atomicAdd(S.Ymean + (size_t)b * 256 + 64 * w + 32 * t + 8 * (i16 >> 2) + 4 * h + (i16 & 3), tot * inv_n);
+      }
+    }
   }
   __syncthreads();
   stamp(a.stamps, 2);
-  {   // mean pool of the LayerNorm output: thread t owns feature t
+  if constexpr (OCC == 2) {   // mean pool of the LayerNorm output: thread t owns feature t
     float sum = 0.f;
     for (int r = 0; r < nrows; ++r) sum += tile32[r * PT + tid];
     atomicAdd(S.Ymean + (size_t)b * 256 + tid, sum * inv_n);
@@ -630,18 +670,20 @@ __global__ __launch_bounds__(256, 2) void back_kernel(const BackArgs a) {
   }
   if (a.save) {
     // saved-for-backward tensors, all at the end (no weight stream left to delay): the normalised LayerNorm input goes
-    // through region A (free since the mean-pool pass) so that it leaves as whole rows like the other two tiles
-    char* bufXH = smem;
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float* o = u + 16 * t + 4 * g;
-        *reinterpret_cast<u32x2*>(bufXH + l31 * PR + 2 * (64 * w + 32 * t + 8 * g + 4 * h)) = u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])};
-      }
+    // through its own tile of region A so that it leaves as whole rows like the other two tiles
+    char* bufXH = smem + L::XH;
     if (w == 0 && h == 0 && l31 < nrows) S.rstd[rowg0 + l31] = rstd_keep;
-    __syncthreads();
+    __syncthreads();                                         // (every wave is done reading bufY; OCC = 3: the XH tile was written before the FFN)
+    if constexpr (OCC == 2) {                                // region A is free since the mean-pool pass
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float* o = u + 16 * t + 4 * g;
+          *reinterpret_cast<u32x2*>(bufXH + l31 * PR + 2 * (64 * w + 32 * t + 8 * g + 4 * h)) = u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+        }
+      __syncthreads();
+    }
     copy_out<5>(bufXH, PR, 0, S.XH16, 256, rowg0, nrows);
     copy_out<5>(bufO, PR, 0, S.O16, 256, rowg0, nrows);
     copy_out<5>(bufY, PR, 0, S.Y16, 256, rowg0, nrows);
@@ -1431,9 +1473,10 @@ int launch_fused_back(BackArgs& a, int variant, hipStream_t stream) {
     if (!al16(S.bo) || !al16(S.ln_g) || !al16(S.ln_b) || !al16(S.Wo) || !al16(S.W1) || !al16(S.R16)) return (int)hipErrorInvalidValue;
   }
   static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&back_kernel<12, false>), hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&back_kernel<12, true>), hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&back_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&back_kernel<12, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, BackL<2>::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&back_kernel<12, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, BackL<2>::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&back_kernel<12, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, BackL<3>::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&back_kernel<16, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, BackL<2>::LDS);
     return true;
   }();
   (void)attr;
@@ -1442,9 +1485,10 @@ int launch_fused_back(BackArgs& a, int variant, hipStream_t stream) {
   // executed FLOPs per row: out-projection 256 -> 256, FFN layer 0 256 -> 512, both attention directions (2 x 2 x Nk x 256)
   const double rows = (double)a.rows_rg + (double)a.B * a.Nk;
   const int prof = gemm_prof_open(stream, 2.0 * rows * (256.0 * 256.0 + 256.0 * 512.0) + 8.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BACK);
-  if (variant == 0)      hipLaunchKernelGGL((back_kernel<12, false>), grid, dim3(256), B_LDS, stream, a);
-  else if (variant == 2) hipLaunchKernelGGL((back_kernel<16, true>), grid, dim3(256), B_LDS, stream, a);
-  else                   hipLaunchKernelGGL((back_kernel<12, true>), grid, dim3(256), B_LDS, stream, a);
+  if (variant == 0)        hipLaunchKernelGGL((back_kernel<12, false, 2>), grid, dim3(256), BackL<2>::LDS, stream, a);
+  else if (variant == 2)   hipLaunchKernelGGL((back_kernel<16, true, 2>), grid, dim3(256), BackL<2>::LDS, stream, a);
+  else if (grid.x > 512u)  hipLaunchKernelGGL((back_kernel<12, true, 3>), grid, dim3(256), BackL<3>::LDS, stream, a);
+  else                     hipLaunchKernelGGL((back_kernel<12, true, 2>), grid, dim3(256), BackL<2>::LDS, stream, a);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }

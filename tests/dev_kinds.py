@@ -5,12 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import make_batches
 from camouflage_multimodal_amd import NativeTrainer, _lib, build_multimodal_model
 B, rt = int(sys.argv[1]), int(sys.argv[2]); train = len(sys.argv) > 3 and sys.argv[3] == "train"
-model = build_multimodal_model({}).cuda().set_precision("bf16"); model.train(train)
+cfg = {"dropout": float([a.split("=")[1] for a in sys.argv if a.startswith("dropout=")][0])} if any(a.startswith("dropout=") for a in sys.argv) else {}
+model = build_multimodal_model(cfg).cuda().set_precision("bf16"); model.train(train)
 tr = NativeTrainer(model)
 L = _lib.lib()
 _lib.check(L.camo_debug_set_option(b"fused_rt", rt), "opt")
 for kv in sys.argv[3:]:
-    if "=" in kv:
+    if "=" in kv and not kv.startswith("dropout="):
         _lib.check(L.camo_debug_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1])), kv)
 hb = make_batches(2, B, 0, seed=100 + B)
 db = [tuple(torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else x for x in b) for b in hb]
