@@ -347,14 +347,16 @@ bool sched16_ok(const camo_dims_t& d, const float* const* P, int precision, int 
 struct FusedLoss { const int64_t* y; const float* e; const float* s; float* terms; int32_t* pred; float* const* head_grads; };
 
 int heads_forward(const camo_dims_t& d, const float* const* hp /*16 pointers*/, const Ws& w, int B, int F,
-                  float* outs, GB& g, const FusedLoss* fl = nullptr) {
+                  float* outs, GB& g, const FusedLoss* fl = nullptr, bool hidden_done = false) {
   const int Fh = F / 2, C = d.num_classes, Wd = 2 * C + 2;
   const int nout[4] = {C, C, 1, 1}, coff[4] = {0, C, 2 * C, 2 * C + 1};
-  for (int x = 0; x < 4; ++x) {
-    GemmProb& p = g.nt(w.fused, F, hp[4 * x], F, hp[4 * x + 1], w.hid + x * Fh, 4 * Fh, B, Fh, F, GF_RELU);
-    set_drop(p, SITE_HEAD0 + x);
+  if (!hidden_done) {                      // (else w.hid came out of the two-plane tail launch)
+    for (int x = 0; x < 4; ++x) {
+      GemmProb& p = g.nt(w.fused, F, hp[4 * x], F, hp[4 * x + 1], w.hid + x * Fh, 4 * Fh, B, Fh, F, GF_RELU);
+      set_drop(p, SITE_HEAD0 + x);
+    }
+    CK(g.run(), "heads hidden");
   }
-  CK(g.run(), "heads hidden");
   if (fl) {
     HeadsOut ho;
     for (int x = 0; x < 4; ++x) { ho.W[x] = hp[4 * x + 2]; ho.b[x] = hp[4 * x + 3]; ho.gW[x] = fl->head_grads[4 * x + 2]; ho.gb[x] = fl->head_grads[4 * x + 3]; }
@@ -617,8 +619,9 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   t_nzero_front = 0;
   const int rt = wide_rt(T, max_nr, save);
   const bool one = rt >= 2 && g_opt_fused_one != 0;
-  if (one && want_tailw) {
-    // the per-sample tail's weights as hi / lo bf16 planes in fragment order: extra blocks of the KG rows' front launch
+  const bool wide_train_front = !rt && g_opt_fused_rt < 0 && save && T >= 4 * 32 * 224 && max_nr <= wide_max_rows(4) - 256;
+  if ((one || wide_train_front) && want_tailw) {
+    // the per-sample tail's weights as hi / lo bf16 planes in fragment order: extra blocks of the (KG rows') wide front launch
     const size_t HH = (size_t)H * H;
     const float* hsrc[4] = {P[CAMO_P_HEADS], P[CAMO_P_HEADS + 4], P[CAMO_P_HEADS + 8], P[CAMO_P_HEADS + 12]};
     auto xj = [&](us* dst, int N, int K, const float* src, int lo) {
@@ -642,7 +645,7 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   else if (rt) CK(launch_wide_front(fa, rt, st, 0), "fused forward, front half (wide tiles)");
   // training calls at large batches: the front half alone on 128-row blocks (same outputs; measured B = 64: 37.5 -> 30.3 us, B = 256:
   // 130 -> 104 us), the back half stays on the 32-row kernel, whose saving + dropout variant is the faster one (77 vs 94 us at B = 64)
-  else if (g_opt_fused_rt < 0 && save && T >= 4 * 32 * 224 && max_nr <= wide_max_rows(4) - 256)
+  else if (wide_train_front)
     CK(launch_wide_front(fa, 4, st, 0), "fused forward, front half (wide tiles)");
   else CK(launch_fused_front(fa, g_opt_fused_variant, st), "fused forward, front half");
   BackArgs ba; std::memset(&ba, 0, sizeof(ba));
@@ -959,8 +962,13 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   const size_t HH2 = (size_t)H * H;
   if (use17) {
     const bool tailw = (flags & CAMO_FWD_INFERENCE) && !fl && !fl17 && tailw_taken(d, B, T, max_nr, save17);
-    if (int e = forward_nodes17(d, P, rg, rg_offsets, bd, kg, B, T, Nk, max_nr, w, drop, save17, st, tailw)) return e;
-    if (tailw) {
+    // training calls on the wide front half with more than 64 samples: the tail's FORWARD as the one two-plane launch (with fp32
+    // copies of what the backward launches read) instead of four fp32 GEMM launches (B = 256: 4 x 27 us -> 34 us); the loss launch
+    // and the backward launches follow as before
+    const bool tailw_train = !tailw && fl && !fl17 && save17 && B > 64 && g_opt_tailw != 0 && g_opt_fused_rt < 0 && T >= 4 * 32 * 224 &&
+                             max_nr <= wide_max_rows(4) - 256 && tail_wide_ok(B, d.num_classes) && heads_loss_ok(B, d.num_classes);
+    if (int e = forward_nodes17(d, P, rg, rg_offsets, bd, kg, B, T, Nk, max_nr, w, drop, save17, st, tailw || tailw_train)) return e;
+    if (tailw || tailw_train) {
       TailWideArgs ta; std::memset(&ta, 0, sizeof(ta));
       ta.Ymean = w.Ymean; ta.H1mean = w.H1mean; ta.Y2mean = w.Y2mean; ta.H2mean = w.H2mean;
       const us* const* tw = w.f.tailw;
@@ -968,8 +976,10 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
       ta.b13 = P[CAMO_P_F1_B3]; ta.b23 = P[CAMO_P_F2_B3]; ta.bfu0 = P[CAMO_P_FU_B0]; ta.bfu3 = P[CAMO_P_FU_B3];
       for (int x = 0; x < 4; ++x) { ta.bh0[x] = P[CAMO_P_HEADS + 4 * x + 1]; ta.Wh3[x] = P[CAMO_P_HEADS + 4 * x + 2]; ta.bh3[x] = P[CAMO_P_HEADS + 4 * x + 3]; }
       ta.outs = outs; ta.B = B; ta.C = d.num_classes; ta.drop = drop;
+      if (tailw_train) { ta.comb_out = w.comb; ta.F1_out = w.F1; ta.fused_out = w.fused; ta.hid_out = w.hid; }
       CK(launch_tail_wide(ta, st), "per-sample tail (wide, one launch)");
-      return 0;
+      if (!tailw_train) return 0;
+      return heads_forward(d, P + CAMO_P_HEADS, w, B, H, outs, gt, fl, /*hidden_done=*/true);
     }
   } else if (use16) {
     if (int e = forward_nodes16(d, P, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, w, attn_rg2kg, attn_kg2rg, drop, st)) return e;

@@ -12,6 +12,9 @@ struct TailWideArgs {
   const us16 *T13h, *T13l, *T23h, *T23l, *Tfu0h, *Tfu0l, *Tfu3h, *Tfu3l, *Th0h, *Th0l;
   const float *b13, *b23, *bfu0, *bfu3; const float* bh0[4]; const float* Wh3[4]; const float* bh3[4];
   float* outs;                                              // [B][2C+2]
+  // training calls: fp32 copies of what the backward launches read -- comb [B][512], F1 [B][256] (after ReLU and dropout), fused [B][256],
+  // hid [B][512] (after ReLU and dropout); all four or none.  With them the head output layer is left to the loss launch (outs may be null).
+  float *comb_out, *F1_out, *fused_out, *hid_out;
   int B, C; DropCfg drop;
 };
 #define TAILW_MAXC 8

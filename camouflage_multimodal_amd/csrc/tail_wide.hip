@@ -171,6 +171,11 @@ __global__ __launch_bounds__(NTH, 2) void tailw_fwd_kernel(const TailWideArgs a)
       v[4 * g + 2] = acc[0][4 * g + 2] + bb[2] + rv[g].z; v[4 * g + 3] = acc[0][4 * g + 3] + bb[3] + rv[g].w;
     }
     put_hl(bufB, P512, PLANE, 256 * half + 32 * w8, v);
+    if (a.comb_out && b0 + l31 < B) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(a.comb_out + (size_t)(b0 + l31) * 512 + 256 * half + 32 * w8 + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    }
     if (half == 0) {
       __syncthreads();                                         // every wave is done with the first input
       store_in512(bufA, in);
@@ -195,6 +200,11 @@ __global__ __launch_bounds__(NTH, 2) void tailw_fwd_kernel(const TailWideArgs a)
       if (DROP) v[i] *= drop_mult(a.drop, SITE_FUSE, (uint32_t)(b0 + l31) * 256u + (uint32_t)col);
     }
     put_hl(bufA, P256, TS * P256, 32 * w8, v);
+    if (a.F1_out && b0 + l31 < B) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(a.F1_out + (size_t)(b0 + l31) * 256 + 32 * w8 + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    }
   }
   __syncthreads();
   // ---- layer 3: fused = Wfu3 F1 + bfu3  (fusion_model.py:72)
@@ -208,6 +218,11 @@ __global__ __launch_bounds__(NTH, 2) void tailw_fwd_kernel(const TailWideArgs a)
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = acc[0][i] + cst[C_BFU3 + 32 * w8 + acc_row(i, h)];
     put_hl(bufB, P256, TS * P256, 32 * w8, v);
+    if (a.fused_out && b0 + l31 < B) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(a.fused_out + (size_t)(b0 + l31) * 256 + 32 * w8 + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    }
   }
   __syncthreads();
   // ---- layer 4: the four heads' hidden layers, hid_x = dropout(relu(Wh0_x fused + bh0_x)), x = column / 128  (fusion_model.py:208-235)
@@ -228,8 +243,10 @@ __global__ __launch_bounds__(NTH, 2) void tailw_fwd_kernel(const TailWideArgs a)
           op[j] = v;
         }
         *reinterpret_cast<float4*>(bufA + l31 * PHID + 4 * (32 * (2 * w8 + t) + 8 * g + 4 * h)) = o;
+        if (a.hid_out && b0 + l31 < B) *reinterpret_cast<float4*>(a.hid_out + (size_t)(b0 + l31) * 512 + 32 * (2 * w8 + t) + 8 * g + 4 * h) = o;
       }
   }
+  if (a.hid_out) return;                                     // (training call: the head output layer belongs to the loss launch)
   __syncthreads();
   // ---- layer 5: the head outputs (fp32, VALU): 16 lanes per sample, 8 hidden units each; score head through the sigmoid
   {
@@ -253,7 +270,9 @@ __global__ __launch_bounds__(NTH, 2) void tailw_fwd_kernel(const TailWideArgs a)
 int tail_wide_ok(int B, int C) { return B >= 1 && C >= 1 && C <= TAILW_MAXC; }
 
 int launch_tail_wide(const TailWideArgs& a, hipStream_t stream) {
-  if (!tail_wide_ok(a.B, a.C) || !a.Ymean || !a.H1mean || !a.Y2mean || !a.H2mean || !a.outs || !a.T13h || !a.T13l || !a.T23h || !a.T23l ||
+  const bool saves = a.comb_out || a.F1_out || a.fused_out || a.hid_out;
+  if (saves && !(a.comb_out && a.F1_out && a.fused_out && a.hid_out)) return (int)hipErrorInvalidValue;
+  if (!tail_wide_ok(a.B, a.C) || !a.Ymean || !a.H1mean || !a.Y2mean || !a.H2mean || (!a.outs && !saves) || !a.T13h || !a.T13l || !a.T23h || !a.T23l ||
       !a.Tfu0h || !a.Tfu0l || !a.Tfu3h || !a.Tfu3l || !a.Th0h || !a.Th0l || !a.b13 || !a.b23 || !a.bfu0 || !a.bfu3)
     return (int)hipErrorInvalidValue;
   for (int x = 0; x < 4; ++x) if (!a.bh0[x] || !a.Wh3[x] || !a.bh3[x]) return (int)hipErrorInvalidValue;
