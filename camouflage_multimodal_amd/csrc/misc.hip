@@ -542,56 +542,89 @@ __global__ void loss_kernel(const float* __restrict__ outs, const long long* __r
 // backward launch (d hidden = (d logits . W) * relu/dropout mask, dW = d logits^T . hidden, db) are 100 kFLOP in
 // all; as three launches they cost three launch floors.  One block per sample, wave x owns head x; only the
 // output-layer weight gradients cross samples (atomics).
+// S consecutive samples per block (large batches): the output layers' weight-gradient contributions are summed over the block's
+// samples in registers (ACC: nout <= 8) and leave as ONE atomic per element and block -- with one sample per block a batch of 256 is
+// 256-way contention on the same 770 addresses (35 us at B = 256).
+template <bool ACC>
 __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict__ hid, HeadsOut hp,
                                                          const long long* __restrict__ y, const float* __restrict__ e,
-                                                         const float* __restrict__ s, int C, int Fh, float scale,
+                                                         const float* __restrict__ s, int B, int S, int C, int Fh, float scale,
                                                          float* __restrict__ outs, float* __restrict__ terms,
                                                          int* __restrict__ pred, float* __restrict__ dhid) {
   __shared__ float so[HEADS_MAXW], sd[HEADS_MAXW];
-  const int b = blockIdx.x, x = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int x = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int W = 2 * C + 2, nout = x < 2 ? C : 1, coff = x == 0 ? 0 : (x == 1 ? C : (x == 2 ? 2 * C : 2 * C + 1));
   // (static indices + selects: indexing the by-value argument struct with the runtime wave id would move it to scratch)
   const float* Wx = x == 0 ? hp.W[0] : (x == 1 ? hp.W[1] : (x == 2 ? hp.W[2] : hp.W[3]));
   const float* bx = x == 0 ? hp.b[0] : (x == 1 ? hp.b[1] : (x == 2 ? hp.b[2] : hp.b[3]));
   float* gWx = x == 0 ? hp.gW[0] : (x == 1 ? hp.gW[1] : (x == 2 ? hp.gW[2] : hp.gW[3]));
   float* gbx = x == 0 ? hp.gb[0] : (x == 1 ? hp.gb[1] : (x == 2 ? hp.gb[2] : hp.gb[3]));
-  const float* h = hid + (size_t)b * 4 * Fh + x * Fh;
-  const float bias0 = bx[0];                                  // (in flight with the hidden row)
-  // labels first: their load latency hides under the dot products instead of following the barrier
-  const int yb = (int)y[b]; const float eb = e[b], sb = s[b];
+  const float bias0 = bx[0];
   constexpr int HC = 4;                                       // hidden values cached per lane (Fh <= 256), else re-read
-  float hv[HC];
+  constexpr int AO = ACC ? 8 : 1;
+  float gacc[AO][HC], gbacc = 0.f;
 #pragma unroll
-  for (int i = 0; i < HC; ++i) { const int c = lane + 64 * i; hv[i] = c < Fh ? h[c] : 0.f; }
-  for (int o = 0; o < nout; ++o) {
-    float acc = 0.f;
+  for (int o = 0; o < AO; ++o)
 #pragma unroll
-    for (int i = 0; i < HC; ++i) { const int c = lane + 64 * i; if (c < Fh) acc = fmaf(hv[i], Wx[(size_t)o * Fh + c], acc); }
-    for (int c = lane + 64 * HC; c < Fh; c += 64) acc = fmaf(h[c], Wx[(size_t)o * Fh + c], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      float v = acc + (o == 0 ? bias0 : bx[o]);
-      if (x == 3) v = 1.0f / (1.0f + __expf(-v));
-      so[coff + o] = v;
-      outs[(size_t)b * W + coff + o] = v;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) loss_sample(so, yb, eb, sb, C, terms + 4 * b, nullptr, sd, pred ? pred + b : nullptr);
-  __syncthreads();
-  auto back = [&](int c, float hval) {
-    float dh = 0.f;
+    for (int i = 0; i < HC; ++i) gacc[o][i] = 0.f;
+  for (int si = 0; si < S; ++si) {
+    const int b = blockIdx.x * S + si;
+    if (b >= B) break;                                        // (block-uniform)
+    const float* h = hid + (size_t)b * 4 * Fh + x * Fh;
+    // labels first: their load latency hides under the dot products instead of following the barrier
+    const int yb = (int)y[b]; const float eb = e[b], sb = s[b];
+    float hv[HC];
+#pragma unroll
+    for (int i = 0; i < HC; ++i) { const int c = lane + 64 * i; hv[i] = c < Fh ? h[c] : 0.f; }
     for (int o = 0; o < nout; ++o) {
-      const float d = sd[coff + o];
-      dh = fmaf(d, Wx[(size_t)o * Fh + c], dh);
-      atomicAdd(gWx + (size_t)o * Fh + c, d * hval);
-    }
-    dhid[(size_t)b * 4 * Fh + x * Fh + c] = hval > 0.f ? dh * scale : 0.f;
-  };
+      float acc = 0.f;
 #pragma unroll
-  for (int i = 0; i < HC; ++i) { const int c = lane + 64 * i; if (c < Fh) back(c, hv[i]); }     // (static register indices)
-  for (int c = lane + 64 * HC; c < Fh; c += 64) back(c, h[c]);
-  if (lane < nout) atomicAdd(gbx + lane, sd[coff + lane]);
+      for (int i = 0; i < HC; ++i) { const int c = lane + 64 * i; if (c < Fh) acc = fmaf(hv[i], Wx[(size_t)o * Fh + c], acc); }
+      for (int c = lane + 64 * HC; c < Fh; c += 64) acc = fmaf(h[c], Wx[(size_t)o * Fh + c], acc);
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        float v = acc + (o == 0 ? bias0 : bx[o]);
+        if (x == 3) v = 1.0f / (1.0f + __expf(-v));
+        so[coff + o] = v;
+        outs[(size_t)b * W + coff + o] = v;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) loss_sample(so, yb, eb, sb, C, terms + 4 * b, nullptr, sd, pred ? pred + b : nullptr);
+    __syncthreads();
+    auto back = [&](int c, float hval, int i) {
+      float dh = 0.f;
+      if constexpr (ACC) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          if (o < nout) {
+            const float d = sd[coff + o];
+            dh = fmaf(d, Wx[(size_t)o * Fh + c], dh);
+            if (i >= 0) gacc[o][i >= 0 ? i : 0] = fmaf(d, hval, gacc[o][i >= 0 ? i : 0]); else atomicAdd(gWx + (size_t)o * Fh + c, d * hval);
+          }
+        }
+      } else {
+        for (int o = 0; o < nout; ++o) {
+          const float d = sd[coff + o];
+          dh = fmaf(d, Wx[(size_t)o * Fh + c], dh);
+          atomicAdd(gWx + (size_t)o * Fh + c, d * hval);
+        }
+      }
+      dhid[(size_t)b * 4 * Fh + x * Fh + c] = hval > 0.f ? dh * scale : 0.f;
+    };
+#pragma unroll
+    for (int i = 0; i < HC; ++i) { const int c = lane + 64 * i; if (c < Fh) back(c, hv[i], i); }     // (static register indices)
+    for (int c = lane + 64 * HC; c < Fh; c += 64) back(c, h[c], -1);
+    if (lane < nout) gbacc += sd[coff + lane];
+    __syncthreads();                                          // (so / sd are rewritten by the next sample)
+  }
+  if constexpr (ACC) {
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+      for (int i = 0; i < HC; ++i) { const int c = lane + 64 * i; if (o < nout && c < Fh) atomicAdd(gWx + (size_t)o * Fh + c, gacc[o][i]); }
+  }
+  if (lane < nout) atomicAdd(gbx + lane, gbacc);
 }
 
 
@@ -1481,7 +1514,11 @@ int launch_heads_loss(const float* hid, const HeadsOut& hp, const long long* y, 
                       int Fh, float scale, float* outs, float* terms, int* pred, float* dhid, hipStream_t stream) {
   if (!heads_loss_ok(B, C)) return (int)hipErrorInvalidValue;
   const int prof = gemm_prof_open(stream, 0.0, PROF_TAIL);
-  hipLaunchKernelGGL(heads_loss_kernel, dim3(B), dim3(256), 0, stream, hid, hp, y, e, s, C, Fh, scale, outs, terms, pred, dhid);
+  // samples per block: 1 up to 64 samples (every block's latency counts), then 2 / 4 / 8 so that the grid stays at 64-128 blocks
+  const int S = B <= 64 ? 1 : (B <= 256 ? 2 : (B <= 512 ? 4 : 8));
+  const dim3 grid((B + S - 1) / S);
+  if (C <= 8) hipLaunchKernelGGL(heads_loss_kernel<true>, grid, dim3(256), 0, stream, hid, hp, y, e, s, B, S, C, Fh, scale, outs, terms, pred, dhid);
+  else        hipLaunchKernelGGL(heads_loss_kernel<false>, grid, dim3(256), 0, stream, hid, hp, y, e, s, B, S, C, Fh, scale, outs, terms, pred, dhid);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
