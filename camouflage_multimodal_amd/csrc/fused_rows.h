@@ -32,7 +32,7 @@ struct FrontStream {
   int tile_begin;
 };
 #define FUSED_FRONT_MAXZ 4
-#define FUSED_FRONT_MAXX 10
+#define FUSED_FRONT_MAXX 20
 #define FUSED_BWD1_MAXZ 16
 struct FrontArgs {
   FrontStream s[2]; float qscale; int save; unsigned long long* stamps; int exp;   // exp: developer experiments (timing only), 0 in product calls

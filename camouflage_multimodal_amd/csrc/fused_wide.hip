@@ -1224,10 +1224,10 @@ int launch_wide_front(FrontArgs& a, int rt, hipStream_t stream, int kg_only) {
   a.xchunks = 0;
   for (int i = 0; i < a.nxjob; ++i) {
     ShadowJob& J = a.xjob[i];
-    if ((J.N & 127) || (J.K & 15) || J.nsrc < 1 || J.nsrc > 4 || !J.dst || !al16(J.dst) || J.transposed) return (int)hipErrorInvalidValue;
+    if ((J.N & 127) || (J.K & 15) || J.nsrc < 1 || J.nsrc > 4 || !J.dst || !al16(J.dst)) return (int)hipErrorInvalidValue;
     int sum = 0;
-    for (int q = 0; q < J.nsrc; ++q) { if (!J.src[q] || !al16(J.src[q]) || (J.ld[q] & 3)) return (int)hipErrorInvalidValue; sum += J.rows[q]; }
-    if (sum != J.N) return (int)hipErrorInvalidValue;
+    for (int q = 0; q < J.nsrc; ++q) { if (!J.src[q] || !al16(J.src[q]) || (J.ld[q] & 3) || (J.transposed && (J.rows[q] & 7))) return (int)hipErrorInvalidValue; sum += J.rows[q]; }
+    if (sum != (J.transposed ? J.K : J.N)) return (int)hipErrorInvalidValue;      // (a transposed job's sources stack along K)
     J.chunk_begin = a.xchunks;
     a.xchunks += J.N * J.K / 8;
   }

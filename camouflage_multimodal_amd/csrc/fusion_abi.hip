@@ -44,6 +44,8 @@ int g_opt_tail17 = -1;                        // 0 = never take the one-launch t
 int g_opt_fused_variant = 1;                  // developer A/B of the fused kernels' weight streaming (fused_rows.h)
 int g_opt_fused_rt = -1;     // wide row tiles (fused_wide.hip): -1 = by batch size, 0 = never, 1 / 2 / 4 = that many 32-row tiles per block
 int g_opt_fused_one = 1;     // wide tiles: 1 = the RG rows' forward as ONE launch behind the KG rows' front half (rgfwd_kernel), 0 = front + back launches
+static thread_local bool t_tailw_bwd_planes = false;   // set by a training forward that built the tail's transposed planes (this call's workspace)
+int g_opt_tailw_bwd = -1;                     // 0: the tail's backward stays on the four GEMM launches (developer A/B)
 int g_opt_tailw = -1;        // the per-sample tail of wide-tile inference calls as one launch (tail_wide.h): 0 = never
 int g_opt_exp = 0;           // developer experiments inside the wide kernels (timing only)
 int g_opt_fused_save = 0;  // 1 = inference calls of the fused schedule also write what a backward would need (tests read it back)
@@ -117,7 +119,8 @@ struct Ws {
     us16 *W1T, *W2T, *Wo1T, *Wo2T, *WcRgT, *WcKgT;
     us16 *dH16, *dH2_16, *dU16, *dU2_16, *dQKV16, *dQKVkg16, *dR16, *dG16, *dO2_16;
     float *delta2, *dGpart;
-    us16* tailw[10];      // hi / lo planes of the per-sample tail's weights (tail_wide.h): W13, W23, Wfu0 [256 x 512], Wfu3 [256 x 256], heads [512 x 256]
+    us16* tailw[20];      // hi / lo planes of the per-sample tail's weights (tail_wide.h): W13, W23, Wfu0 [256 x 512], Wfu3 [256 x 256], heads [512 x 256];
+                          // 10..19: of their transposes for the tail's backward: heads^T [256 x 512], Wfu3^T [256 x 256], Wfu0^T, W13^T, W23^T [512 x 256]
   } f;
   int* tickets;         // [2][B] arrival counters (forward: KG->RG attention splits; backward: a sample's RG tiles), in the zero block
   float* dQ2acc;        // [TK][H] fp32 sums of the KG->RG query gradient (in the zero block, fused backward)
@@ -204,6 +207,7 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
         f.dQKV16 = c.take<us>(Tp * 3 * H); f.dQKVkg16 = c.take<us>(TKp * 3 * H); f.dR16 = c.take<us>(Tp * H); f.dG16 = c.take<us>(TKp * H);
         f.dO2_16 = c.take<us>(TKp * H); f.delta2 = c.take<float>((size_t)B * 8 * 16); f.dGpart = c.take<float>(TKp * H);
         for (int i = 0; i < 10; ++i) f.tailw[i] = c.take<us>(i < 6 ? 2 * H * H : (i < 8 ? H * H : 2 * H * H));
+        for (int i = 10; i < 20; ++i) f.tailw[i] = c.take<us>((i == 12 || i == 13) ? H * H : 2 * H * H);
       }
     }
   } else {
@@ -541,7 +545,7 @@ static bool tailw_taken(const camo_dims_t& d, int B, int T, int max_nr, bool sav
 }
 
 int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg, const int32_t* rg_offsets, const Desc& bd,
-                    const float* kg, int B, int T, int Nk, int max_nr, const Ws& w, const DropCfg& drop, bool save, hipStream_t st, bool want_tailw = false) {
+                    const float* kg, int B, int T, int Nk, int max_nr, const Ws& w, const DropCfg& drop, bool save, hipStream_t st, int want_tailw = 0) {
   const int H = 256, D = 128, TK = B * Nk;
   const size_t HH = (size_t)H * H;
   const Ws::F17& f = w.f;
@@ -639,6 +643,23 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
       std::memset(&J, 0, sizeof(J));
       J.dst = w.f.tailw[8 + lo]; J.N = 2 * H; J.K = H; J.nsrc = 4; J.lo = lo;
       for (int x = 0; x < 4; ++x) { J.src[x] = hsrc[x]; J.rows[x] = H / 2; J.ld[x] = H; }
+    }
+    if (want_tailw > 1) {                   // the transposed planes of the tail's backward (tail_wide.h, TailWideBwdArgs)
+      auto xjT = [&](us* dst, int N, int K, const float* src, int ld, int lo) {      // shadow of src^T: src has K rows of >= N columns
+        ShadowJob& J = fa.xjob[fa.nxjob++];
+        std::memset(&J, 0, sizeof(J));
+        J.dst = dst; J.N = N; J.K = K; J.transposed = 1; J.nsrc = 1; J.src[0] = src; J.rows[0] = K; J.ld[0] = ld; J.lo = lo;
+      };
+      for (int lo = 0; lo < 2; ++lo) {
+        ShadowJob& J = fa.xjob[fa.nxjob++];   // [Wh0_0; ..; Wh0_3]^T: 512 source rows (4 x 128) of 256 columns
+        std::memset(&J, 0, sizeof(J));
+        J.dst = w.f.tailw[10 + lo]; J.N = H; J.K = 2 * H; J.transposed = 1; J.nsrc = 4; J.lo = lo;
+        for (int x = 0; x < 4; ++x) { J.src[x] = hsrc[x]; J.rows[x] = H / 2; J.ld[x] = H; }
+        xjT(w.f.tailw[12 + lo], H, H, P[CAMO_P_FU_W3], H, lo);
+        xjT(w.f.tailw[14 + lo], 2 * H, H, P[CAMO_P_FU_W0], 2 * H, lo);
+        xjT(w.f.tailw[16 + lo], 2 * H, H, P[CAMO_P_F1_W3], 2 * H, lo);
+        xjT(w.f.tailw[18 + lo], 2 * H, H, P[CAMO_P_F2_W3], 2 * H, lo);
+      }
     }
   }
   if (one) { fa.split3 = 1; CK(launch_wide_front(fa, 1, st, 1), "fused forward, KG rows' front half (32-row tiles, one in-projection pass per block)"); }
@@ -916,6 +937,7 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
                         size_t workspace_bytes, float* outs, float* attn_rg2kg, float* attn_kg2rg, int32_t training,
                         uint64_t seed, int32_t precision, int32_t flags, void* stream, const FusedLoss* fl,
                         const FusedLoss* fl17 = nullptr /* given: loss + the whole tail backward ride in the one-launch tail */) {
+  t_tailw_bwd_planes = false;
   if (int e = check_dims(dims, B, T, Nk)) return e;
   if (!params || !rg || !rg_offsets || !desc || !kg || !workspace || !outs)
     return fail(CAMO_E_ARG, "null pointer argument");
@@ -967,7 +989,8 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
     // and the backward launches follow as before
     const bool tailw_train = !tailw && fl && !fl17 && save17 && B > 64 && g_opt_tailw != 0 && g_opt_fused_rt < 0 && T >= 4 * 32 * 224 &&
                              max_nr <= wide_max_rows(4) - 256 && tail_wide_ok(B, d.num_classes) && heads_loss_ok(B, d.num_classes);
-    if (int e = forward_nodes17(d, P, rg, rg_offsets, bd, kg, B, T, Nk, max_nr, w, drop, save17, st, tailw || tailw_train)) return e;
+    if (int e = forward_nodes17(d, P, rg, rg_offsets, bd, kg, B, T, Nk, max_nr, w, drop, save17, st, tailw_train ? 2 : (tailw ? 1 : 0))) return e;
+    t_tailw_bwd_planes = tailw_train;        // (the backward half of this training call may take the two-plane launch too)
     if (tailw || tailw_train) {
       TailWideArgs ta; std::memset(&ta, 0, sizeof(ta));
       ta.Ymean = w.Ymean; ta.H1mean = w.H1mean; ta.Y2mean = w.Y2mean; ta.H2mean = w.H2mean;
@@ -1112,6 +1135,28 @@ static int backward_impl(const camo_dims_t* dims, const float* const* params, fl
   const bool has_rgp = P[CAMO_P_RG_PROJ_W] != nullptr, has_kgp = P[CAMO_P_KG_PROJ_W] != nullptr;
   const float* R = has_rgp ? w.R : rg;
   const float* G = has_kgp ? w.G : kg;
+  const bool tailw_bwd = t_tailw_bwd_planes && heads_out_done && g_opt_tailw_bwd != 0;
+  t_tailw_bwd_planes = false;
+  if (tailw_bwd) {
+    // the tail's input-gradient chain as ONE two-plane launch (tail_wide.h) + ONE launch for its weight gradients, instead of four
+    // fp32 GEMM launches that each pair an input gradient with a weight gradient (B = 256: 108 us)
+    TailWideBwdArgs ta; std::memset(&ta, 0, sizeof(ta));
+    const us* const* tw = w.f.tailw;
+    ta.dhid = w.dhid; ta.F1 = w.F1;
+    ta.Th0h = tw[10]; ta.Th0l = tw[11]; ta.Tfu3h = tw[12]; ta.Tfu3l = tw[13]; ta.Tfu0h = tw[14]; ta.Tfu0l = tw[15];
+    ta.T13h = tw[16]; ta.T13l = tw[17]; ta.T23h = tw[18]; ta.T23l = tw[19];
+    ta.dfused = w.dfused; ta.dF1 = w.dF1; ta.dcomb = w.dcomb; ta.dHm1 = w.dHm1; ta.dHm2 = w.dHm2;
+    ta.B = B; ta.scale = drop.scale;
+    CK(launch_tail_wide_bwd(ta, st), "per-sample tail, input gradients (wide, one launch)");
+    const int Fh = H / 2;
+    float* const* hg = Gr + CAMO_P_HEADS;
+    for (int x = 0; x < 4; ++x) gt.tn(w.dhid + x * Fh, 4 * Fh, w.fused, H, hg[4 * x], H, hg[4 * x + 1], Fh, H, B);
+    gt.tn(w.dfused, H, w.F1, H, Gr[CAMO_P_FU_W3], H, Gr[CAMO_P_FU_B3], H, H, B);
+    gt.tn(w.dF1, H, w.comb, 2 * H, Gr[CAMO_P_FU_W0], 2 * H, Gr[CAMO_P_FU_B0], H, 2 * H, B);
+    gt.tn(w.dcomb, 2 * H, w.H1mean, 2 * H, Gr[CAMO_P_F1_W3], 2 * H, Gr[CAMO_P_F1_B3], H, 2 * H, B);
+    gt.tn(w.dcomb + H, 2 * H, w.H2mean, 2 * H, Gr[CAMO_P_F2_W3], 2 * H, Gr[CAMO_P_F2_B3], H, 2 * H, B);
+    CK(gt.run(), "per-sample tail, weight gradients");
+  } else {
   if (int e = heads_backward(d, P + CAMO_P_HEADS, Gr + CAMO_P_HEADS, w, B, H, outs, d_outs, d_outs_pre_activation, drop, st, gt, heads_out_done)) return e;
   // fusion layer
   set_relu_bwd(gt.nn(w.dfused, H, P[CAMO_P_FU_W3], H, w.dF1, H, B, H, H), w.F1, H, drop.scale);
@@ -1126,6 +1171,7 @@ static int backward_impl(const camo_dims_t* dims, const float* const* params, fl
   gt.tn(w.dcomb, 2 * H, w.H1mean, 2 * H, Gr[CAMO_P_F1_W3], 2 * H, Gr[CAMO_P_F1_B3], H, 2 * H, B);
   gt.tn(w.dcomb + H, 2 * H, w.H2mean, 2 * H, Gr[CAMO_P_F2_W3], 2 * H, Gr[CAMO_P_F2_B3], H, 2 * H, B);
   CK(gt.run(), "ffn layer 3 bwd (pooled)");
+  }
   CK(record_tail_event(st), "tail event");
   if (!(flags & CAMO_FLAG_ATTN_MAPS) && fused17_ok(d, P, precision, Nk, max_nr))
     return backward_nodes17(d, P, Gr, rg_offsets, bd, B, T, Nk, w, drop, st);
@@ -1364,6 +1410,7 @@ int camo_debug_set_option(const char* name, int32_t value) {
   if (std::strcmp(name, "exp") == 0) { g_opt_exp = value; return 0; }
   if (std::strcmp(name, "fused_one") == 0) { g_opt_fused_one = value; return 0; }
   if (std::strcmp(name, "tailw") == 0) { g_opt_tailw = value; return 0; }
+  if (std::strcmp(name, "tailw_bwd") == 0) { g_opt_tailw_bwd = value; return 0; }
   if (std::strcmp(name, "tail_skip_arrival") == 0) { g_tail_debug_skip = value; return 0; }
   if (std::strcmp(name, "fused_variant") == 0) { g_opt_fused_variant = value; return 0; }
   if (std::strcmp(name, "tail17") == 0) { g_opt_tail17 = value; return 0; }

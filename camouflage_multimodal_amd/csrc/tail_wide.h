@@ -20,3 +20,18 @@ struct TailWideArgs {
 #define TAILW_MAXC 8
 int tail_wide_ok(int B, int C);
 int launch_tail_wide(const TailWideArgs& a, hipStream_t stream);
+
+// ---- the same for the tail's input-gradient chain (training calls): from the gradient of the four heads' hidden pre-activations
+//   dfused = dhid . [Wh0_0; ..; Wh0_3]      dF1 = (F1 > 0) * scale * (dfused . Wfu3)      dcomb = dF1 . Wfu0
+//   d(mean H1d) = dcomb[:, :256] . W13      d(mean H2d) = dcomb[:, 256:] . W23
+// for 32 samples per block, two-plane operands; the weight planes are the TRANSPOSED matrices' shadows (the contraction runs over a
+// weight's rows).  The weight gradients (sums over the batch) are one batched GEMM launch behind it, fed by the fp32 outputs here.
+struct TailWideBwdArgs {
+  const float* dhid;                                        // [B][512] gradient of the hidden layers' pre-activations (loss launch)
+  const float* F1;                                          // [B][256] fusion layer 0 activations (after ReLU and dropout)
+  const us16 *Th0h, *Th0l, *Tfu3h, *Tfu3l, *Tfu0h, *Tfu0l, *T13h, *T13l, *T23h, *T23l;   // shadows of Wh0s^T [256 x 512], Wfu3^T [256 x 256],
+                                                                                         // Wfu0^T, W13^T, W23^T [512 x 256]
+  float *dfused, *dF1, *dcomb, *dHm1, *dHm2;                // [B][256], [B][256], [B][512], [B][512], [B][512]
+  int B; float scale;                                       // scale: the dropout keep scale 1 / (1 - p) (1 in eval mode)
+};
+int launch_tail_wide_bwd(const TailWideBwdArgs& a, hipStream_t stream);

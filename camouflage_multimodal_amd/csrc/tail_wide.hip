@@ -265,6 +265,106 @@ __global__ __launch_bounds__(NTH, 2) void tailw_fwd_kernel(const TailWideArgs a)
   }
 }
 
+// ---------------------------------------------------------------- the input-gradient chain (tail_wide.h, TailWideBwdArgs)
+// Same machinery as the forward: 32 samples per block, 8 waves, every product three bf16 MFMAs on hi / lo planes; the planes
+// ping-pong between the two LDS buffers.  Every result also leaves as fp32 (the operands of the weight-gradient launch, and the
+// pooled gradients the node-level backward reads).
+__global__ __launch_bounds__(NTH, 2) void tailw_bwd_kernel(const TailWideBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b0 = (int)blockIdx.x * TS, B = a.B;
+  char* bufA = smem; char* bufB = smem + BUF;
+  const size_t frag0 = (size_t)((w8 >> 1) * 2 * 32 + (w8 & 1)) * 64 + lane;       // tile w8 of a [256 x 512] shadow
+  const size_t frag3 = (size_t)((w8 >> 1) * 2 * 16 + (w8 & 1)) * 64 + lane;       // tile w8 of a [256 x 256] shadow
+  const size_t frag4 = (size_t)((w8 >> 1) * 4 * 16 + 2 * (w8 & 1)) * 64 + lane;   // tiles 2 w8, 2 w8 + 1 of a [512 x 256] shadow
+  StageHL<1, 32, 2, 6> s1;
+  s1.prefetch(reinterpret_cast<const u32x4*>(a.Th0h) + frag0, reinterpret_cast<const u32x4*>(a.Th0l) + frag0);
+  float4 in[8];
+  load_in512(a.dhid, b0, B, in);
+  const bool rok = b0 + l31 < B;
+  const size_t srow = (size_t)min(b0 + l31, B - 1);
+  float4 f1v[4];                                             // this lane's 16 F1 values of tile w8 (the ReLU mask of layer 2)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) f1v[g] = *reinterpret_cast<const float4*>(a.F1 + srow * 256 + 32 * w8 + 8 * g + 4 * h);
+  store_in512(bufA, in);
+  __syncthreads();
+  auto put_hl = [&](char* dst, int pitch, int plane, int col0, const float (&v)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const HiLo p = split2(v[4 * g], v[4 * g + 1]), q = split2(v[4 * g + 2], v[4 * g + 3]);
+      *reinterpret_cast<u32x2*>(dst + l31 * pitch + 2 * (col0 + 8 * g + 4 * h)) = u32x2{p.hi, q.hi};
+      *reinterpret_cast<u32x2*>(dst + plane + l31 * pitch + 2 * (col0 + 8 * g + 4 * h)) = u32x2{p.lo, q.lo};
+    }
+  };
+  auto put_g = [&](float* out, int ld, int col0, const float (&v)[16]) {
+    if (!rok) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(out + (size_t)(b0 + l31) * ld + col0 + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+  };
+  StageHL<1, 16, 2, 6> s2;
+  // ---- dfused = dhid . Wh0s  (K = 512)
+  {
+    f32x16 acc[1] = {zero16()};
+    s1.run(bufA + l31 * P512 + 16 * h, bufA + PLANE + l31 * P512 + 16 * h, acc);
+    s2.prefetch(reinterpret_cast<const u32x4*>(a.Tfu3h) + frag3, reinterpret_cast<const u32x4*>(a.Tfu3l) + frag3);
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = acc[0][i];
+    put_hl(bufB, P256, TS * P256, 32 * w8, v);
+    put_g(a.dfused, 256, 32 * w8, v);
+  }
+  __syncthreads();
+  StageHL<2, 16, 4, 6> s3;
+  // ---- dF1 = (F1 > 0) * scale * (dfused . Wfu3)  (K = 256)
+  {
+    f32x16 acc[1] = {zero16()};
+    s2.run(bufB + l31 * P256 + 16 * h, bufB + TS * P256 + l31 * P256 + 16 * h, acc);
+    s3.prefetch(reinterpret_cast<const u32x4*>(a.Tfu0h) + frag4, reinterpret_cast<const u32x4*>(a.Tfu0l) + frag4);
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float m[4] = {f1v[g].x, f1v[g].y, f1v[g].z, f1v[g].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * g + e] = m[e] > 0.f ? acc[0][4 * g + e] * a.scale : 0.f;
+    }
+    put_hl(bufA, P256, TS * P256, 32 * w8, v);
+    put_g(a.dF1, 256, 32 * w8, v);
+  }
+  __syncthreads();
+  StageHL<2, 16, 4, 6> s4;
+  // ---- dcomb = dF1 . Wfu0  (K = 256, 512 outputs: tiles 2 w8, 2 w8 + 1)
+  {
+    f32x16 acc[2] = {zero16(), zero16()};
+    s3.run(bufA + l31 * P256 + 16 * h, bufA + TS * P256 + l31 * P256 + 16 * h, acc);
+    s4.prefetch(reinterpret_cast<const u32x4*>(a.T13h) + frag4, reinterpret_cast<const u32x4*>(a.T13l) + frag4);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = acc[t][i];
+      put_hl(bufB, P512, PLANE, 32 * (2 * w8 + t), v);
+      put_g(a.dcomb, 512, 32 * (2 * w8 + t), v);
+    }
+  }
+  __syncthreads();
+  // ---- d(mean H1d) = dcomb[:, :256] . W13,  d(mean H2d) = dcomb[:, 256:] . W23  (K = 256 each, 512 outputs)
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x16 acc[2] = {zero16(), zero16()};
+    s4.run(bufB + l31 * P512 + 512 * half + 16 * h, bufB + PLANE + l31 * P512 + 512 * half + 16 * h, acc);
+    if (half == 0) s4.prefetch(reinterpret_cast<const u32x4*>(a.T23h) + frag4, reinterpret_cast<const u32x4*>(a.T23l) + frag4);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = acc[t][i];
+      put_g(half ? a.dHm2 : a.dHm1, 512, 32 * (2 * w8 + t), v);
+    }
+  }
+}
+
 }  // namespace
 
 int tail_wide_ok(int B, int C) { return B >= 1 && C >= 1 && C <= TAILW_MAXC; }
@@ -286,6 +386,21 @@ int launch_tail_wide(const TailWideArgs& a, hipStream_t stream) {
   const dim3 grid((a.B + TS - 1) / TS);
   if (a.drop.p > 0.f) hipLaunchKernelGGL((tailw_fwd_kernel<true>), grid, dim3(NTH), LDS_BYTES, stream, a);
   else                hipLaunchKernelGGL((tailw_fwd_kernel<false>), grid, dim3(NTH), LDS_BYTES, stream, a);
+  gemm_prof_close(prof, stream);
+  return (int)hipGetLastError();
+}
+
+int launch_tail_wide_bwd(const TailWideBwdArgs& a, hipStream_t stream) {
+  if (a.B < 1 || !a.dhid || !a.F1 || !a.Th0h || !a.Th0l || !a.Tfu3h || !a.Tfu3l || !a.Tfu0h || !a.Tfu0l || !a.T13h || !a.T13l || !a.T23h || !a.T23l ||
+      !a.dfused || !a.dF1 || !a.dcomb || !a.dHm1 || !a.dHm2)
+    return (int)hipErrorInvalidValue;
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tailw_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+    return true;
+  }();
+  (void)attr;
+  const int prof = gemm_prof_open(stream, 2.0 * a.B * (512.0 * 256 + 256.0 * 256 + 3.0 * 256 * 512) * 3.0, PROF_TAIL);
+  hipLaunchKernelGGL(tailw_bwd_kernel, dim3((a.B + TS - 1) / TS), dim3(NTH), 2 * BUF, stream, a);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
