@@ -26,7 +26,7 @@ def _opt(name, value):
 @pytest.fixture
 def fused_opts():
     yield _opt
-    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1); _opt("fused_rt", -1); _opt("tailw", -1); _opt("fused_one", 1); _opt("tn_big", -1); _opt("param_space", -1)
+    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1); _opt("fused_rt", -1); _opt("tailw", -1); _opt("fused_one", 1); _opt("tn_big", -1); _opt("param_space", -1); _opt("tailw_bwd", -1)
 
 
 def bf16_round(x):
@@ -369,7 +369,8 @@ def test_wide_tail_matches_separate_launches(B, ncls, kg_real, fused_opts):
 
 
 def test_large_batch_training_takes_the_wide_front_half(kg_real, fused_opts):
-    """Training calls with at least 4 * 32 * 224 rows run the front half on 128-row blocks (fused_wide.hip, front8_kernel) and keep the
+    """Training calls with at least 4 * 32 * 224 rows run the front half on 128-row blocks (fused_wide.hip, front8_kernel), past 64
+    samples the per-sample tail's forward and input-gradient chain on two-plane MFMA launches (tail_wide.hip), and keep the
     32-row back half: the same bf16 tensors leave the front launch, so outputs and loss terms agree to rounding and every parameter
     gradient to a few 1e-4 of its tensor against the all-32-row schedule (fused_rt = 0) on the same masks."""
     cfg = OP.full_cfg()
@@ -393,6 +394,20 @@ def test_large_batch_training_takes_the_wide_front_half(kg_real, fused_opts):
         torch.cuda.synchronize()
         res.append((t2n(outs), t2n(terms), {k: t2n(p.grad).copy() for k, p in m.named_parameters()}))
     fused_opts("fused_rt", -1)
+    # the same wide-front step with the tail's backward on its four fp32 GEMM launches instead of the two-plane launch: the tail
+    # parameters' gradients differ by the planes' 2^-17 and by summation order only
+    fused_opts("tailw_bwd", 0)
+    ws = eng.workspace(batch, private=True)
+    ws.zero_()
+    g.zero_()
+    eng.train_raw(batch, ws, torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s), True, 41, eng._gtab)
+    torch.cuda.synchronize()
+    fused_opts("tailw_bwd", -1)
+    gc = {k: t2n(p.grad).copy() for k, p in m.named_parameters()}
+    for k in gc:
+        if k.startswith(("mask_head", "instance_head", "edge_head", "score_head")) or "fusion_layer" in k or ".3." in k:
+            scale = max(float(np.abs(gc[k]).max()), 1e-8)
+            assert float(np.abs(res[0][2][k] - gc[k]).max()) <= 3e-4 * scale + 2e-7, (k, float(np.abs(res[0][2][k] - gc[k]).max()), scale)
     (oa, ta, ga), (ob, tb, gb) = res
     assert np.isfinite(oa).all()
     assert_close(oa, ob, 2e-4, 1e-4, "outputs")
