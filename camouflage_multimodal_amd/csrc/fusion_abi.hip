@@ -351,7 +351,7 @@ bool sched16_ok(const camo_dims_t& d, const float* const* P, int precision, int 
 struct FusedLoss { const int64_t* y; const float* e; const float* s; float* terms; int32_t* pred; float* const* head_grads; };
 
 int heads_forward(const camo_dims_t& d, const float* const* hp /*16 pointers*/, const Ws& w, int B, int F,
-                  float* outs, GB& g, const FusedLoss* fl = nullptr, bool hidden_done = false) {
+                  float* outs, GB& g, const FusedLoss* fl = nullptr, bool hidden_done = false, bool defer_out_grads = false) {
   const int Fh = F / 2, C = d.num_classes, Wd = 2 * C + 2;
   const int nout[4] = {C, C, 1, 1}, coff[4] = {0, C, 2 * C, 2 * C + 1};
   if (!hidden_done) {                      // (else w.hid came out of the two-plane tail launch)
@@ -365,7 +365,7 @@ int heads_forward(const camo_dims_t& d, const float* const* hp /*16 pointers*/, 
     HeadsOut ho;
     for (int x = 0; x < 4; ++x) { ho.W[x] = hp[4 * x + 2]; ho.b[x] = hp[4 * x + 3]; ho.gW[x] = fl->head_grads[4 * x + 2]; ho.gb[x] = fl->head_grads[4 * x + 3]; }
     CK(launch_heads_loss(w.hid, ho, reinterpret_cast<const long long*>(fl->y), fl->e, fl->s, B, C, Fh, g.b.drop.scale, outs, fl->terms,
-                         fl->pred, w.dhid, g.st), "heads out + loss + heads out bwd");
+                         fl->pred, w.dhid, g.st, defer_out_grads ? w.dlog : nullptr), "heads out + loss + heads out bwd");
     return 0;
   }
   for (int x = 0; x < 4; ++x)
@@ -1002,7 +1002,8 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
       if (tailw_train) { ta.comb_out = w.comb; ta.F1_out = w.F1; ta.fused_out = w.fused; ta.hid_out = w.hid; }
       CK(launch_tail_wide(ta, st), "per-sample tail (wide, one launch)");
       if (!tailw_train) return 0;
-      return heads_forward(d, P + CAMO_P_HEADS, w, B, H, outs, gt, fl, /*hidden_done=*/true);
+      // (the output layers' weight gradients ride in the tail's weight-gradient launch of the backward half, when that half takes it)
+      return heads_forward(d, P + CAMO_P_HEADS, w, B, H, outs, gt, fl, /*hidden_done=*/true, /*defer_out_grads=*/g_opt_tailw_bwd != 0);
     }
   } else if (use16) {
     if (int e = forward_nodes16(d, P, rg, rg_offsets, row_sample, inv_nr, kg, B, T, Nk, max_nr, w, attn_rg2kg, attn_kg2rg, drop, st)) return e;
@@ -1150,6 +1151,10 @@ static int backward_impl(const camo_dims_t* dims, const float* const* params, fl
     CK(launch_tail_wide_bwd(ta, st), "per-sample tail, input gradients (wide, one launch)");
     const int Fh = H / 2;
     float* const* hg = Gr + CAMO_P_HEADS;
+    {
+      const int C = d.num_classes, Wd = 2 * C + 2, nout[4] = {C, C, 1, 1}, coff[4] = {0, C, 2 * C, 2 * C + 1};
+      for (int x = 0; x < 4; ++x) gt.tn(w.dlog + coff[x], Wd, w.hid + x * Fh, 4 * Fh, hg[4 * x + 2], Fh, hg[4 * x + 3], nout[x], Fh, B);   // (left by the loss launch)
+    }
     for (int x = 0; x < 4; ++x) gt.tn(w.dhid + x * Fh, 4 * Fh, w.fused, H, hg[4 * x], H, hg[4 * x + 1], Fh, H, B);
     gt.tn(w.dfused, H, w.F1, H, Gr[CAMO_P_FU_W3], H, Gr[CAMO_P_FU_B3], H, H, B);
     gt.tn(w.dF1, H, w.comb, 2 * H, Gr[CAMO_P_FU_W0], 2 * H, Gr[CAMO_P_FU_B0], H, 2 * H, B);

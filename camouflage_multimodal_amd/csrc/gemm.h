@@ -3,7 +3,7 @@
 #pragma once
 #include "common.h"
 
-#define GEMM_MAXP 8
+#define GEMM_MAXP 12
 
 enum : int {
   GF_RELU = 1,        // v = max(v, 0)                       (after bias)

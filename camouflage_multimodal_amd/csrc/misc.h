@@ -51,7 +51,7 @@ int launch_loss(const float* outs, const long long* y, const float* e, const flo
 struct HeadsOut { const float* W[4]; const float* b[4]; float* gW[4]; float* gb[4]; };
 int heads_loss_ok(int B, int C);
 int launch_heads_loss(const float* hid, const HeadsOut& hp, const long long* y, const float* e, const float* s, int B, int C,
-                      int Fh, float scale, float* outs, float* terms, int* pred, float* dhid, hipStream_t stream);
+                      int Fh, float scale, float* outs, float* terms, int* pred, float* dhid, hipStream_t stream, float* dlog = nullptr);
 int launch_sumsq(const float* g, size_t n, float* out, hipStream_t stream);
 int launch_clip_adamw(float* p, float* g, float* m, float* v, size_t n, float* sumsq, float max_norm,
                       float lr, float b1, float b2, float eps, float wd, int step, int zero_grads, hipStream_t stream);

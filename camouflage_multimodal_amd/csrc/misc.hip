@@ -550,7 +550,9 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict
                                                          const long long* __restrict__ y, const float* __restrict__ e,
                                                          const float* __restrict__ s, int B, int S, int C, int Fh, float scale,
                                                          float* __restrict__ outs, float* __restrict__ terms,
-                                                         int* __restrict__ pred, float* __restrict__ dhid) {
+                                                         int* __restrict__ pred, float* __restrict__ dhid, float* __restrict__ dlog) {
+  // dlog != null: the output layers' weight and bias gradients are left to a GEMM launch of the caller, which gets the gradient of
+  // the 2C + 2 pre-activations here ([B][2C+2]) -- N blocks adding to the same 770 addresses serialise at the memory side
   __shared__ float so[HEADS_MAXW], sd[HEADS_MAXW];
   const int x = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int W = 2 * C + 2, nout = x < 2 ? C : 1, coff = x == 0 ? 0 : (x == 1 ? C : (x == 2 ? 2 * C : 2 * C + 1));
@@ -592,9 +594,12 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) loss_sample(so, yb, eb, sb, C, terms + 4 * b, nullptr, sd, pred ? pred + b : nullptr);
     __syncthreads();
+    if (dlog && threadIdx.x < W) dlog[(size_t)b * W + threadIdx.x] = sd[threadIdx.x];
     auto back = [&](int c, float hval, int i) {
       float dh = 0.f;
-      if constexpr (ACC) {
+      if (dlog) {
+        for (int o = 0; o < nout; ++o) dh = fmaf(sd[coff + o], Wx[(size_t)o * Fh + c], dh);
+      } else if constexpr (ACC) {
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
           if (o < nout) {
@@ -615,9 +620,10 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < HC; ++i) { const int c = lane + 64 * i; if (c < Fh) back(c, hv[i], i); }     // (static register indices)
     for (int c = lane + 64 * HC; c < Fh; c += 64) back(c, h[c], -1);
-    if (lane < nout) gbacc += sd[coff + lane];
+    if (!dlog && lane < nout) gbacc += sd[coff + lane];
     __syncthreads();                                          // (so / sd are rewritten by the next sample)
   }
+  if (dlog) return;
   if constexpr (ACC) {
 #pragma unroll
     for (int o = 0; o < 8; ++o)
@@ -1511,14 +1517,14 @@ int launch_loss(const float* outs, const long long* y, const float* e, const flo
 
 int heads_loss_ok(int B, int C) { return B >= 1 && C >= 1 && 2 * C + 2 <= HEADS_MAXW; }
 int launch_heads_loss(const float* hid, const HeadsOut& hp, const long long* y, const float* e, const float* s, int B, int C,
-                      int Fh, float scale, float* outs, float* terms, int* pred, float* dhid, hipStream_t stream) {
+                      int Fh, float scale, float* outs, float* terms, int* pred, float* dhid, hipStream_t stream, float* dlog) {
   if (!heads_loss_ok(B, C)) return (int)hipErrorInvalidValue;
   const int prof = gemm_prof_open(stream, 0.0, PROF_TAIL);
   // samples per block: 1 up to 64 samples (every block's latency counts), then 2 / 4 / 8 so that the grid stays at 64-128 blocks
   const int S = B <= 64 ? 1 : (B <= 256 ? 2 : (B <= 512 ? 4 : 8));
   const dim3 grid((B + S - 1) / S);
-  if (C <= 8) hipLaunchKernelGGL(heads_loss_kernel<true>, grid, dim3(256), 0, stream, hid, hp, y, e, s, B, S, C, Fh, scale, outs, terms, pred, dhid);
-  else        hipLaunchKernelGGL(heads_loss_kernel<false>, grid, dim3(256), 0, stream, hid, hp, y, e, s, B, S, C, Fh, scale, outs, terms, pred, dhid);
+  if (C <= 8) hipLaunchKernelGGL(heads_loss_kernel<true>, grid, dim3(256), 0, stream, hid, hp, y, e, s, B, S, C, Fh, scale, outs, terms, pred, dhid, dlog);
+  else        hipLaunchKernelGGL(heads_loss_kernel<false>, grid, dim3(256), 0, stream, hid, hp, y, e, s, B, S, C, Fh, scale, outs, terms, pred, dhid, dlog);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
