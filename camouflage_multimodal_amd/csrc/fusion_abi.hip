@@ -45,6 +45,7 @@ int g_opt_fused_variant = 1;                  // developer A/B of the fused kern
 int g_opt_fused_rt = -1;     // wide row tiles (fused_wide.hip): -1 = by batch size, 0 = never, 1 / 2 / 4 = that many 32-row tiles per block
 int g_opt_fused_one = 1;     // wide tiles: 1 = the RG rows' forward as ONE launch behind the KG rows' front half (rgfwd_kernel), 0 = front + back launches
 static thread_local bool t_tailw_bwd_planes = false;   // set by a training forward that built the tail's transposed planes (this call's workspace)
+int g_opt_wide_front_rt = 0;                  // developer A/B: > 0 forces the wide front half of training calls with that many sub-tiles per block, < 0 never
 int g_opt_tailw_bwd = -1;                     // 0: the tail's backward stays on the four GEMM launches (developer A/B)
 int g_opt_tailw = -1;        // the per-sample tail of wide-tile inference calls as one launch (tail_wide.h): 0 = never
 int g_opt_exp = 0;           // developer experiments inside the wide kernels (timing only)
@@ -623,7 +624,11 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   t_nzero_front = 0;
   const int rt = wide_rt(T, max_nr, save);
   const bool one = rt >= 2 && g_opt_fused_one != 0;
-  const bool wide_train_front = !rt && g_opt_fused_rt < 0 && save && T >= 4 * 32 * 224 && max_nr <= wide_max_rows(4) - 256;
+  // training calls: the front half alone on wide blocks -- 64-row blocks from 10 240 packed rows (front 21 -> 17 us at B = 24, 31 -> 26 at
+  // B = 48, 37 -> 28 at B = 56), 128-row blocks from 28 672
+  const int wf_rt = g_opt_wide_front_rt > 0 ? g_opt_wide_front_rt : (T >= 4 * 32 * 224 ? 4 : 2);
+  const bool wide_train_front = !rt && g_opt_fused_rt < 0 && g_opt_wide_front_rt >= 0 && save && (T >= 10240 || g_opt_wide_front_rt > 0) &&
+                                max_nr <= wide_max_rows(wf_rt) - 64 * wf_rt;
   if ((one || wide_train_front) && want_tailw) {
     // the per-sample tail's weights as hi / lo bf16 planes in fragment order: extra blocks of the (KG rows') wide front launch
     const size_t HH = (size_t)H * H;
@@ -664,10 +669,9 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   }
   if (one) { fa.split3 = 1; CK(launch_wide_front(fa, 1, st, 1), "fused forward, KG rows' front half (32-row tiles, one in-projection pass per block)"); }
   else if (rt) CK(launch_wide_front(fa, rt, st, 0), "fused forward, front half (wide tiles)");
-  // training calls at large batches: the front half alone on 128-row blocks (same outputs; measured B = 64: 37.5 -> 30.3 us, B = 256:
-  // 130 -> 104 us), the back half stays on the 32-row kernel, whose saving + dropout variant is the faster one (77 vs 94 us at B = 64)
+  // (the back half of training calls stays on the 32-row kernel, whose saving + dropout variant is the faster one: 77 vs 94 us at B = 64)
   else if (wide_train_front)
-    CK(launch_wide_front(fa, 4, st, 0), "fused forward, front half (wide tiles)");
+    CK(launch_wide_front(fa, wf_rt, st, 0), "fused forward, front half (wide tiles)");
   else CK(launch_fused_front(fa, g_opt_fused_variant, st), "fused forward, front half");
   BackArgs ba; std::memset(&ba, 0, sizeof(ba));
   ba.s[0] = BackStream{f.Wo1, P[CAMO_P_A1_OUT_B], f.W1, P[CAMO_P_F1_B0], P[CAMO_P_LN1_W], P[CAMO_P_LN1_B], f.R16,
@@ -1416,6 +1420,7 @@ int camo_debug_set_option(const char* name, int32_t value) {
   if (std::strcmp(name, "fused_one") == 0) { g_opt_fused_one = value; return 0; }
   if (std::strcmp(name, "tailw") == 0) { g_opt_tailw = value; return 0; }
   if (std::strcmp(name, "tailw_bwd") == 0) { g_opt_tailw_bwd = value; return 0; }
+  if (std::strcmp(name, "wide_front_rt") == 0) { g_opt_wide_front_rt = value; return 0; }
   if (std::strcmp(name, "tail_skip_arrival") == 0) { g_tail_debug_skip = value; return 0; }
   if (std::strcmp(name, "fused_variant") == 0) { g_opt_fused_variant = value; return 0; }
   if (std::strcmp(name, "tail17") == 0) { g_opt_tail17 = value; return 0; }
