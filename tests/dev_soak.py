@@ -1,4 +1,4 @@
-"""Developer aid: optimizer steps on repeated synthetic batches (loss must fall, parameters stay finite): 40 at B = 128, 2 000 at B = 40 (grouped one-launch tail) and\n20 000 at B = 16 (the one-launch tail with its in-kernel all-reduces); reports the tail kernel's timeout counter.\n  python tests/dev_soak.py"""
+"""Developer aid: optimizer steps on repeated synthetic batches (loss must fall, parameters stay finite): 1 000 at B = 128 (two-plane tail launches, parameter-space backward), 2 000 at B = 40 (grouped one-launch tail) and\n20 000 at B = 16 (the one-launch tail with its in-kernel all-reduces); reports the tail kernel's timeout counter.\n  python tests/dev_soak.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,7 +12,7 @@ for B in (128, 40, 16):          # 128: separate-launch tail, parameter-space ba
     host = bench.make_batches(4, B, 0)
     bt = [(torch.from_numpy(rg).to(dev), nrs, torch.from_numpy(kg).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(e).to(dev), torch.from_numpy(s).to(dev)) for rg, nrs, kg, y, e, s in host]
     losses = []
-    steps = 20000 if B == 16 else (2000 if B == 40 else 40)
+    steps = 20000 if B == 16 else (2000 if B == 40 else 1000)
     for i in range(steps):
         terms, pred = tr.step(*bt[i % 4])
         if i % 50 == 49:                       # a validation pass now and then: inference calls share the optimizer's weight shadows
