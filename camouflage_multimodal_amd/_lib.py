@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcamo_fusion.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 FWD_INFERENCE = 1
 FLAG_ATTN_MAPS = 2
 SUMSQ_FLOATS = 257
@@ -23,7 +23,7 @@ NPARAMS_CROSS, NPARAMS_LATE = 44, 22
 # every symbol include/camo_fusion.h declares
 SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_batch_desc_bytes", "camo_prepare_batch", "camo_gather_batch", "camo_forward", "camo_forward_cached", "camo_backward", "camo_forward_loss_backward",
            "camo_loss", "camo_grad_sumsq", "camo_clip_adamw", "camo_shadow_bytes", "camo_clip_adamw_shadows", "camo_debug_gemm", "camo_debug_gemm16", "camo_debug_ws_offset",
-           "camo_debug_set_option", "camo_debug_set_stamps", "camo_prof_begin", "camo_prof_end", "camo_prof_kind", "camo_tail_timeouts")
+           "camo_debug_set_option", "camo_debug_set_stamps", "camo_prof_begin", "camo_prof_end", "camo_prof_kind", "camo_tail_timeouts", "camo_tail_poison_to_grads")
 
 
 # every symbol include/camo_rg_gnn.h declares
@@ -100,6 +100,8 @@ def lib():
     L.camo_rg_node_embeddings.argtypes = [C.POINTER(CamoRgDims), vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, vp]
     L.camo_tail_timeouts.restype = C.c_int
     L.camo_tail_timeouts.argtypes = [vp]
+    L.camo_tail_poison_to_grads.restype = C.c_int
+    L.camo_tail_poison_to_grads.argtypes = [vp, vp]
     L.camo_rg_graph_workspace_bytes.restype = sz
     L.camo_rg_graph_workspace_bytes.argtypes = [i32]
     L.camo_rg_region_graph.restype = C.c_int

@@ -539,6 +539,17 @@ static int wide_rt(int T, int max_nr, bool save = false) {
   return rt;
 }
 
+// Training calls (save): the front half alone on wide blocks -- 64-row blocks from 10 240 packed rows (front 21 -> 17 us at B = 24,
+// 31 -> 26 at B = 48, 37 -> 28 at B = 56), 128-row blocks from 28 672.  -> sub-tiles per block, 0 = the 32-row front kernel.
+// ONE predicate for everything that rides on that launch (the two-plane tail's weight planes are built by its extra blocks).
+static int wide_train_front_rt(int T, int max_nr, bool save) {
+  if (!save || wide_rt(T, max_nr, save) || g_opt_fused_rt >= 0 || g_opt_wide_front_rt < 0) return 0;
+  if (T < 10240 && g_opt_wide_front_rt <= 0) return 0;
+  const int wf_rt = g_opt_wide_front_rt > 0 ? g_opt_wide_front_rt : (T >= 4 * 32 * 224 ? 4 : 2);
+  if (wf_rt != 1 && wf_rt != 2 && wf_rt != 4) return 0;
+  return max_nr <= wide_max_rows(wf_rt) - 64 * wf_rt ? wf_rt : 0;
+}
+
 static bool tailw_taken(const camo_dims_t& d, int B, int T, int max_nr, bool save) {
   // (B <= 32: the grouped fp32 tail, forward only, is the shorter one: 29.8 vs 33.5 us at B = 32; equal at 48)
   return g_opt_tailw != 0 && g_opt_fused_one != 0 && wide_rt(T, max_nr, save) >= 2 && tail_wide_ok(B, d.num_classes) &&
@@ -591,7 +602,8 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
       zero(w.dHm1, (size_t)B * 2 * H * sizeof(float)); zero(w.dHm2, (size_t)B * 2 * H * sizeof(float));   // atomically summed by the one-launch tail
     } else {
       zero(w.zero_base, (size_t)(reinterpret_cast<char*>(w.dKV) - reinterpret_cast<char*>(w.zero_base)));
-      zero(w.tailsum, ((size_t)B * 4 * H + ((tail_counter_words(B) + 3) & ~size_t(3)) + (size_t)2 * (3 * H * d.rg_dim + 3 * H) + 8) * sizeof(float));
+      // (the one-launch tail's all-reduce buffers and counter words; the parameter-space block behind them belongs to the backward)
+      zero(w.tailsum, ((size_t)B * 4 * H + ((tail_counter_words(B) + 3) & ~size_t(3))) * sizeof(float));
     }
     if (build) {
       CK(launch_weight_shadows(sb, st), "weight shadows");
@@ -624,11 +636,9 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   t_nzero_front = 0;
   const int rt = wide_rt(T, max_nr, save);
   const bool one = rt >= 2 && g_opt_fused_one != 0;
-  // training calls: the front half alone on wide blocks -- 64-row blocks from 10 240 packed rows (front 21 -> 17 us at B = 24, 31 -> 26 at
-  // B = 48, 37 -> 28 at B = 56), 128-row blocks from 28 672
-  const int wf_rt = g_opt_wide_front_rt > 0 ? g_opt_wide_front_rt : (T >= 4 * 32 * 224 ? 4 : 2);
-  const bool wide_train_front = !rt && g_opt_fused_rt < 0 && g_opt_wide_front_rt >= 0 && save && (T >= 10240 || g_opt_wide_front_rt > 0) &&
-                                max_nr <= wide_max_rows(wf_rt) - 64 * wf_rt;
+  const int wf_rt = wide_train_front_rt(T, max_nr, save);
+  const bool wide_train_front = wf_rt != 0;
+  if (want_tailw && !(one || wide_train_front)) return fail(CAMO_E_ARG, "two-plane tail asked for on a call whose front launch cannot build its weight planes");
   if ((one || wide_train_front) && want_tailw) {
     // the per-sample tail's weights as hi / lo bf16 planes in fragment order: extra blocks of the (KG rows') wide front launch
     const size_t HH = (size_t)H * H;
@@ -991,8 +1001,9 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
     // training calls on the wide front half with more than 64 samples: the tail's FORWARD as the one two-plane launch (with fp32
     // copies of what the backward launches read) instead of four fp32 GEMM launches (B = 256: 4 x 27 us -> 34 us); the loss launch
     // and the backward launches follow as before
-    const bool tailw_train = !tailw && fl && !fl17 && save17 && B > 64 && g_opt_tailw != 0 && g_opt_fused_rt < 0 && T >= 4 * 32 * 224 &&
-                             max_nr <= wide_max_rows(4) - 256 && tail_wide_ok(B, d.num_classes) && heads_loss_ok(B, d.num_classes);
+    // (its weight planes are built by extra blocks of the wide front launch: the same predicate as forward_nodes17's)
+    const bool tailw_train = !tailw && fl && !fl17 && save17 && B > 64 && g_opt_tailw != 0 && T >= 4 * 32 * 224 && wide_train_front_rt(T, max_nr, save17) != 0 &&
+                             tail_wide_ok(B, d.num_classes) && heads_loss_ok(B, d.num_classes);
     if (int e = forward_nodes17(d, P, rg, rg_offsets, bd, kg, B, T, Nk, max_nr, w, drop, save17, st, tailw_train ? 2 : (tailw ? 1 : 0))) return e;
     t_tailw_bwd_planes = tailw_train;        // (the backward half of this training call may take the two-plane launch too)
     if (tailw || tailw_train) {
@@ -1449,6 +1460,12 @@ int camo_tail_timeouts(uint32_t* count) {
   CK(tail_timeouts(&n), "tail timeouts");
   *count = n;
   return 0;
+}
+
+int camo_tail_poison_to_grads(float* flat_grads, void* stream) {
+  if (!flat_grads) return fail(CAMO_E_ARG, "camo_tail_poison_to_grads: null gradient buffer");
+  const int e = launch_tail_poison_to_grads(flat_grads, static_cast<hipStream_t>(stream));
+  return e ? fail_hip(e, "camo_tail_poison_to_grads") : 0;
 }
 
 int camo_prof_kind(int32_t kind, double* ms, int32_t* launches, double* flops) {

@@ -77,6 +77,7 @@ extern int g_tail_debug_skip;
 int tail_fused_ok(int B, int C);
 int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream);
 int tail_timeouts(unsigned int* out);
+int launch_tail_poison_to_grads(float* g, hipStream_t stream);      // data parallel: a pending tail timeout -> NaN in g[0] (misc.hip)
 
 // ---- AdamW that also emits the bf16 weight shadows of the fused row-tile schedule (fused_rows.h), so that the next training
 // step needs no shadow launch.  A "row block" is a run of rows of one parameter matrix; it feeds one plain shadow (rows pn0.. of a

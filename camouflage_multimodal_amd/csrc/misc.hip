@@ -1558,6 +1558,19 @@ int tail_timeouts(unsigned int* out) {          // synchronous (hipMemcpyFromSym
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_timeouts), sizeof(unsigned int));
 }
 
+// Data parallel: a rank whose tail gave up must take every OTHER rank's step down with it -- its garbage gradients are about to be
+// summed into all of them.  One thread: if the poison flag is up, the first element of the flat gradient buffer becomes NaN; the
+// SUM all-reduce carries it to every rank, every rank's norm launch then sees a NaN norm and every optimizer skips the same step.
+// (The flag stays up: this rank's own norm launch consumes it as before.)  Enqueued by the trainer between the training call and the
+// all-reduce of the bucket that holds element 0.
+__global__ void tail_poison_to_grads_kernel(float* __restrict__ g) {
+  if (__hip_atomic_load(&g_tail_poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) g[0] = __uint_as_float(0x7FC00000u);
+}
+int launch_tail_poison_to_grads(float* g, hipStream_t stream) {
+  hipLaunchKernelGGL(tail_poison_to_grads_kernel, dim3(1), dim3(1), 0, stream, g);
+  return (int)hipGetLastError();
+}
+
 int launch_sumsq(const float* g, size_t n, float* out, hipStream_t stream) {
   const int prof = gemm_prof_open(stream, 0.0, PROF_OPT);
   hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, g, n, out);

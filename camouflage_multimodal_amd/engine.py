@@ -210,6 +210,7 @@ class FusionEngine:
         self._same_device(rg_packed, "rg_embeddings")
         self._same_device(kg, "kg_embeddings")
         dev_offs = getattr(nrs, "offsets_dev", None)            # DeviceResidentDataset.batch: the offsets already exist on the device
+        nrs_obj = nrs if dev_offs is not None else None         # (its descriptor is kept ON the object: a prebuilt validation batch is reused every epoch)
         nrs = [int(n) for n in nrs]
         B = len(nrs)
         if B < 1 or min(nrs) < 1:
@@ -223,7 +224,9 @@ class FusionEngine:
         if kg.dtype is not torch.float32 or kg.requires_grad or not kg.is_contiguous():
             kg = kg.detach().to(torch.float32).contiguous()
         key = None if dev_offs is not None else tuple(nrs)
-        desc = self._offsets_cache.get(key) if key is not None else None
+        desc = self._offsets_cache.get(key) if key is not None else getattr(nrs_obj, "_desc", None)
+        if desc is not None and (desc[0].device != rg_packed.device or (nrs_obj is not None and desc[0] is not dev_offs)):
+            desc = None
         if desc is None:
             # batch descriptor (row offsets + the library's opaque row/tile maps): ONE launch.  Repeated shape tuples (a fixed
             # validation set, a benchmark's minibatches) are cached; a training epoch's minibatches each have their own tuple
@@ -254,6 +257,11 @@ class FusionEngine:
                 if len(self._offsets_cache) > 1024:
                     self._offsets_cache.clear()
                 self._offsets_cache[key] = desc
+            elif nrs_obj is not None:
+                try:
+                    nrs_obj._desc = desc
+                except AttributeError:
+                    pass
         return Batch(rg_packed, kg, desc[0], desc[1], nrs)
 
     def workspace(self, batch, private=False):

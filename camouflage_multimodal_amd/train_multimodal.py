@@ -208,6 +208,12 @@ class NativeTrainer:
             outs, _ = eng.forward_raw(batch, ws, training, seed)
             terms, d_pre, pred = multitask_loss(outs, mask_label, edge_label, score_label, self.num_classes, pre_activation=True)
             eng.backward_raw(batch, ws, outs, d_pre, training, seed, eng._gtab, pre_activation=True)
+        if ar is not None and getattr(ar, "world", 1) > 1 and g.is_cuda:
+            # a tail timeout on THIS rank must skip the step on EVERY rank (its gradients are about to be summed into all of them):
+            # NaN into g[0] if one is pending; the SUM carries it, every rank's norm turns NaN, every optimizer skips (include/camo_fusion.h)
+            with torch.cuda.device(g.device):
+                _lib.check(_lib.lib().camo_tail_poison_to_grads(g.data_ptr(), torch.cuda.current_stream(g.device).cuda_stream),
+                           "camo_tail_poison_to_grads")
         self.opt.step(allreduce=(lambda g: ar(g, split=split)) if ev else ar, zero_grads=not self.keep_grads, shadows=self.reuse_shadows)
         self._grads_clean = not self.keep_grads
         return terms, pred
@@ -296,7 +302,14 @@ def fit(config, train_loader, val_loader, device="cuda", grad_allreduce=None, lo
         loader = train_loader(epoch) if callable(train_loader) else train_loader
         tl, tf1 = train_epoch_fixed(model, loader, trainer, device, epoch + 1)
         vl, vf1, a0, a1 = validate_fixed(model, val_loader, device)
-        if _lib.tail_timeouts(device) != timeouts0:
+        timed_out = int(_lib.tail_timeouts(device) != timeouts0)
+        if world > 1:
+            # every rank must reach the same decision (a rank that raises alone leaves the others blocked in the next collective)
+            import torch.distributed as dist
+            flag = torch.tensor([timed_out], dtype=torch.int32, device=device if dist.get_backend(getattr(grad_allreduce, "group", None)) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=getattr(grad_allreduce, "group", None))
+            timed_out = int(flag.item())
+        if timed_out:
             raise _lib.CamoError("the one-launch tail kernel timed out waiting for its own blocks (GPU shared with another process?): "
                                  "this epoch's results are invalid")
         trainer.opt.set_epoch(epoch + 1)                     # scheduler.step() [:439]: a checkpoint carries the NEXT epoch's lr
@@ -341,7 +354,9 @@ def train_multimodal_fixed(config, device="cuda", seed=0, grad_allreduce=None, w
     weights = dataset.get_aggressive_sample_weights()
     train_w = [weights[i] for i in train_idx]
     samples = dataset.training_samples()
-    train_ds = DeviceResidentDataset([samples[i] for i in train_idx], device, augment=True, seed=seed)
+    # (the augmentation's coins and noise are keyed by (seed, call, position in the minibatch, element): fold the rank in, as
+    # FusionEngine.fold_rank does for dropout, or every rank would add the same noise tensor to its own samples)
+    train_ds = DeviceResidentDataset([samples[i] for i in train_idx], device, augment=True, seed=seed * world + rank)
     val_ds = DeviceResidentDataset([samples[i] for i in val_idx], device)
     bs = int(config["batch_size"])
 

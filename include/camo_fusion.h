@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CAMO_ABI_VERSION 8
+#define CAMO_ABI_VERSION 9
 
 enum {
   CAMO_OK = 0,
@@ -286,6 +286,14 @@ int camo_prof_kind(int32_t kind, double* ms, int32_t* launches, double* flops);
  * GPU was shared with another process that kept the launch's blocks from being co-resident).  SYNCHRONOUS (reads a device
  * counter): call it between epochs, not inside a step.  train_multimodal.fit does, and raises. */
 int camo_tail_timeouts(uint32_t* count);
+
+/* Data-parallel companion of the rule above (no reference counterpart; the reference is single-process).  A rank whose tail gave
+ * up holds garbage gradients that the SUM all-reduce (ddp.py; SURVEY 8e "sum, then clip", train_multimodal.py:238-279) would add
+ * into every rank's buffer, and only that rank's norm would turn NaN.  Enqueue this on the launch stream between
+ * camo_forward_loss_backward and the all-reduce of the piece that holds element 0 of the flat gradient buffer: if a timeout is
+ * pending on this device, flat_grads[0] becomes NaN, the SUM carries it to every rank, every rank's camo_grad_sumsq yields a NaN
+ * norm and every rank's optimizer call skips the same step -- replicas stay bit-identical.  One thread, enqueue-only. */
+int camo_tail_poison_to_grads(float* flat_grads, void* stream);
 
 #ifdef __cplusplus
 }

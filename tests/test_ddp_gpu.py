@@ -71,6 +71,32 @@ def _worker(rank, world, port, q, precision, reducer="single"):
         dist.destroy_process_group()
 
 
+def _poison_worker(rank, world, port, q, reducer):
+    """Three steps in bf16 mode (one-launch tail); on rank 1 the tail of step 1 times out (developer hook).  Reports the
+    parameters after step 0, after step 1 and after step 2, and step 1's gradient norm."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from camouflage_multimodal_amd import NativeTrainer, _lib
+        from camouflage_multimodal_amd.ddp import BucketedGradAllReducer, GradAllReducer, broadcast_parameters, shard_by_rows
+        torch.cuda.set_device(0)
+        m = _build("bf16")
+        broadcast_parameters(m._engine)
+        tr = NativeTrainer(m, grad_allreduce=BucketedGradAllReducer() if reducer == "bucketed" else GradAllReducer())
+        mine = shard_by_rows(NRS, world, rank)
+        snaps, norms = [], []
+        for step in range(3):
+            if step == 1 and rank == 1:
+                _lib.check(_lib.lib().camo_debug_set_option(b"tail_skip_arrival", 6), "hook")
+            _step(tr, mine, step)
+            torch.cuda.synchronize()
+            snaps.append(m._engine.flat_params.cpu().numpy().copy()); norms.append(float(tr.opt.grad_norm().item()))
+        q.put((rank, snaps, norms, _lib.tail_timeouts()))
+    finally:
+        dist.destroy_process_group()
+
+
 def _collect(q, procs, limit=300.0):
     """One result per child; a child that dies (or the time limit) fails the test at once instead of blocking on the queue."""
     import queue, time
@@ -102,6 +128,21 @@ def test_two_rank_product_path_equals_single_process():
         procs = [ctx.Process(target=_worker, args=(r, 2, port, q, precision, reducer)) for r in range(2)]
         for p in procs: p.start()
         results[(precision, reducer)] = _collect(q, procs)
+    poison = {}
+    for reducer in ("single", "bucketed"):               # (a tail timeout on ONE rank under data parallelism)
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_poison_worker, args=(r, 2, port, q, reducer)) for r in range(2)]
+        for p in procs: p.start()
+        poison[reducer] = _collect(q, procs)
+    for reducer, ((_, s0, n0, t0), (_, s1, n1, t1)) in poison.items():
+        # rank 1's tail gave up in step 1: BOTH ranks must skip that step (its garbage gradients were summed into both buffers)
+        assert t1 > 0 and t0 == 0, (reducer, t0, t1)
+        assert not np.isfinite(n0[1]) and not np.isfinite(n1[1]), (reducer, n0, n1)
+        for k in range(3):
+            assert np.array_equal(s0[k], s1[k]), f"{reducer}: replicas differ after step {k}"
+        assert np.array_equal(s0[1], s0[0]), f"{reducer}: the poisoned step was applied"
+        assert not np.array_equal(s0[2], s0[1]) and np.isfinite(s0[2]).all() and np.isfinite(n0[2]), f"{reducer}: the step after it must be a normal one"
     from camouflage_multimodal_amd import NativeTrainer
     want, norm = {}, {}
     for precision in ("f32", "bf16"):                    # single process, global batch = the reference with batch_size = 8

@@ -290,7 +290,7 @@ def test_fused_training_step_shape_envelope(nrs, nk, pseed, fused_opts):
     against the train step of the oracle in its bf16-operand mode with the same dropout masks, at FIXED bounds: global relative
     gradient error < 0.2 %, every tensor that carries weight < 1 % (measured: 0.002-0.02 % and <= 0.2 %).  Tiny samples weigh single rows heavily, and with parameter
     seed 6 the six-sample case has head units whose pre-activation sits within bf16 noise of zero in three samples: against
-    the reference-exact f32 oracle one such ReLU flip moves instance_head.0.bias by 18 % (tests/dev_relu_flip.py); the bf16-operand
+    the reference-exact f32 oracle one such ReLU flip moves instance_head.0.bias by 18 % (tools/dev/dev_relu_flip.py); the bf16-operand
     oracle rounds what the kernels round and lands on the same side.  The f32 oracle still bounds the logits (north_star: 1e-3)."""
     cfg = OP.full_cfg()
     m = make_model(cfg, pseed, "bf16").train()
@@ -309,7 +309,7 @@ def test_fused_training_step_shape_envelope(nrs, nk, pseed, fused_opts):
     torch.cuda.synchronize()
     grads = {k: t2n(p.grad).copy() for k, p in m.named_parameters()}
     assert np.isfinite(t2n(outs)).all() and all(np.isfinite(v).all() for v in grads.values())
-    # (tail units whose pre-activation is within 2e-4 of the ReLU threshold may land on either side: helpers.py)
+    # (tail units whose pre-activation is within 5e-5 of the ReLU threshold may land on either side: helpers.py bounds how many)
     ref, near, flipped = oracle_step_at_relu_thresholds(
         lambda: FO.FusionOracle(cfg, OP.make_params(cfg, pseed), bf16_operands=True),
         lambda o: FO.train_step(o, FO.AdamW(o.p), rgl, kg, y, e, s, training=True, seed=dseed), grads)

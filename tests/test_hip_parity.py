@@ -268,31 +268,39 @@ def test_bf16_mode_within_north_star_tolerance(kg_real):
 
 
 def test_bf16_training_step_close_to_oracle():
+    """The golden 'default' minibatch (dropout 0, Nr = 303 / 481 / 500 / 530) through NativeTrainer in bf16 mode against the train
+    step of the oracle in its bf16-operand mode, at the absolute bounds of every other bf16 training test: global relative gradient
+    error < 2e-3, every tensor that carries weight < 1e-2 (round 1 asserted 5 % / 15 % here against the f32 oracle)."""
     from camouflage_multimodal_amd import NativeTrainer
+    from helpers import oracle_step_at_relu_thresholds
     cfg, seed, nrs, nk, kg_fixed, _ = train_case("default")
     m = make_model(cfg, seed, "bf16").train()
     tr = NativeTrainer(m, keep_grads=True)
-    orc = FO.FusionOracle(cfg, OP.make_params(cfg, seed))
     rg, kg, y, e, s = train_batch(cfg, seed, nrs, nk, kg_fixed, 0)
-    ref = FO.train_step(orc, FO.AdamW(orc.p), rg, kg, y, e, s, training=True)
     terms, _ = tr.step(torch.from_numpy(np.concatenate(rg)).cuda(), list(nrs), torch.from_numpy(kg).cuda(),
                        torch.from_numpy(y), torch.from_numpy(e), torch.from_numpy(s))
-    assert_close(t2n(terms), ref["loss_terms"], 2e-3, 2e-3, "bf16 loss terms")
-    assert_close(t2n(tr.opt.grad_norm())[0], ref["grad_norm"], 0, 2e-2, "bf16 grad norm")
-    coef = min(1.0, 1.0 / (float(ref["grad_norm"]) + 1e-6))
+    gnorm = float(t2n(tr.opt.grad_norm())[0])
+    coef = min(1.0, 1.0 / (gnorm + 1e-6))
     tr.engine.ensure_flat_grads(attach=True)
+    grads = {k: t2n(p.grad).astype(np.float32) / np.float32(coef) for k, p in m.named_parameters()}
+    ref, near, flipped = oracle_step_at_relu_thresholds(
+        lambda: FO.FusionOracle(cfg, OP.make_params(cfg, seed), bf16_operands=True),
+        lambda o: FO.train_step(o, FO.AdamW(o.p), rg, kg, y, e, s, training=True), grads)
+    assert_close(t2n(terms), ref["loss_terms"], 5e-4, 5e-4, "bf16 loss terms")
+    assert_close(gnorm, ref["grad_norm"], 0, 5e-3, "bf16 grad norm")
     num = den = 0.0
     rels = []
-    for k, p in m.named_parameters():
-        want = ref["raw_grads"][k].astype(np.float64); got = t2n(p.grad).astype(np.float64) / coef
+    for k in grads:
+        want = ref["raw_grads"][k].astype(np.float64); got = grads[k].astype(np.float64)
         num += ((got - want) ** 2).sum(); den += (want ** 2).sum()
         rels.append((np.sqrt(((got - want) ** 2).sum()) / max(np.sqrt((want ** 2).sum()), 1e-30), np.sqrt((want ** 2).sum()), k))
     total = np.sqrt(num / den)
     rels.sort(reverse=True)
-    print("bf16 global relative gradient error =", total, "; worst tensors:", [(f"{r:.3f}", f"{n:.2e}", k) for r, n, k in rels[:4]])
-    assert total < 5e-2
+    print("bf16 global relative gradient error vs the bf16-operand oracle =", total, "; worst tensors:", [(f"{r:.4f}", f"{n:.2e}", k) for r, n, k in rels[:4]],
+          "; near the ReLU threshold:", near, "flipped:", flipped)
+    assert total < 2e-3
     gn = np.sqrt(den)
-    assert all(r < 0.15 for r, n, _ in rels if n > 1e-3 * gn)
+    assert all(r < 1e-2 for r, n, _ in rels if n > 1e-3 * gn), rels[:4]
 
 
 def test_product_path_loaded_native_library():

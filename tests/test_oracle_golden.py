@@ -202,3 +202,36 @@ def test_torch_port_matches_numpy_oracle_and_golden_step():
     for k, v in orc.p.items():
         err = np.abs(tp.P[k].detach().numpy() - v)
         assert err.max() <= 2.2 * 5e-4 and (err <= 3e-6 + 1e-5 * np.abs(v)).mean() > 0.99, k
+
+
+def test_per_sample_batch_step_equals_train_step_and_flips_by_replacement():
+    """tests/helpers.py::oracle_batch_step (the large-batch yardstick of tests/test_hip_large_batch.py: one sample at a time, a ReLU
+    decision tried flipped by replacing that sample's gradient contribution) against FO.train_step on a small case, with and
+    without a forced flip: samples are independent, so both routes must give the same sums."""
+    from helpers import oracle_batch_step
+    cfg = OP.full_cfg()
+    nrs = [40, 7, 65]
+    rg = [OP.make_rg(n, 128, seed=30 + i) for i, n in enumerate(nrs)]
+    kg = np.stack([OP.make_kg(13, 128, seed=40 + i) for i in range(3)])
+    y, e, s = OP.make_labels(3, seed=2)
+    mk = lambda: FO.FusionOracle(cfg, OP.make_params(cfg, 3), bf16_operands=True)
+    o = mk()
+    ref = FO.train_step(o, FO.AdamW(o.p), rg, kg, y, e, s, training=True, seed=77)
+    got = oracle_batch_step(mk, rg, kg, y, e, s, 77)
+    for k in ref["raw_grads"]:
+        assert np.array_equal(got["raw_grads"][k], ref["raw_grads"][k]), k
+    assert np.array_equal(got["loss_terms"], ref["loss_terms"])
+    for k in ("mask", "instance", "edge", "score"):
+        assert np.array_equal(got["outs"][k], ref["outs"][k])
+    # a flipped unit: the whole-batch step with relu_flip set == the per-sample replacement route, when the flipped pattern is
+    # what the "kernel" computed.  A wide near_eps makes candidates; the target gradients are those of one chosen flip.
+    probe = mk(); probe.near = []; probe.near_eps = 5e-3
+    FO.train_step(probe, FO.AdamW(probe.p), rg, kg, y, e, s, training=True, seed=77)
+    assert probe.near, "no tail unit within 5e-3 of the threshold in this case: pick another seed"
+    site, b, u, _ = probe.near[0]
+    of = mk(); of.relu_flip = frozenset([(site, b, u)])
+    target = FO.train_step(of, FO.AdamW(of.p), rg, kg, y, e, s, training=True, seed=77)["raw_grads"]
+    fit = oracle_batch_step(mk, rg, kg, y, e, s, 77, got_grads=target, near_eps=5e-3, max_near=len(probe.near), max_flips=len(probe.near))
+    assert (site, b, u) in fit["flips"]
+    err = max(float(np.abs(fit["raw_grads"][k] - target[k]).max()) / max(float(np.abs(target[k]).max()), 1e-12) for k in target)
+    assert err < 1e-5, err
