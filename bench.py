@@ -390,7 +390,7 @@ def main():
             _lib.check(L.camo_prof_kind(2, C.byref(kms), C.byref(kn), C.byref(kfl)), "camo_prof_kind")
             rows_f = float(sum(nrf))
             alg = rows_f * FWD_MFLOP_PER_ROW * 1e6 + Bf * 13.0 * 2.0 * (256.0 * 256.0 + 256.0 * 512.0)      # RG rows + the KG rows' chain (same launch)
-            us = kms.value * 1e3 / max(kn.value, 1)
+            us = kms.value * 1e3 / kf                               # per CALL: the RG rows' launch + (64-row half-blocks) the KG rows' launch behind it
             del rgf, kgf
             # shader clock: one stamped call at B = 256 (the stamp buffer holds 2048 blocks per kernel)
             hb = make_batches(1, 256, rank, seed=100 + 256)
@@ -411,9 +411,9 @@ def main():
             model._engine._ws = None
             torch.cuda.empty_cache()
             extras["roofline_forward"] = {
-                "bound": "mfma", "kernel": "rgfwd kernel (the RG rows' whole forward + the KG rows' chain in one launch; csrc/fused_wide*.hip)", "batch": Bf, "rows": int(rows_f),
+                "bound": "mfma", "kernel": "rgfwd2_kernel + kgchain_kernel (csrc/fused_wide2.hip: the RG rows' whole forward on 64-row half-blocks, two per CU, and the KG rows' chain behind it; avg_launch_us = both launches of one call)", "batch": Bf, "rows": int(rows_f),
                 "launches_per_call": round(kn.value / kf, 2), "avg_launch_us": round(us, 2), "algorithmic_gflop_per_launch": round(alg / 1e9, 2),
-                "executed_gflop_per_launch": round(kfl.value / max(kn.value, 1) / 1e9, 2), "achieved": round(alg / (us * 1e-6) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                "executed_gflop_per_launch": round(kfl.value / kf / 1e9, 2), "achieved": round(alg / (us * 1e-6) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(alg / (us * 1e-6) / 1e12 / peak, 5), "achieved_executed": round(kfl.value / max(kms.value, 1e-9) / 1e9, 1),
                 "frac_executed": round(kfl.value / max(kms.value, 1e-9) / 1e9 / peak, 5), "shader_clock_mhz_observed": round(float(np.median(mhz)), 0),
                 "frac_at_observed_clock": round(alg / (us * 1e-6) / 1e12 / (peak * float(np.median(mhz)) / 2400.0), 5) if np.median(mhz) > 0 else None,

@@ -130,3 +130,8 @@ int launch_wide_front(FrontArgs& a, int rt, hipStream_t stream, int kg_only = 0)
 int launch_wide_rgfwd(const FrontStream& f, float qscale, BackArgs& b, int rt, int max_nr, hipStream_t stream);   // RG rows: front + back in one launch
 int launch_wide_back(BackArgs& a, int rt, int max_nr, hipStream_t stream);
 int wide_max_rows(int rt);
+
+// ---- second wide design (fused_wide2.hip): the RG rows' whole forward in one launch on 64-row half-blocks of 4 waves, two
+// independent blocks per CU; inference calls only (nothing saved, no dropout).  Same arguments as launch_wide_rgfwd.
+int launch_wide2_rgfwd(const FrontStream& f, float qscale, BackArgs& b, int max_nr, hipStream_t stream);
+int wide2_max_rows();

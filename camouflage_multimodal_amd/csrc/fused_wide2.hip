@@ -1,0 +1,770 @@
+// The RG rows' whole forward in ONE launch, second design (gfx950): 64-row half-blocks of 4 waves, two independent blocks per CU.
+// Contract and argument blocks: fused_rows.h (FrontStream, BackArgs: the same weight shadows, tile table, partial / ticket
+// protocol of the KG->RG attention and pooled-sum outputs as rgfwd_kernel of fused_wide.hip, which this replaces for inference
+// calls); the KG rows' projections (Q2_16, KV16) come from the front kernel's KG launch as before.
+//
+// Why a second design.  rgfwd_kernel<4> runs one block of 8 waves per CU on 128 rows: the two
+// waves of a SIMD execute the same program between the same barriers, so they reach their MFMA passes together and their
+// epilogues together -- matrix time and vector time ADD (25 % MFMA issue), and the vector work itself was 9 instructions per
+// MFMA (the MFMA gap hides 5-6).  Here
+//   * a block is 4 waves (one per SIMD) on 64 rows, 79 KB of LDS: TWO blocks per CU that share nothing, so the two waves of a
+//     SIMD belong to different blocks and drift through their phases independently -- one block's epilogue, barrier wait or
+//     input load runs under the other block's MFMAs;
+//   * a wave owns 2 feature tiles (= 2 attention heads) x 2 sub-tiles: a weight fragment feeds 2 MFMAs, an activation fragment
+//     feeds 2 MFMAs (one LDS read and one L2 load per 2 MFMAs);
+//   * the vector work per MFMA is cut by algebra, not by scheduling:
+//       - biases enter as the first MFMA's C operand (a per-register constant vector read from LDS), never as adds;
+//       - the KG->RG keys carry no bias at all (a constant per query cancels in its softmax) and the KG->RG values get theirs in
+//         the combine (softmax weights sum to 1: O2 = sum p (v + b) = sum p v + b);
+//       - invalid keys (Nk..15) are masked through the score MFMA's C operand (-1e30), not by selects;
+//       - both softmaxes run in exp2 with log2(e) / sqrt(32) folded into one fma per score (the queries are not pre-scaled);
+//       - LayerNorm statistics in one pass (sum and sum of squares: ONE cross-wave exchange instead of two);
+//       - ReLU + bias as max(acc, -b), the bias re-added once per column sum;
+//       - the mean pool of the LayerNorm output as MFMAs against an identity fragment (column sums fall out of the accumulator
+//         layout: 16 in-lane adds and one cross-half add per tile instead of a 5-step lane butterfly per value).
+//
+// Numerics relative to rgfwd_kernel (both within north_star's 1e-3 of the f32 oracle; tests/test_hip_wide2.py): queries are
+// rounded to bf16 unscaled; the pooled LayerNorm output is the sum of the bf16-rounded Y the FFN reads (fp32 accumulation).
+#include "fused_rows.h"
+#include "gemm.h"      // launch timing hooks
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ bf16x8 join(s16x4 lo, s16x4 hi) { return bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}; }
+__device__ __forceinline__ f32x16 splat16(float v) {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = v;
+  return z;
+}
+__device__ __forceinline__ float bf_lo(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t v) { return __uint_as_float(v & 0xFFFF0000u); }
+// accumulator register r of lane half h holds row (r & 3) + 8 (r >> 2) + 4 h of the 32x32 tile
+__device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ u32x4 pack8(const f32x16& a, int k) {
+  return u32x4{pack2(a[8 * k], a[8 * k + 1]), pack2(a[8 * k + 2], a[8 * k + 3]), pack2(a[8 * k + 4], a[8 * k + 5]), pack2(a[8 * k + 6], a[8 * k + 7])};
+}
+__device__ __forceinline__ void store16_wt(void* p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+// Developer timeline (testing hook "stamps"): lane 0 of every wave records the 100 MHz wall clock at phase boundaries:
+// stamps[(block * 8 + wave) * 16 + k] (the 8-wave kernels' layout: waves 4..7 of a block stay empty here).
+__device__ __forceinline__ void stamp(unsigned long long* stamps, int k) {
+  if (stamps && (threadIdx.x & 63) == 0) {
+    unsigned long long* p = stamps + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16;
+    p[k] = __builtin_amdgcn_s_memrealtime();
+    if (k == 0) p[11] = __builtin_amdgcn_s_memtime();
+    if (k == 12) p[15] = __builtin_amdgcn_s_memtime();
+    // (the block's XCD, in the first slot of the unused wave row 4: HW_REG_XCC_ID = hardware register 20, bits 3..0)
+    if (k == 0 && threadIdx.x == 0) stamps[((size_t)blockIdx.x * 8 + 4) * 16] = 1 + (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15);
+  }
+}
+
+constexpr int NW = 4;        // waves per block
+constexpr int NTH = 64 * NW;
+constexpr int RT = 2;        // 32-row sub-tiles per block
+constexpr int ROWS = 32 * RT;
+constexpr int PX = 272;      // row pitch (bytes) of a [rows][128] bf16 tile
+constexpr int PR = 528;      // ... of a [rows][256] bf16 tile (a ds_read_b128 lane group's 16 rows land on 16 distinct bank quads)
+// KG->RG partial of one (segment, head), this file's layout inside the workspace's partial buffer (sized for the other kernels'
+// FUSED_PART_FLOATS = 544 floats per slot): max[16] fp32 (log2 units) | sum[16] fp32 | Z[16 queries][32 features] BF16 -- the partials
+// are 150 KB per sample in fp32 and the KG rows' launch reads all of them at once (160 MB at B = 1024: its combine ran at the HBM
+// roof); Z is a sum of <= 64 products whose factors are bf16 already, and the attention output it ends in is rounded to bf16 too
+constexpr int PART_FLOATS = 16 + 16 + 16 * 32 / 2;
+static_assert(PART_FLOATS <= FUSED_PART_FLOATS, "fused_rows.h");
+constexpr float LOG2E = 1.4426950408889634f;
+// one-instruction transcendentals (v_exp_f32, v_rcp_f32, v_rsq_f32: 1 ulp): exp2f / division / 1 / sqrtf compile to range-fixing and
+// Newton sequences of 5-15 instructions each, which the bf16 operands downstream cannot see
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// ---- one linear layer: acc[s][t] = init[t] + sum over KS k steps of (weight fragment (ks, t)) x (activation fragment (s, ks)).
+// `wp` = this wave's first fragment + lane (16-byte units); fragment (ks, t) is wp[64 (ks KST + t)] (KST = tiles per k step and
+// wave in the shadow's 4-wave layout).  DEPTH weight fragments are kept in flight; the scheduling barriers pin {issue the load
+// DEPTH fragments ahead, (first tile of a k step: start the NEXT k step's activation reads), RS MFMAs} -- left alone, hipcc sinks
+// loads and LDS reads behind the MFMAs and every k step waits out a round trip (fused_wide.hip, StageW).
+template <int RS, int NT, int KS, int KST, int DEPTH>
+struct Stage {
+  static constexpr int TOTAL = NT * KS;
+  static constexpr int D = DEPTH < TOTAL ? DEPTH : TOTAL;
+  u32x4 buf[D];
+  const u32x4* wp;
+  __device__ __forceinline__ const u32x4* wptr(int i) const { return wp + 64 * ((i / NT) * KST + (i % NT)); }
+  __device__ __forceinline__ void prefetch(const u32x4* __restrict__ wp_) {
+    wp = wp_;
+#pragma unroll
+    for (int i = 0; i < D; ++i) buf[i] = *wptr(i);
+  }
+  // W_IS_A: the weights are the A operand (accumulator: lane = tile row, registers = features) -- else the B operand (lane = feature,
+  // registers = tile rows).  init[t]: the first k step's C operand (a bias vector, or zeros).
+  template <bool W_IS_A, class F>
+  __device__ __forceinline__ void run_f(F&& frag, const f32x16 (&init)[NT], f32x16 (&acc)[RS][NT]) {
+    bf16x8 x[RS], xn[RS];
+#pragma unroll
+    for (int s = 0; s < RS; ++s) xn[s] = frag(s, 0);
+#pragma unroll
+    for (int i = 0; i < TOTAL; ++i) {
+      const int ks = i / NT, t = i % NT;
+      const bf16x8 wf = as_frag(buf[i % D]);
+      if (i + D < TOTAL) buf[i % D] = *wptr(i + D);
+      if (t == 0) {
+#pragma unroll
+        for (int s = 0; s < RS; ++s) x[s] = xn[s];
+        if (ks + 1 < KS) {
+#pragma unroll
+          for (int s = 0; s < RS; ++s) xn[s] = frag(s, ks + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int s = 0; s < RS; ++s) {
+        const f32x16 c = ks == 0 ? init[t] : acc[s][t];
+        if constexpr (W_IS_A) acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, x[s], c, 0, 0, 0);
+        else                  acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[s], wf, c, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // activation tiles in LDS: `act` = address of this lane's first fragment of sub-tile 0 (row lane & 31, byte 16 (lane >> 5)),
+  // sub-tile s is `sub` bytes further, k step ks 32 bytes further
+  template <bool W_IS_A>
+  __device__ __forceinline__ void run(const char* act, int sub, const f32x16 (&init)[NT], f32x16 (&acc)[RS][NT]) {
+    run_f<W_IS_A>([&](int s, int ks) { return *reinterpret_cast<const bf16x8*>(act + s * sub + 32 * ks); }, init, acc);
+  }
+};
+
+// a per-register constant vector for the W_IS_A orientation: register i = c[acc_row(i, h)], c = 32 floats in LDS (four 16-byte reads)
+__device__ __forceinline__ f32x16 feature_vec(const float* c, int h) {
+  f32x16 v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(c + 8 * g + 4 * h);
+    v[4 * g] = q[0]; v[4 * g + 1] = q[1]; v[4 * g + 2] = q[2]; v[4 * g + 3] = q[3];
+  }
+  return v;
+}
+
+struct Sub { int b; int row0; int nr; float inv_n; };          // one 32-row sub-tile (wave-uniform)
+
+// LDS map (bytes).  The attention output lives in per-wave STRIPS [wave][rows][64 features of the wave's two heads] (pitch PS): a
+// wave writes only its own strip, whose space it used before as scratch (the KG partial's Z, the transposing value reads), so
+// nothing but the "attention output complete" barrier orders the waves there.  The input tile lives in the strips' space first.
+// Constants: every bias / LayerNorm vector of the RG stream, once (no key bias: it cancels in the KG->RG softmax).
+constexpr int PS = 144;      // row pitch (bytes) of a strip [rows][64]: 16 rows of a ds_read_b128 lane group land on 16 distinct 16-byte slots
+struct Cfg {
+  static constexpr int BUFR = 0, TILE = ROWS * PR;                 // R tile, then (in place) the LayerNorm output Y
+  static constexpr int BUFO = TILE, STRIP = ROWS * PS, STRIPS = NW * STRIP;
+  static constexpr int RED = BUFO + STRIPS, RED_BYTES = NW * ROWS * 8;   // LayerNorm partials {sum, sum of squares} per (wave, row)
+  static constexpr int CST = RED + RED_BYTES;
+  // floats: b0 [256] | bq [256] | bv2 [256] | bo [256] | ln_g [256] | ln_b [256] | b1 [512]
+  static constexpr int C_B0 = 0, C_BQ = 256, C_BV = 512, C_BO = 768, C_G = 1024, C_BT = 1280, C_B1 = 1536, C_FLOATS = 2048;
+  static constexpr int FLAG = CST + C_FLOATS * 4, LDS = FLAG + 64;
+  // the KG rows' launch: one 32-row attention tile [32][256] (pitch PR) in the strips' space
+  static_assert(ROWS * PX <= STRIPS && 4096 <= STRIP, "aliases of the strips' space");
+  static_assert(LDS <= 81920, "two blocks per CU");
+};
+
+// ---- out-projection + residual -> LayerNorm -> FFN layer 0 (+ReLU) -> pooled sums, for RS sub-tiles.  The attention output (bf16)
+// is read through `ofrag(s, ks)` (strips, or a plain [32][256] tile for the KG rows); the residual rows (bf16) sit in bufY, which
+// the LayerNorm output overwrites in place (each wave reads and writes only its own 64 columns).  Wave w owns features
+// 64 w .. + 63 of the 256-wide layers and 128 w .. + 127 of the FFN layer.  `cst`: bo | ln_g | ln_b | b1 at the offsets of Cfg.
+// PAIR (the KG rows' launch): RS = 1 and the tile holds TWO samples of sub[0].nr <= 16 rows each -- sample sub[0].b in rows 0 .., sample
+// sub[0].b + 1 (if `pair2`) in rows 16 .. -- pooled separately: accumulator registers 0..7 are rows 0..15, registers 8..15 rows 16..31.
+template <int RS, int DEPTH, bool PAIR, class OF>
+__device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS], OF&& ofrag, char* bufY, float* red, const float* cst,
+                                      int w, int lane, Stage<RS, 2, 16, 2, DEPTH>& sto, unsigned long long* stamps, bool pair2 = false) {
+  static_assert(!PAIR || RS == 1, "pair mode: one tile");
+  const int l31 = lane & 31, h = lane >> 5;
+  const bool same = RS == 2 && sub[RS - 1].nr > 0 && sub[RS - 1].b == sub[0].b;      // (wave-uniform) both sub-tiles of one sample: one atomic per column
+  // column sums of an accumulator tile in the lane = feature orientation (registers = rows), times 1 / n, into dst[sample][ld] + col
+  auto pooled = [&](const f32x16 (&p)[RS], float add_per_row, float* dst, int ld) {
+    if constexpr (PAIR) {
+      float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { c0 += acc_row(i, h) < sub[0].nr ? p[0][i] + add_per_row : 0.f; c1 += acc_row(i, h) < sub[0].nr ? p[0][8 + i] + add_per_row : 0.f; }
+      c0 = (c0 + __shfl_xor(c0, 32, 64)) * sub[0].inv_n; c1 = (c1 + __shfl_xor(c1, 32, 64)) * sub[0].inv_n;
+      if (h == 0) { atomicAdd(dst + (size_t)sub[0].b * ld, c0); if (pair2) atomicAdd(dst + (size_t)(sub[0].b + 1) * ld, c1); }
+    } else {
+      float cs[RS];
+#pragma unroll
+      for (int s = 0; s < RS; ++s) {
+        float c = 0.f;
+        if (sub[s].nr >= 32) {                                    // (wave-uniform) full sub-tiles -- the common case -- carry no row masks
+#pragma unroll
+          for (int i = 0; i < 16; ++i) c += p[s][i];
+          c = fmaf(16.f, add_per_row, c);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) c += acc_row(i, h) < sub[s].nr ? p[s][i] + add_per_row : 0.f;
+        }
+        cs[s] = (c + __shfl_xor(c, 32, 64)) * sub[s].inv_n;
+      }
+      if (same) {
+        if (h == 0) atomicAdd(dst + (size_t)sub[0].b * ld, cs[0] + cs[RS - 1]);
+      } else {
+#pragma unroll
+        for (int s = 0; s < RS; ++s)
+          if (h == 0 && sub[s].nr > 0) atomicAdd(dst + (size_t)sub[s].b * ld, cs[s]);
+      }
+    }
+  };
+  Stage<RS, 2, 16, 4, DEPTH> stf;
+  {
+    f32x16 acc[RS][2];
+    {
+      f32x16 init[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) init[t] = feature_vec(cst + Cfg::C_BO + 32 * (2 * w + t), h);
+      sto.template run_f<true>(ofrag, init, acc);
+    }
+    stamp(stamps, 9);
+    // u = out-projection + bias (C operand) + residual; one-pass statistics over this lane's 32 features, then the other lane half
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x2 rv = *reinterpret_cast<const u32x2*>(bufY + (32 * s + l31) * PR + 2 * (32 * (2 * w + t) + 8 * g + 4 * h));
+          const float a0 = acc[s][t][4 * g] + bf_lo(rv.x), a1 = acc[s][t][4 * g + 1] + bf_hi(rv.x);
+          const float a2 = acc[s][t][4 * g + 2] + bf_lo(rv.y), a3 = acc[s][t][4 * g + 3] + bf_hi(rv.y);
+          acc[s][t][4 * g] = a0; acc[s][t][4 * g + 1] = a1; acc[s][t][4 * g + 2] = a2; acc[s][t][4 * g + 3] = a3;
+          sm += (a0 + a1) + (a2 + a3);
+          sq = fmaf(a0, a0, sq); sq = fmaf(a1, a1, sq); sq = fmaf(a2, a2, sq); sq = fmaf(a3, a3, sq);
+        }
+      sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+      if (h == 0) *reinterpret_cast<float2*>(red + 2 * (w * ROWS + 32 * s + l31)) = make_float2(sm, sq);
+      __builtin_amdgcn_sched_barrier(0);                          // (one sub-tile's residual reads at a time: registers)
+    }
+    __syncthreads();
+    stf.prefetch(reinterpret_cast<const u32x4*>(S.W1) + (size_t)(w * (16 * 4)) * 64 + lane);      // (flows during the normalisation and the pooling products)
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+      float ts = 0.f, tq = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) {
+        const float2 p = *reinterpret_cast<const float2*>(red + 2 * (ww * ROWS + 32 * s + l31));
+        ts += p.x; tq += p.y;
+      }
+      const float mean = ts * (1.0f / 256.0f);
+      const float var = fmaxf(tq * (1.0f / 256.0f) - mean * mean, 0.f);
+      const float rstd = frsq(var + 1e-5f);
+      const float nmr = -mean * rstd;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = 32 * (2 * w + t) + 8 * g + 4 * h;
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(cst + Cfg::C_G + c0), bt = *reinterpret_cast<const f32x4*>(cst + Cfg::C_BT + c0);
+          const float y0 = fmaf(fmaf(acc[s][t][4 * g], rstd, nmr), gm[0], bt[0]), y1 = fmaf(fmaf(acc[s][t][4 * g + 1], rstd, nmr), gm[1], bt[1]);
+          const float y2 = fmaf(fmaf(acc[s][t][4 * g + 2], rstd, nmr), gm[2], bt[2]), y3 = fmaf(fmaf(acc[s][t][4 * g + 3], rstd, nmr), gm[3], bt[3]);
+          *reinterpret_cast<u32x2*>(bufY + (32 * s + l31) * PR + 2 * c0) = u32x2{pack2(y0, y1), pack2(y2, y3)};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __syncthreads();                                              // Y tile complete
+  stamp(stamps, 10);
+  // ---- mean pool of the LayerNorm output: column sums of the bf16 Y tile as MFMAs against an identity fragment.  Product
+  // Y_s [32 rows][32 features of tile (2w + t)] . I: lane = feature, registers = rows -> 16 in-lane adds + the other lane half.
+  {
+    // B operand I [k][col]: lane (col = l31, h) holds k = 8 h + j of k step kk: 1.0 where 16 kk + 8 h + j == col
+    u32x4 idf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int j = l31 - 16 * kk - 8 * h;                        // the element of this lane's fragment that is 1.0 (if 0 <= j < 8)
+      const uint32_t one_lo = 0x3F80u, one_hi = 0x3F800000u;
+      idf[kk] = u32x4{j == 0 ? one_lo : (j == 1 ? one_hi : 0u), j == 2 ? one_lo : (j == 3 ? one_hi : 0u),
+                      j == 4 ? one_lo : (j == 5 ? one_hi : 0u), j == 6 ? one_lo : (j == 7 ? one_hi : 0u)};
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 p[RS];
+#pragma unroll
+      for (int s = 0; s < RS; ++s) {
+        const char* yp = bufY + (32 * s + l31) * PR + 2 * (32 * (2 * w + t)) + 16 * h;
+        p[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(yp), as_frag(idf[0]), splat16(0.f), 0, 0, 0);
+        p[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(yp + 32), as_frag(idf[1]), p[s], 0, 0, 0);
+      }
+      pooled(p, 0.f, S.Ymean + 32 * (2 * w + t) + l31, 256);
+    }
+  }
+  // ---- FFN layer 0 + ReLU, pooled over the rows (lane = feature): two passes of 64 features per wave
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    f32x16 acc[RS][2];
+    {
+      f32x16 init[2] = {splat16(0.f), splat16(0.f)};
+      stf.template run<false>(bufY + l31 * PR + 16 * h, 32 * PR, init, acc);
+    }
+    if (p == 0) stf.prefetch(reinterpret_cast<const u32x4*>(S.W1) + (size_t)(w * (16 * 4) + 2) * 64 + lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int f = 128 * w + 64 * p + 32 * t + l31;
+      const float bias = cst[Cfg::C_B1 + f], nb = -bias;
+      // relu(a + b) = max(a, -b) + b: one max and one add per element, the bias re-added once per valid row
+      f32x16 r[RS];
+#pragma unroll
+      for (int s = 0; s < RS; ++s)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[s][i] = fmaxf(acc[s][t][i], nb);
+      pooled(r, bias, S.Hmean + f, 512);
+    }
+  }
+}
+
+// Combine the partials {max, sum, Z} of the KG->RG attention of the block's two samples into their attention outputs (bf16: sample 0
+// -> rows j < Nk of bufO, sample 1 -> rows 16 + j; the other rows stay zero) and add the values' bias (softmax weights sum to 1).
+// Segment k of a sample whose first tile is t0 sits at tile slot k == 0 ? t0 : (t0 / RT + k) RT.  One pass with online rescaling,
+// no tables, no barriers: a thread owns (head, query, 8 features) of both samples -- four independent items -- and keeps the loads
+// of four segments of all of them in flight (the partials come from HBM / the Infinity Cache: 150 KB per sample, written by the
+// previous launch on other XCDs -- what this costs is round trips and bytes, not arithmetic).
+__device__ __forceinline__ void kg_combine2(const BackArgs& a, const float* bv2, char* bufO, const int (&t0)[2], const int (&nseg)[2]) {
+  const int tid = threadIdx.x, Nk = a.Nk;
+  const int hdlo = tid >> 6, j = (tid >> 2) & 15, f8 = tid & 3;
+  const int jl = min(j, Nk - 1);                                  // (rows j >= Nk are not stored: those threads re-read row Nk - 1 and store nothing)
+  float M[4], L[4];
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) { M[it] = -INFINITY; L[it] = 0.f; acc[it][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[it][1] = acc[it][0]; }
+  const int nmax = max(nseg[0], nseg[1]);
+  for (int s0 = 0; s0 < nmax; s0 += 4) {
+    float mm[4][4], ll[4][4];
+    u32x4 zz[4][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                              // item = (sample it >> 1, head 4 (it & 1) + hdlo)
+      const int smp = it >> 1, hd = 4 * (it & 1) + hdlo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sg = max(0, min(s0 + k, nseg[smp] - 1));
+        const float* p = a.part + ((size_t)(sg == 0 ? t0[smp] : (t0[smp] / RT + sg) * RT) * 8 + hd) * PART_FLOATS;
+        mm[it][k] = p[jl]; ll[it][k] = p[16 + jl];
+        zz[it][k] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const us16*>(p + 32) + jl * 32 + 8 * f8);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int smp = it >> 1;
+      float Mn = M[it];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) Mn = s0 + k < nseg[smp] ? fmaxf(Mn, mm[it][k]) : Mn;
+      const float r = fexp2(M[it] - Mn);                          // (maxima are kept in log2 units; first chunk: exp2(-inf) = 0)
+      L[it] *= r; acc[it][0] *= r; acc[it][1] *= r;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (s0 + k < nseg[smp]) {
+          const float e = fexp2(mm[it][k] - Mn);
+          L[it] = fmaf(ll[it][k], e, L[it]);
+          const u32x4 z = zz[it][k];
+          acc[it][0] += f32x4{bf_lo(z[0]), bf_hi(z[0]), bf_lo(z[1]), bf_hi(z[1])} * e;
+          acc[it][1] += f32x4{bf_lo(z[2]), bf_hi(z[2]), bf_lo(z[3]), bf_hi(z[3])} * e;
+        }
+      M[it] = Mn;
+    }
+  }
+  if (j < Nk) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int smp = it >> 1, hd = 4 * (it & 1) + hdlo;
+      if (nseg[smp] <= 0) continue;                               // (block-uniform: no second sample)
+      const float il = 1.0f / L[it];
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bv2 + 32 * hd + 8 * f8), b1 = *reinterpret_cast<const f32x4*>(bv2 + 32 * hd + 8 * f8 + 4);
+      *reinterpret_cast<u32x4*>(bufO + (16 * smp + j) * PR + 2 * (32 * hd + 8 * f8)) =
+          u32x4{pack2(fmaf(acc[it][0][0], il, b0[0]), fmaf(acc[it][0][1], il, b0[1])), pack2(fmaf(acc[it][0][2], il, b0[2]), fmaf(acc[it][0][3], il, b0[3])),
+                pack2(fmaf(acc[it][1][0], il, b1[0]), fmaf(acc[it][1][1], il, b1[1])), pack2(fmaf(acc[it][1][2], il, b1[2]), fmaf(acc[it][1][3], il, b1[3]))};
+    }
+  }
+}
+
+// ---- the KG rows' launch (behind the RG rows'): per block TWO samples -- their 2 x Nk <= 32 KG rows are one 32-row tile -- combine each
+// sample's KG->RG partials into its attention output, then out-projection + residual -> LayerNorm -> FFN layer 0 -> pooled sums.
+// Why its own launch and not the RG block that completes a sample (fused_wide.hip does that, and so did this file's first build): the
+// extra 19 us made one RG block in eight 65 % longer than the rest, and the dispatcher deals blocks to XCDs / shader engines in a fixed
+// rotation -- with unequal blocks a fifth of the CU slots sat empty behind the long ones (measured: 400 of 512 slots busy at B = 1024;
+// before the units were spread evenly over the XCDs, one XCD drew 854 of 987 chains and ran 230 us behind the other seven).  With
+// every RG block alike the slots stay full, the partials need no write-through stores, no tickets and no acquire, and the KG rows of
+// two samples share one weight stream.
+struct KgChainArgs { BackArgs b; const float* bv2; };
+
+template <int DEPTH>
+__global__ __launch_bounds__(NTH, 2) void kgchain_kernel(const KgChainArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const BackArgs& a = g.b;
+  const BackStream& K = a.s[1];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5, Nk = a.Nk;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* kbufY = smem + Cfg::BUFR; char* kbufO = smem + Cfg::BUFO;
+  float* red = reinterpret_cast<float*>(smem + Cfg::RED);
+  float* cst = reinterpret_cast<float*>(smem + Cfg::CST);
+  const int b0 = 2 * (int)blockIdx.x;
+  const bool pair2 = b0 + 1 < a.B;                                  // (block-uniform)
+  stamp(a.stamps, 0);
+  const int ta0 = a.tile_off[b0], ta1 = a.tile_off[b0 + 1], tb1 = pair2 ? a.tile_off[b0 + 2] : ta1;
+  Stage<1, 2, 16, 2, DEPTH> stk;
+  stk.prefetch(reinterpret_cast<const u32x4*>(K.Wo) + (size_t)(w * (16 * 2)) * 64 + lane);
+  // constants: the KG->RG values' bias (added by the combine) | bo | ln_g | ln_b | b1 of the KG stream
+  for (int i = tid; i < 384; i += NTH) {
+    const float* src = i < 64 ? g.bv2 + 4 * i : (i < 128 ? K.bo + 4 * (i - 64) : (i < 192 ? K.ln_g + 4 * (i - 128) : (i < 256 ? K.ln_b + 4 * (i - 192) : K.b1 + 4 * (i - 256))));
+    *reinterpret_cast<float4*>(cst + (i < 64 ? Cfg::C_BV : Cfg::C_BO - 256) + 4 * i) = *reinterpret_cast<const float4*>(src);
+  }
+  // attention tile cleared (rows past Nk of either sample stay zero); residual rows G: sample b0 -> rows 0 .., sample b0 + 1 -> rows 16 ..
+  for (int c = tid; c < 32 * PR / 16; c += NTH) reinterpret_cast<u32x4*>(kbufO)[c] = u32x4{0u, 0u, 0u, 0u};
+  for (int c = tid; c < 32 * 32; c += NTH) {
+    const int r = c >> 5, k = c & 31, smp = r >> 4, j = r & 15;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (j < Nk && (smp == 0 || pair2)) v = *reinterpret_cast<const u32x4*>(K.R16 + ((size_t)(b0 + smp) * Nk + j) * 256 + 8 * k);
+    *reinterpret_cast<u32x4*>(kbufY + r * PR + 16 * k) = v;
+  }
+  __syncthreads();
+  {
+    const int t0[2] = {ta0, ta1};
+    const int ns[2] = {(ta1 - 1) / RT - ta0 / RT + 1, pair2 ? (tb1 - 1) / RT - ta1 / RT + 1 : 0};
+    kg_combine2(a, cst + Cfg::C_BV, kbufO, t0, ns);
+  }
+  __syncthreads();
+  stamp(a.stamps, 13);
+  const Sub ksub[1] = {Sub{b0, b0 * Nk, Nk, 1.0f / (float)Nk}};
+  chain<1, DEPTH, true>(K, ksub, [&](int, int ks) { return *reinterpret_cast<const bf16x8*>(kbufO + l31 * PR + 32 * ks + 16 * h); },
+                        kbufY, red, cst, w, lane, stk, nullptr, pair2);
+  stamp(a.stamps, 12);
+}
+
+struct RgFwd2Args { FrontStream f; BackArgs b; float qscale; };
+
+template <int DEPTH>
+__global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const FrontStream& F = g.f;
+  const BackArgs& a = g.b;
+  const BackStream& S = a.s[0];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5, Nk = a.Nk;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* bufR = smem + Cfg::BUFR; char* strips = smem + Cfg::BUFO; char* bufX = strips;
+  char* strip = strips + w * Cfg::STRIP;                          // this wave's strip; before the attention output: its scratch
+  float* red = reinterpret_cast<float*>(smem + Cfg::RED);
+  float* cst = reinterpret_cast<float*>(smem + Cfg::CST);
+  const int g0 = (int)blockIdx.x * RT;
+  Sub sub[RT];
+#pragma unroll
+  for (int s = 0; s < RT; ++s) {
+    int4 td = make_int4(-1, 0, 0, 0);
+    if (g0 + s < a.rg_tiles_max) td = a.tile_desc[g0 + s];
+    const int tb = __builtin_amdgcn_readfirstlane(td.x);
+    sub[s].b = tb < 0 ? 0 : tb; sub[s].row0 = tb < 0 ? 0 : __builtin_amdgcn_readfirstlane(td.y); sub[s].nr = tb < 0 ? 0 : __builtin_amdgcn_readfirstlane(td.z);
+    sub[s].inv_n = tb < 0 ? 0.f : __int_as_float(__builtin_amdgcn_readfirstlane(td.w));
+  }
+  if (sub[0].nr == 0) return;                                     // (tiles are dense from 0: the whole group is past the end)
+  stamp(a.stamps, 0);
+  const bool same = sub[1].nr > 0 && sub[1].b == sub[0].b;        // (wave-uniform) both sub-tiles belong to one sample
+  Stage<RT, 2, 8, 2, DEPTH> st0;
+  st0.prefetch(reinterpret_cast<const u32x4*>(F.W0) + (size_t)(w * (8 * 2)) * 64 + lane);
+  // ---- input rows: fp32 -> bf16 tile (rows past a sub-tile's end cleared)
+  {
+    constexpr int XIT = ROWS * 8 / NTH;
+    float4 xv[XIT][4];
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int idx = tid + NTH * it, r = idx >> 3, c = idx & 7;
+      const int srow = r < 32 ? sub[0].row0 : sub[1].row0, snr = r < 32 ? sub[0].nr : sub[1].nr;
+      const float4* src = reinterpret_cast<const float4*>(F.X + ((size_t)srow + max(0, min(r & 31, snr - 1))) * 128 + 16 * c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xv[it][q] = src[q];
+    }
+    // every bias / LayerNorm vector of the RG stream -> LDS, once: 512 float4 (bkv: the values' half only)
+#pragma unroll
+    for (int i = tid; i < Cfg::C_FLOATS / 4; i += NTH) {
+      const float* src = i < 64 ? F.b0 + 4 * i : (i < 128 ? F.bq + 4 * (i - 64) : (i < 192 ? F.bkv + 256 + 4 * (i - 128) : (i < 256 ? S.bo + 4 * (i - 192) :
+                         (i < 320 ? S.ln_g + 4 * (i - 256) : (i < 384 ? S.ln_b + 4 * (i - 320) : S.b1 + 4 * (i - 384))))));
+      *reinterpret_cast<float4*>(cst + 4 * i) = *reinterpret_cast<const float4*>(src);
+    }
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int idx = tid + NTH * it, r = idx >> 3, c = idx & 7;
+      const int snr = r < 32 ? sub[0].nr : sub[1].nr;
+      const bool ok = (r & 31) < snr;
+      const float4 v0 = xv[it][0], v1 = xv[it][1], v2 = xv[it][2], v3 = xv[it][3];
+      u32x4 p0 = u32x4{pack2(v0.x, v0.y), pack2(v0.z, v0.w), pack2(v1.x, v1.y), pack2(v1.z, v1.w)};
+      u32x4 p1 = u32x4{pack2(v2.x, v2.y), pack2(v2.z, v2.w), pack2(v3.x, v3.y), pack2(v3.z, v3.w)};
+      if (!ok) { p0 = u32x4{0u, 0u, 0u, 0u}; p1 = p0; }
+      *reinterpret_cast<u32x4*>(bufX + r * PX + 32 * c) = p0;
+      *reinterpret_cast<u32x4*>(bufX + r * PX + 32 * c + 16) = p1;
+    }
+  }
+  __syncthreads();
+  stamp(a.stamps, 1);
+  // ---- projection 128 -> 256: wave w owns features 64 w .. + 63 of the R tile
+  Stage<RT, 2, 16, 6, DEPTH> st1;
+  auto w1pair = [&](int tg) { return reinterpret_cast<const u32x4*>(F.W1) + (size_t)((tg / 6) * (16 * 6) + tg % 6) * 64 + lane; };   // tiles tg, tg + 1 (tg even)
+  {
+    f32x16 acc[RT][2];
+    {
+      f32x16 init[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) init[t] = feature_vec(cst + Cfg::C_B0 + 32 * (2 * w + t), h);
+      st0.template run<true>(bufX + l31 * PX + 16 * h, 32 * PX, init, acc);
+    }
+    st1.prefetch(w1pair(8 + 2 * w));
+#pragma unroll
+    for (int s = 0; s < RT; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<u32x2*>(bufR + (32 * s + l31) * PR + 2 * (32 * (2 * w + t) + 8 * gq + 4 * h)) =
+              u32x2{pack2(acc[s][t][4 * gq], acc[s][t][4 * gq + 1]), pack2(acc[s][t][4 * gq + 2], acc[s][t][4 * gq + 3])};
+  }
+  __syncthreads();                                                // R tile complete; every wave is done with the input tile
+  stamp(a.stamps, 2);
+  const float sc2 = LOG2E * g.qscale;                             // RG->KG scores -> log2 units (the RG queries are NOT pre-scaled here)
+  // ---- passes k2, v2 (heads 2w, 2w + 1): the KG->RG partial of this block's rows
+  {
+    u32x4 ef[RT][2][2];
+    float Lsub[RT][2], mseg[RT][2];
+    {
+      // the samples' KG queries in accumulator k order (B operand: lane = query).  They arrive PRE-SCALED by 1 / sqrt(32) (the KG
+      // front launch): the scores below need log2(e) only.
+      u32x4 q2f[RT][2][2];
+#pragma unroll
+      for (int s = 0; s < RT; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const us16* q2p = a.Q2_16 + ((size_t)sub[s].b * Nk + min(l31, Nk - 1)) * 256 + 32 * (2 * w + t) + 4 * h;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(q2p + 16 * kk), hi = *reinterpret_cast<const u32x2*>(q2p + 16 * kk + 8);
+            q2f[s][t][kk] = u32x4{lo.x, lo.y, hi.x, hi.y};
+          }
+        }
+      f32x16 acc[RT][2];
+      {
+        f32x16 init[2] = {splat16(0.f), splat16(0.f)};            // (no key bias: a constant per query cancels in its softmax)
+        st1.template run<true>(bufR + l31 * PR + 16 * h, 32 * PR, init, acc);
+      }
+      st1.prefetch(w1pair(16 + 2 * w));
+      stamp(a.stamps, 3);
+      float mx[RT][2];
+      f32x16 S2[RT][2];
+#pragma unroll
+      for (int s = 0; s < RT; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const u32x4 k0 = pack8(acc[s][t], 0), k1 = pack8(acc[s][t], 1);
+          S2[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(k0), as_frag(q2f[s][t][0]), splat16(0.f), 0, 0, 0);   // [key row][query]: lane = query
+          S2[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(k1), as_frag(q2f[s][t][1]), S2[s][t], 0, 0, 0);
+        }
+#pragma unroll
+      for (int s = 0; s < RT; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          float m = -INFINITY;
+          if (sub[s].nr >= 32) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m = fmaxf(m, S2[s][t][i]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m = acc_row(i, h) < sub[s].nr ? fmaxf(m, S2[s][t][i]) : m;
+          }
+          mx[s][t] = fmaxf(m, __shfl_xor(m, 32, 64));
+        }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        mseg[0][t] = same ? fmaxf(mx[0][t], mx[1][t]) : mx[0][t];
+        mseg[1][t] = same ? mseg[0][t] : mx[1][t];
+      }
+#pragma unroll
+      for (int s = 0; s < RT; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float nm = -mseg[s][t] * LOG2E;
+          float e[16], L = 0.f;
+          if (sub[s].nr >= 32) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { e[i] = fexp2(fmaf(S2[s][t][i], LOG2E, nm)); L += e[i]; }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { e[i] = acc_row(i, h) < sub[s].nr ? fexp2(fmaf(S2[s][t][i], LOG2E, nm)) : 0.f; L += e[i]; }
+          }
+          Lsub[s][t] = L;
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            ef[s][t][k] = u32x4{pack2(e[8 * k], e[8 * k + 1]), pack2(e[8 * k + 2], e[8 * k + 3]), pack2(e[8 * k + 4], e[8 * k + 5]), pack2(e[8 * k + 6], e[8 * k + 7])};
+        }
+    }
+    f32x16 vacc[RT][2];
+    {
+      f32x16 init[2] = {splat16(0.f), splat16(0.f)};              // (the values' bias is added by the combine)
+      st1.template run<false>(bufR + l31 * PR + 16 * h, 32 * PR, init, vacc);      // same fragments, operands swapped: lane = feature
+    }
+    st1.prefetch(w1pair(2 * w));
+    stamp(a.stamps, 4);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 Z = splat16(0.f);
+      float L = 0.f;
+      int seg_first = g0;
+      us16* zt = reinterpret_cast<us16*>(strip + 1024 * t);          // [16 queries][32 features] bf16 (the strip is free until the attention output)
+#pragma unroll
+      for (int s = 0; s < RT; ++s) {
+        if (sub[s].nr <= 0) continue;                             // (wave-uniform)
+        L += Lsub[s][t];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ef[s][t][k]), as_frag(pack8(vacc[s][t], k)), Z, 0, 0, 0);      // Z[query][feature] += E^T . V2
+        const bool seg_end = s == RT - 1 || sub[s + 1].nr <= 0 || sub[s + 1].b != sub[s].b;      // (wave-uniform)
+        if (seg_end) {
+          L += __shfl_xor(L, 32, 64);
+          float* part = a.part + ((size_t)seg_first * 8 + (2 * w + t)) * PART_FLOATS;
+          if (lane < 16) { part[lane] = mseg[s][t] * LOG2E; part[16 + lane] = L; }      // (log2 units: the combine runs in exp2)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) zt[acc_row(i, h) * 32 + l31] = f2bf(Z[i]);
+          // (the wave's own LDS writes: program order) rows j < Nk leave as one 16-byte store per lane: lane -> row lane >> 2, chunk lane & 3
+          if ((lane >> 2) < Nk) *reinterpret_cast<u32x4*>(reinterpret_cast<us16*>(part + 32) + 8 * lane) = *reinterpret_cast<const u32x4*>(zt + 8 * lane);
+          if (s + 1 < RT) { Z = splat16(0.f); L = 0.f; seg_first = g0 + s + 1; }
+        }
+      }
+    }
+  }
+  // ---- pass q (lane = row) -> RG->KG attention straight from the accumulators -> the wave's strip
+  stamp(a.stamps, 5);
+  Stage<RT, 2, 16, 2, DEPTH> sto;
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+  {
+    // the samples' KG keys in accumulator k order (A operand: lane = key) and value rows [16][32 features of the head] (L2 hits by now)
+    u32x4 kf[RT][2][2], vkg[RT][2];
+#pragma unroll
+    for (int s = 0; s < RT; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int jk = l31 & 15;
+        const us16* kp = a.KV16 + ((size_t)sub[s].b * Nk + min(jk, Nk - 1)) * 512 + 32 * (2 * w + t) + 4 * h;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(kp + 16 * kk), hi = *reinterpret_cast<const u32x2*>(kp + 16 * kk + 8);
+          kf[s][t][kk] = jk < Nk ? u32x4{lo.x, lo.y, hi.x, hi.y} : u32x4{0u, 0u, 0u, 0u};
+        }
+        const int j = lane >> 2, c = lane & 3;
+        vkg[s][t] = u32x4{0u, 0u, 0u, 0u};
+        if (j < Nk) vkg[s][t] = *reinterpret_cast<const u32x4*>(a.KV16 + ((size_t)sub[s].b * Nk + j) * 512 + 256 + 32 * (2 * w + t) + 8 * c);
+      }
+    f32x16 acc[RT][2];
+    {
+      f32x16 init[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) init[t] = feature_vec(cst + Cfg::C_BQ + 32 * (2 * w + t), h);
+      st1.template run<true>(bufR + l31 * PR + 16 * h, 32 * PR, init, acc);
+    }
+    sto.prefetch(reinterpret_cast<const u32x4*>(S.Wo) + (size_t)(w * (16 * 2)) * 64 + lane);
+    stamp(a.stamps, 6);
+    // invalid keys (Nk .. 15) leave the softmax through the score product's C operand
+    f32x16 kmask;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kmask[i] = (i < 8 && acc_row(i, h) >= Nk) ? -1e30f : 0.f;
+#pragma unroll
+    for (int s = 0; s < RT; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const u32x4 q0 = pack8(acc[s][t], 0), q1 = pack8(acc[s][t], 1);
+        f32x16 Sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf[s][t][0]), as_frag(q0), kmask, 0, 0, 0);     // S^T[key][row]: lane = row
+        Sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf[s][t][1]), as_frag(q1), Sc, 0, 0, 0);
+        float m = fmaxf(fmaxf(fmaxf(Sc[0], Sc[1]), fmaxf(Sc[2], Sc[3])), fmaxf(fmaxf(Sc[4], Sc[5]), fmaxf(Sc[6], Sc[7])));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float nm = -m * sc2;
+        float e[8], sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { e[i] = fexp2(fmaf(Sc[i], sc2, nm)); sum += e[i]; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = frcp(sum);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] *= inv;
+        const bf16x8 pf = as_frag(u32x4{pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])});
+        char* vs = strip + 1024 * (2 * s + t);                    // 1 KB scratch for the transposing read: [16 keys][64 bytes], linear
+        *reinterpret_cast<u32x4*>(vs + 16 * lane) = vkg[s][t];
+        const char* vp = vs + (4 * h + q4) * 64 + 2 * (16 * g1 + 4 * p4);
+        const bf16x8 vf = join(lds_tr16(vp), lds_tr16(vp + 8 * 64));
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, splat16(0.f), 0, 0, 0);       // O^T[feature][row]
+      }
+    // (the wave's own scratch reads are done -- same wave, program order -- before its strip is written)
+#pragma unroll
+    for (int s = 0; s < RT; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<u32x2*>(strip + (32 * s + l31) * PS + 2 * (32 * t + 8 * gq + 4 * h)) =
+              u32x2{pack2(acc[s][t][4 * gq], acc[s][t][4 * gq + 1]), pack2(acc[s][t][4 * gq + 2], acc[s][t][4 * gq + 3])};
+  }
+  stamp(a.stamps, 7);
+  __syncthreads();                                                // strips complete
+  stamp(a.stamps, 8);
+  // attention output fragment of sub-tile s, k step ks (features 16 ks ..): strip ks >> 2, byte 32 (ks & 3) of the row
+  chain<RT, DEPTH, false>(S, sub, [&](int s, int ks) { return *reinterpret_cast<const bf16x8*>(strips + (ks >> 2) * Cfg::STRIP + (32 * s + l31) * PS + 32 * (ks & 3) + 16 * h); },
+                          bufR, red, cst, w, lane, sto, a.stamps);
+  stamp(a.stamps, 12);
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int DEPTH>
+void wide2_launch(const RgFwd2Args& g, dim3 grid, hipStream_t stream) {
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rgfwd2_kernel<DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kgchain_kernel<DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    return true;
+  }();
+  (void)attr;
+  hipLaunchKernelGGL((rgfwd2_kernel<DEPTH>), grid, dim3(NTH), Cfg::LDS, stream, g);
+}
+template <int DEPTH>
+void kgchain_launch(const KgChainArgs& k, hipStream_t stream) {
+  hipLaunchKernelGGL((kgchain_kernel<DEPTH>), dim3((k.b.B + 1) / 2), dim3(NTH), Cfg::LDS, stream, k);
+}
+
+}  // namespace
+
+int wide2_max_rows() { return 4096; }      // (the fused schedule's own limit: nothing here depends on a sample's length)
+
+// The RG rows' whole forward on 64-row half-blocks (inference calls: nothing is saved, no dropout) and, behind it, the KG rows'
+// launch (two samples per block).  `f` = the RG stream of the front half (X, shadows, biases), `b` = the back half's arguments.  The
+// KG rows' projections (b.Q2_16, b.KV16, b.s[1].R16) must already exist: launch_wide_front(..., kg_only = 1) first.
+int launch_wide2_rgfwd(const FrontStream& f, float qscale, BackArgs& b, int max_nr, hipStream_t stream) {
+  if (b.B < 1 || b.Nk < 1 || b.Nk > 16 || b.rg_tiles_max < 1 || !b.KV16 || !b.Q2_16 || !b.off || !b.tile_off || !b.tile_desc || !b.inv_nr || !b.part)
+    return (int)hipErrorInvalidValue;
+  if (b.save || b.drop.p > 0.f) return (int)hipErrorInvalidValue;
+  if (max_nr > wide2_max_rows()) return (int)hipErrorInvalidValue;
+  if (!f.X || !f.W0 || !f.W1 || !f.b0 || !f.bq || !f.bkv || !al16(f.X) || !al16(f.b0) || !al16(f.bq) || !al16(f.bkv) || !al16(f.W0) || !al16(f.W1)) return (int)hipErrorInvalidValue;
+  for (int i = 0; i < 2; ++i) {
+    const BackStream& S = b.s[i];
+    if (!S.Wo || !S.bo || !S.W1 || !S.b1 || !S.ln_g || !S.ln_b || !S.Ymean || !S.Hmean || (i == 1 && !S.R16)) return (int)hipErrorInvalidValue;
+    if (!al16(S.bo) || !al16(S.ln_g) || !al16(S.ln_b) || !al16(S.b1) || !al16(S.Wo) || !al16(S.W1) || (i == 1 && !al16(S.R16))) return (int)hipErrorInvalidValue;
+  }
+  RgFwd2Args g; g.f = f; g.b = b; g.qscale = qscale;
+  KgChainArgs k; k.b = b; k.bv2 = f.bkv + 256;
+  k.b.stamps = b.stamps ? b.stamps + (size_t)(b.rg_tiles_max + RT - 1) / RT * 8 * 16 : nullptr;      // (timeline: the KG blocks' rows follow the RG blocks')
+  // executed FLOPs per RG row: 128 -> 256, 256 -> 768, 256 -> 256, 256 -> 512 and both attention directions
+  const double rows = (double)b.rows_rg, kgrows = (double)b.B * b.Nk;
+  const dim3 grid((b.rg_tiles_max + RT - 1) / RT);
+  int prof = gemm_prof_open(stream, 2.0 * rows * (128.0 * 256.0 + 256.0 * 768.0 + 256.0 * 256.0 + 256.0 * 512.0) + 8.0 * rows * b.Nk * 256.0, PROF_BACK);
+  // weight fragments in flight per wave (b.exp: developer A/B of the prefetch depth; product calls pass 0)
+  if (b.exp == 8) wide2_launch<8>(g, grid, stream); else if (b.exp == 16) wide2_launch<16>(g, grid, stream); else wide2_launch<12>(g, grid, stream);
+  gemm_prof_close(prof, stream);
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  prof = gemm_prof_open(stream, 2.0 * kgrows * (256.0 * 256.0 + 256.0 * 512.0), PROF_BACK);
+  if (b.exp == 8) kgchain_launch<8>(k, stream); else if (b.exp == 16) kgchain_launch<16>(k, stream); else kgchain_launch<12>(k, stream);
+  gemm_prof_close(prof, stream);
+  return (int)hipGetLastError();
+}

@@ -43,6 +43,7 @@ int g_opt_param_space = -1;                   // -1 by size, 0 / 1: the fused ba
 int g_opt_tail17 = -1;                        // 0 = never take the one-launch tail (misc.hip, tail_fused_kernel)
 int g_opt_fused_variant = 1;                  // developer A/B of the fused kernels' weight streaming (fused_rows.h)
 int g_opt_fused_rt = -1;     // wide row tiles (fused_wide.hip): -1 = by batch size, 0 = never, 1 / 2 / 4 = that many 32-row tiles per block
+int g_opt_wide2 = -1;        // the RG rows' forward on 64-row half-blocks, two per CU (fused_wide2.hip): -1 = by size (inference calls), 0 = never, 1 = whenever the shape allows
 int g_opt_fused_one = 1;     // wide tiles: 1 = the RG rows' forward as ONE launch behind the KG rows' front half (rgfwd_kernel), 0 = front + back launches
 static thread_local bool t_tailw_bwd_planes = false;   // set by a training forward that built the tail's transposed planes (this call's workspace)
 int g_opt_wide_front_rt = 0;                  // developer A/B: > 0 forces the wide front half of training calls with that many sub-tiles per block, < 0 never
@@ -539,6 +540,14 @@ static int wide_rt(int T, int max_nr, bool save = false) {
   return rt;
 }
 
+// Inference calls: the RG rows' whole forward in one launch of 64-row half-blocks, two independent blocks per CU (fused_wide2.hip).
+// By size from 13 312 packed rows (where the 8-wave wide kernels start too); a forced fused_rt selects the 8-wave kernels.
+static bool wide2_taken(int T, int max_nr, bool save, bool dropping) {
+  if (save || dropping || g_opt_wide2 == 0 || g_opt_fused_one == 0 || max_nr > wide2_max_rows()) return false;
+  if (g_opt_wide2 > 0) return true;
+  return g_opt_fused_rt < 0 && T >= 13312;
+}
+
 // Training calls (save): the front half alone on wide blocks -- 64-row blocks from 10 240 packed rows (front 21 -> 17 us at B = 24,
 // 31 -> 26 at B = 48, 37 -> 28 at B = 56), 128-row blocks from 28 672.  -> sub-tiles per block, 0 = the 32-row front kernel.
 // ONE predicate for everything that rides on that launch (the two-plane tail's weight planes are built by its extra blocks).
@@ -550,9 +559,9 @@ static int wide_train_front_rt(int T, int max_nr, bool save) {
   return max_nr <= wide_max_rows(wf_rt) - 64 * wf_rt ? wf_rt : 0;
 }
 
-static bool tailw_taken(const camo_dims_t& d, int B, int T, int max_nr, bool save) {
+static bool tailw_taken(const camo_dims_t& d, int B, int T, int max_nr, bool save, bool dropping) {
   // (B <= 32: the grouped fp32 tail, forward only, is the shorter one: 29.8 vs 33.5 us at B = 32; equal at 48)
-  return g_opt_tailw != 0 && g_opt_fused_one != 0 && wide_rt(T, max_nr, save) >= 2 && tail_wide_ok(B, d.num_classes) &&
+  return g_opt_tailw != 0 && g_opt_fused_one != 0 && (wide_rt(T, max_nr, save) >= 2 || wide2_taken(T, max_nr, save, dropping)) && tail_wide_ok(B, d.num_classes) &&
          (g_opt_tailw > 0 || B > 32 || !tail_fused_ok(B, d.num_classes));
 }
 
@@ -634,8 +643,9 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   fa.nzero = t_nzero_front;
   for (int i = 0; i < t_nzero_front; ++i) { fa.zero_ptr[i] = t_zero_front_ptr[i]; fa.zero_bytes[i] = t_zero_front_bytes[i]; }
   t_nzero_front = 0;
-  const int rt = wide_rt(T, max_nr, save);
-  const bool one = rt >= 2 && g_opt_fused_one != 0;
+  const bool w2 = wide2_taken(T, max_nr, save, drop.p > 0.f);
+  const int rt = w2 ? 0 : wide_rt(T, max_nr, save);
+  const bool one = w2 || (rt >= 2 && g_opt_fused_one != 0);
   const int wf_rt = wide_train_front_rt(T, max_nr, save);
   const bool wide_train_front = wf_rt != 0;
   if (want_tailw && !(one || wide_train_front)) return fail(CAMO_E_ARG, "two-plane tail asked for on a call whose front launch cannot build its weight planes");
@@ -694,7 +704,8 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   ba.part = f.part; ba.tickets = w.tickets; ba.max_splits = (max_nr + 63) / 64;
   ba.drop = drop; ba.save = save ? 1 : 0; ba.exp = g_opt_exp;
   ba.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)g_dbg_stamp_blocks * 8 : nullptr;
-  if (one) CK(launch_wide_rgfwd(fa.s[0], fa.qscale, ba, rt, max_nr, st), "fused forward, RG rows in one launch (wide tiles)");
+  if (w2) CK(launch_wide2_rgfwd(fa.s[0], fa.qscale, ba, max_nr, st), "fused forward, RG rows in one launch (64-row half-blocks)");
+  else if (one) CK(launch_wide_rgfwd(fa.s[0], fa.qscale, ba, rt, max_nr, st), "fused forward, RG rows in one launch (wide tiles)");
   else if (rt) CK(launch_wide_back(ba, rt, max_nr, st), "fused forward, back half (wide tiles)");
   else CK(launch_fused_back(ba, g_opt_fused_variant, st), "fused forward, back half");
   return 0;
@@ -997,7 +1008,7 @@ static int forward_impl(const camo_dims_t* dims, const float* const* params, con
   if (!P[CAMO_P_KG_PROJ_W] && Dk != H) return fail(CAMO_E_ARG, "kg_proj weight missing but kg_dim != hidden_dim");
   const size_t HH2 = (size_t)H * H;
   if (use17) {
-    const bool tailw = (flags & CAMO_FWD_INFERENCE) && !fl && !fl17 && tailw_taken(d, B, T, max_nr, save17);
+    const bool tailw = (flags & CAMO_FWD_INFERENCE) && !fl && !fl17 && tailw_taken(d, B, T, max_nr, save17, drop.p > 0.f);
     // training calls on the wide front half with more than 64 samples: the tail's FORWARD as the one two-plane launch (with fp32
     // copies of what the backward launches read) instead of four fp32 GEMM launches (B = 256: 4 x 27 us -> 34 us); the loss launch
     // and the backward launches follow as before
@@ -1429,6 +1440,7 @@ int camo_debug_set_option(const char* name, int32_t value) {
   if (std::strcmp(name, "fused_rt") == 0) { g_opt_fused_rt = value; return 0; }
   if (std::strcmp(name, "exp") == 0) { g_opt_exp = value; return 0; }
   if (std::strcmp(name, "fused_one") == 0) { g_opt_fused_one = value; return 0; }
+  if (std::strcmp(name, "wide2") == 0) { g_opt_wide2 = value; return 0; }
   if (std::strcmp(name, "tailw") == 0) { g_opt_tailw = value; return 0; }
   if (std::strcmp(name, "tailw_bwd") == 0) { g_opt_tailw_bwd = value; return 0; }
   if (std::strcmp(name, "wide_front_rt") == 0) { g_opt_wide_front_rt = value; return 0; }
