@@ -133,5 +133,8 @@ int wide_max_rows(int rt);
 
 // ---- second wide design (fused_wide2.hip): the RG rows' whole forward in one launch on 64-row half-blocks of 4 waves, two
 // independent blocks per CU; inference calls only (nothing saved, no dropout).  Same arguments as launch_wide_rgfwd.
-int launch_wide2_rgfwd(const FrontStream& f, float qscale, BackArgs& b, int max_nr, hipStream_t stream);
+// Wf / bf: the folded in-projection [q | k2 | v2] = x Wf^T + bf (Wf = [Wq1; Wk2; Wv2] Wrg as a [768 x 128] shadow, bf [768] fp32), built by
+// launch_fold_rg whenever the parameters changed; f.W1 / f.bq / f.bkv (the unfolded in-projection) are not read.
+int launch_fold_rg(const float* Wq, const float* Wkv, const float* bq, const float* bkv, const float* Wrg, const float* brg, us16* Wf, float* bf, hipStream_t stream);
+int launch_wide2_rgfwd(const FrontStream& f, const us16* Wf, const float* bf, float qscale, BackArgs& b, int max_nr, hipStream_t stream);
 int wide2_max_rows();

@@ -166,13 +166,14 @@ constexpr int PS = 144;      // row pitch (bytes) of a strip [rows][64]: 16 rows
 struct Cfg {
   static constexpr int BUFR = 0, TILE = ROWS * PR;                 // R tile, then (in place) the LayerNorm output Y
   static constexpr int BUFO = TILE, STRIP = ROWS * PS, STRIPS = NW * STRIP;
+  static constexpr int XT = ROWS * PX, SCR = XT;                   // inside the strips' space until the attention output: input tile | per-wave scratch (4 KB each)
   static constexpr int RED = BUFO + STRIPS, RED_BYTES = NW * ROWS * 8;   // LayerNorm partials {sum, sum of squares} per (wave, row)
   static constexpr int CST = RED + RED_BYTES;
-  // floats: b0 [256] | bq [256] | bv2 [256] | bo [256] | ln_g [256] | ln_b [256] | b1 [512]
+  // floats: b0 [256] | bq' [256] | bv2' [256] (folded biases, launch_fold_rg) | bo [256] | ln_g [256] | ln_b [256] | b1 [512]
   static constexpr int C_B0 = 0, C_BQ = 256, C_BV = 512, C_BO = 768, C_G = 1024, C_BT = 1280, C_B1 = 1536, C_FLOATS = 2048;
   static constexpr int FLAG = CST + C_FLOATS * 4, LDS = FLAG + 64;
   // the KG rows' launch: one 32-row attention tile [32][256] (pitch PR) in the strips' space
-  static_assert(ROWS * PX <= STRIPS && 4096 <= STRIP, "aliases of the strips' space");
+  static_assert(XT + NW * 4096 <= STRIPS, "aliases of the strips' space");
   static_assert(LDS <= 81920, "two blocks per CU");
 };
 
@@ -443,7 +444,45 @@ __global__ __launch_bounds__(NTH, 2) void kgchain_kernel(const KgChainArgs g) {
   stamp(a.stamps, 12);
 }
 
-struct RgFwd2Args { FrontStream f; BackArgs b; float qscale; };
+// ---- the folded in-projection of the RG rows: [q | k2 | v2] = R Win^T + bin with R = x Wrg^T + brg  ==  x Wf^T + bf,
+//   Wf = Win Wrg  [768 x 128],   bf = Win brg + bin  [768],   Win = [Wq1; Wk2; Wv2] (fusion_model.py:108-117, 123-126).
+// One launch per parameter change (an inference loop keeps the result with its weight shadows): fp32 products, Wf leaves as the bf16
+// shadow in fragment order ([wave][k step][tile][lane][8], fused_rows.h), bf as fp32.  Thread = one 16-byte shadow chunk (8 k of one row).
+__global__ __launch_bounds__(256) void fold_rg_kernel(const float* __restrict__ Wq, const float* __restrict__ Wkv, const float* __restrict__ bq, const float* __restrict__ bkv,
+                                                      const float* __restrict__ Wrg, const float* __restrict__ brg, us16* __restrict__ Wf, float* __restrict__ bf) {
+  const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  constexpr int KS = 8, NTW = 6, CHUNKS = 768 * 128 / 8;
+  if (c < CHUNKS) {
+    const int lane = c & 63;
+    int r = c >> 6;
+    const int t = r % NTW; r /= NTW;
+    const int ks = r % KS, w = r / KS;
+    const int n = 32 * (w * NTW + t) + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+    const float* wrow = n < 256 ? Wq + (size_t)n * 256 : Wkv + (size_t)(n - 256) * 256;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int j = 0; j < 256; j += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(wrow + j);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 x0 = *reinterpret_cast<const float4*>(Wrg + (size_t)(j + q) * 128 + k0), x1 = *reinterpret_cast<const float4*>(Wrg + (size_t)(j + q) * 128 + k0 + 4);
+        acc[0] = fmaf(av[q], x0.x, acc[0]); acc[1] = fmaf(av[q], x0.y, acc[1]); acc[2] = fmaf(av[q], x0.z, acc[2]); acc[3] = fmaf(av[q], x0.w, acc[3]);
+        acc[4] = fmaf(av[q], x1.x, acc[4]); acc[5] = fmaf(av[q], x1.y, acc[5]); acc[6] = fmaf(av[q], x1.z, acc[6]); acc[7] = fmaf(av[q], x1.w, acc[7]);
+      }
+    }
+    reinterpret_cast<u32x4*>(Wf)[c] = u32x4{pack2(acc[0], acc[1]), pack2(acc[2], acc[3]), pack2(acc[4], acc[5]), pack2(acc[6], acc[7])};
+  } else if (c < CHUNKS + 768) {
+    const int n = c - CHUNKS;
+    const float* wrow = n < 256 ? Wq + (size_t)n * 256 : Wkv + (size_t)(n - 256) * 256;
+    float acc = n < 256 ? bq[n] : bkv[n - 256];
+    for (int j = 0; j < 256; ++j) acc = fmaf(wrow[j], brg[j], acc);
+    bf[n] = acc;
+  }
+}
+
+struct RgFwd2Args { FrontStream f; BackArgs b; float qscale; const us16* Wf; const float* bf; };      // Wf / bf: the folded in-projection (launch_fold_rg)
 
 template <int DEPTH>
 __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
@@ -454,7 +493,8 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5, Nk = a.Nk;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* bufR = smem + Cfg::BUFR; char* strips = smem + Cfg::BUFO; char* bufX = strips;
-  char* strip = strips + w * Cfg::STRIP;                          // this wave's strip; before the attention output: its scratch
+  char* strip = strips + w * Cfg::STRIP;                          // this wave's strip (the attention output)
+  char* scr = strips + Cfg::SCR + w * 4096;                       // this wave's scratch while the input tile still occupies the strips' space
   float* red = reinterpret_cast<float*>(smem + Cfg::RED);
   float* cst = reinterpret_cast<float*>(smem + Cfg::CST);
   const int g0 = (int)blockIdx.x * RT;
@@ -484,10 +524,10 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) xv[it][q] = src[q];
     }
-    // every bias / LayerNorm vector of the RG stream -> LDS, once: 512 float4 (bkv: the values' half only)
+    // every bias / LayerNorm vector of the RG stream -> LDS, once: 512 float4 (folded biases: the queries' and the values' thirds)
 #pragma unroll
     for (int i = tid; i < Cfg::C_FLOATS / 4; i += NTH) {
-      const float* src = i < 64 ? F.b0 + 4 * i : (i < 128 ? F.bq + 4 * (i - 64) : (i < 192 ? F.bkv + 256 + 4 * (i - 128) : (i < 256 ? S.bo + 4 * (i - 192) :
+      const float* src = i < 64 ? F.b0 + 4 * i : (i < 128 ? g.bf + 4 * (i - 64) : (i < 192 ? g.bf + 512 + 4 * (i - 128) : (i < 256 ? S.bo + 4 * (i - 192) :
                          (i < 320 ? S.ln_g + 4 * (i - 256) : (i < 384 ? S.ln_b + 4 * (i - 320) : S.b1 + 4 * (i - 384))))));
       *reinterpret_cast<float4*>(cst + 4 * i) = *reinterpret_cast<const float4*>(src);
     }
@@ -507,8 +547,10 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
   __syncthreads();
   stamp(a.stamps, 1);
   // ---- projection 128 -> 256: wave w owns features 64 w .. + 63 of the R tile
-  Stage<RT, 2, 16, 6, DEPTH> st1;
-  auto w1pair = [&](int tg) { return reinterpret_cast<const u32x4*>(F.W1) + (size_t)((tg / 6) * (16 * 6) + tg % 6) * 64 + lane; };   // tiles tg, tg + 1 (tg even)
+  // the in-projections read the INPUT tile: [q | k2 | v2] = x Wf^T + bf with Wf = [Wq; Wk2; Wv2] Wrg (768 x 128: half the k steps and
+  // half the weight bytes of the unfolded 256 -> 768 product; launch_fold_rg)
+  Stage<RT, 2, 8, 6, DEPTH> st1;
+  auto w1pair = [&](int tg) { return reinterpret_cast<const u32x4*>(g.Wf) + (size_t)((tg / 6) * (8 * 6) + tg % 6) * 64 + lane; };   // tiles tg, tg + 1 (tg even)
   {
     f32x16 acc[RT][2];
     {
@@ -527,7 +569,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
           *reinterpret_cast<u32x2*>(bufR + (32 * s + l31) * PR + 2 * (32 * (2 * w + t) + 8 * gq + 4 * h)) =
               u32x2{pack2(acc[s][t][4 * gq], acc[s][t][4 * gq + 1]), pack2(acc[s][t][4 * gq + 2], acc[s][t][4 * gq + 3])};
   }
-  __syncthreads();                                                // R tile complete; every wave is done with the input tile
+  __syncthreads();                                                // R tile complete
   stamp(a.stamps, 2);
   const float sc2 = LOG2E * g.qscale;                             // RG->KG scores -> log2 units (the RG queries are NOT pre-scaled here)
   // ---- passes k2, v2 (heads 2w, 2w + 1): the KG->RG partial of this block's rows
@@ -552,7 +594,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
       f32x16 acc[RT][2];
       {
         f32x16 init[2] = {splat16(0.f), splat16(0.f)};            // (no key bias: a constant per query cancels in its softmax)
-        st1.template run<true>(bufR + l31 * PR + 16 * h, 32 * PR, init, acc);
+        st1.template run<true>(bufX + l31 * PX + 16 * h, 32 * PX, init, acc);
       }
       st1.prefetch(w1pair(16 + 2 * w));
       stamp(a.stamps, 3);
@@ -607,7 +649,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
     f32x16 vacc[RT][2];
     {
       f32x16 init[2] = {splat16(0.f), splat16(0.f)};              // (the values' bias is added by the combine)
-      st1.template run<false>(bufR + l31 * PR + 16 * h, 32 * PR, init, vacc);      // same fragments, operands swapped: lane = feature
+      st1.template run<false>(bufX + l31 * PX + 16 * h, 32 * PX, init, vacc);      // same fragments, operands swapped: lane = feature
     }
     st1.prefetch(w1pair(2 * w));
     stamp(a.stamps, 4);
@@ -616,7 +658,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
       f32x16 Z = splat16(0.f);
       float L = 0.f;
       int seg_first = g0;
-      us16* zt = reinterpret_cast<us16*>(strip + 1024 * t);          // [16 queries][32 features] bf16 (the strip is free until the attention output)
+      us16* zt = reinterpret_cast<us16*>(scr + 1024 * t);            // [16 queries][32 features] bf16
 #pragma unroll
       for (int s = 0; s < RT; ++s) {
         if (sub[s].nr <= 0) continue;                             // (wave-uniform)
@@ -665,7 +707,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
       f32x16 init[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) init[t] = feature_vec(cst + Cfg::C_BQ + 32 * (2 * w + t), h);
-      st1.template run<true>(bufR + l31 * PR + 16 * h, 32 * PR, init, acc);
+      st1.template run<true>(bufX + l31 * PX + 16 * h, 32 * PX, init, acc);
     }
     sto.prefetch(reinterpret_cast<const u32x4*>(S.Wo) + (size_t)(w * (16 * 2)) * 64 + lane);
     stamp(a.stamps, 6);
@@ -691,13 +733,13 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) e[i] *= inv;
         const bf16x8 pf = as_frag(u32x4{pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])});
-        char* vs = strip + 1024 * (2 * s + t);                    // 1 KB scratch for the transposing read: [16 keys][64 bytes], linear
+        char* vs = scr + 1024 * (2 * s + t);                      // 1 KB scratch for the transposing read: [16 keys][64 bytes], linear
         *reinterpret_cast<u32x4*>(vs + 16 * lane) = vkg[s][t];
         const char* vp = vs + (4 * h + q4) * 64 + 2 * (16 * g1 + 4 * p4);
         const bf16x8 vf = join(lds_tr16(vp), lds_tr16(vp + 8 * 64));
         acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, splat16(0.f), 0, 0, 0);       // O^T[feature][row]
       }
-    // (the wave's own scratch reads are done -- same wave, program order -- before its strip is written)
+    __syncthreads();                                              // every wave is done with the input tile and with its scratch: the strips may be written
 #pragma unroll
     for (int s = 0; s < RT; ++s)
 #pragma unroll
@@ -740,24 +782,32 @@ int wide2_max_rows() { return 4096; }      // (the fused schedule's own limit: n
 // The RG rows' whole forward on 64-row half-blocks (inference calls: nothing is saved, no dropout) and, behind it, the KG rows'
 // launch (two samples per block).  `f` = the RG stream of the front half (X, shadows, biases), `b` = the back half's arguments.  The
 // KG rows' projections (b.Q2_16, b.KV16, b.s[1].R16) must already exist: launch_wide_front(..., kg_only = 1) first.
-int launch_wide2_rgfwd(const FrontStream& f, float qscale, BackArgs& b, int max_nr, hipStream_t stream) {
+// Wf / bf of the folded in-projection (see fold_rg_kernel): Wq [256 x 256], Wkv [512 x 256] = [Wk2; Wv2], their biases, the projection
+// Wrg [256 x 128] / brg -> Wf (bf16 shadow of [768 x 128], 196 608 bytes), bf [768].
+int launch_fold_rg(const float* Wq, const float* Wkv, const float* bq, const float* bkv, const float* Wrg, const float* brg, us16* Wf, float* bf, hipStream_t stream) {
+  if (!Wq || !Wkv || !bq || !bkv || !Wrg || !brg || !Wf || !bf || !al16(Wq) || !al16(Wkv) || !al16(Wrg) || !al16(Wf)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(fold_rg_kernel, dim3((768 * 128 / 8 + 768 + 255) / 256), dim3(256), 0, stream, Wq, Wkv, bq, bkv, Wrg, brg, Wf, bf);
+  return (int)hipGetLastError();
+}
+
+int launch_wide2_rgfwd(const FrontStream& f, const us16* Wf, const float* bf, float qscale, BackArgs& b, int max_nr, hipStream_t stream) {
   if (b.B < 1 || b.Nk < 1 || b.Nk > 16 || b.rg_tiles_max < 1 || !b.KV16 || !b.Q2_16 || !b.off || !b.tile_off || !b.tile_desc || !b.inv_nr || !b.part)
     return (int)hipErrorInvalidValue;
   if (b.save || b.drop.p > 0.f) return (int)hipErrorInvalidValue;
   if (max_nr > wide2_max_rows()) return (int)hipErrorInvalidValue;
-  if (!f.X || !f.W0 || !f.W1 || !f.b0 || !f.bq || !f.bkv || !al16(f.X) || !al16(f.b0) || !al16(f.bq) || !al16(f.bkv) || !al16(f.W0) || !al16(f.W1)) return (int)hipErrorInvalidValue;
+  if (!f.X || !f.W0 || !f.b0 || !Wf || !bf || !al16(f.X) || !al16(f.b0) || !al16(f.W0) || !al16(Wf) || !al16(bf)) return (int)hipErrorInvalidValue;
   for (int i = 0; i < 2; ++i) {
     const BackStream& S = b.s[i];
     if (!S.Wo || !S.bo || !S.W1 || !S.b1 || !S.ln_g || !S.ln_b || !S.Ymean || !S.Hmean || (i == 1 && !S.R16)) return (int)hipErrorInvalidValue;
     if (!al16(S.bo) || !al16(S.ln_g) || !al16(S.ln_b) || !al16(S.b1) || !al16(S.Wo) || !al16(S.W1) || (i == 1 && !al16(S.R16))) return (int)hipErrorInvalidValue;
   }
-  RgFwd2Args g; g.f = f; g.b = b; g.qscale = qscale;
-  KgChainArgs k; k.b = b; k.bv2 = f.bkv + 256;
+  RgFwd2Args g; g.f = f; g.b = b; g.qscale = qscale; g.Wf = Wf; g.bf = bf;
+  KgChainArgs k; k.b = b; k.bv2 = bf + 512;
   k.b.stamps = b.stamps ? b.stamps + (size_t)(b.rg_tiles_max + RT - 1) / RT * 8 * 16 : nullptr;      // (timeline: the KG blocks' rows follow the RG blocks')
-  // executed FLOPs per RG row: 128 -> 256, 256 -> 768, 256 -> 256, 256 -> 512 and both attention directions
+  // executed FLOPs per RG row: 128 -> 256, 128 -> 768 (folded), 256 -> 256, 256 -> 512 and both attention directions
   const double rows = (double)b.rows_rg, kgrows = (double)b.B * b.Nk;
   const dim3 grid((b.rg_tiles_max + RT - 1) / RT);
-  int prof = gemm_prof_open(stream, 2.0 * rows * (128.0 * 256.0 + 256.0 * 768.0 + 256.0 * 256.0 + 256.0 * 512.0) + 8.0 * rows * b.Nk * 256.0, PROF_BACK);
+  int prof = gemm_prof_open(stream, 2.0 * rows * (128.0 * 256.0 + 128.0 * 768.0 + 256.0 * 256.0 + 256.0 * 512.0) + 8.0 * rows * b.Nk * 256.0, PROF_BACK);
   // weight fragments in flight per wave (b.exp: developer A/B of the prefetch depth; product calls pass 0)
   if (b.exp == 8) wide2_launch<8>(g, grid, stream); else if (b.exp == 16) wide2_launch<16>(g, grid, stream); else wide2_launch<12>(g, grid, stream);
   gemm_prof_close(prof, stream);

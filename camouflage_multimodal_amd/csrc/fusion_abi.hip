@@ -115,6 +115,7 @@ struct Ws {
   // its launches / are saved for backward.  Only carved at the reference configuration (fused17_dims).
   struct F17 {
     us16 *Wrg, *Wkg, *Wqkv_rg, *Wqkv_kg, *Wo1, *Wo2, *W1, *W2;
+    us16* Wf_rg; float* bf_rg;          // the RG rows' folded in-projection (fused_wide2.hip, launch_fold_rg): shadow of [768 x 128], bias [768]
     us16 *X16, *KG16, *R16, *G16, *Q16, *Q2_16, *KV16, *KV2_16, *O16, *O2_16, *Y16, *Y2_16, *XH16, *XH2_16;
     float *rstd1, *rstd2, *lse2, *part; uint32_t *mask1, *mask2;
     // backward: transposed shadows, the bf16 gradients that are weight-gradient operands, per-sample exchange buffers
@@ -210,6 +211,7 @@ Ws carve(const camo_dims_t& d, int B, int T, int Nk, void* base) {
         f.dO2_16 = c.take<us>(TKp * H); f.delta2 = c.take<float>((size_t)B * 8 * 16); f.dGpart = c.take<float>(TKp * H);
         for (int i = 0; i < 10; ++i) f.tailw[i] = c.take<us>(i < 6 ? 2 * H * H : (i < 8 ? H * H : 2 * H * H));
         for (int i = 10; i < 20; ++i) f.tailw[i] = c.take<us>((i == 12 || i == 13) ? H * H : 2 * H * H);
+        f.Wf_rg = c.take<us>(3 * H * D); f.bf_rg = c.take<float>(3 * H);
       }
     }
   } else {
@@ -506,8 +508,9 @@ static thread_local void* t_zero_bwd1_ptr[FUSED_BWD1_MAXZ]; static thread_local 
 static thread_local int t_nzero_bwd1 = 0;
 static thread_local void* t_shadows = nullptr;
 static thread_local bool t_shadows_valid = false;
+static thread_local bool t_fold_missing = false;  // camo_forward_cached(shadows_valid = 2): valid shadows that lack the inference calls' folded in-projection
 static thread_local int t_shadows_state = 0;    // what the fused forward left in external shadows: 0 untouched, 1 forward set, 2 forward + transposed
-struct ShadowSet { us16 *Wrg, *Wkg, *Wqkv_rg, *Wqkv_kg, *Wo1, *Wo2, *W1, *W2, *W1T, *W2T, *Wo1T, *Wo2T, *WcRgT, *WcKgT; size_t bytes; };
+struct ShadowSet { us16 *Wrg, *Wkg, *Wqkv_rg, *Wqkv_kg, *Wo1, *Wo2, *W1, *W2, *W1T, *W2T, *Wo1T, *Wo2T, *WcRgT, *WcKgT, *Wf_rg; float* bf_rg; size_t bytes; };
 static ShadowSet shadow_carve(void* base) {
   ShadowSet x{};
   Carver c(base);
@@ -516,6 +519,7 @@ static ShadowSet shadow_carve(void* base) {
   x.Wo1 = c.take<us16>(HH); x.Wo2 = c.take<us16>(HH); x.W1 = c.take<us16>(2 * HH); x.W2 = c.take<us16>(2 * HH);
   x.W1T = c.take<us16>(2 * HH); x.W2T = c.take<us16>(2 * HH); x.Wo1T = c.take<us16>(HH); x.Wo2T = c.take<us16>(HH);
   x.WcRgT = c.take<us16>(3 * HH); x.WcKgT = c.take<us16>(3 * HH);
+  x.Wf_rg = c.take<us16>(3 * H * D); x.bf_rg = c.take<float>(3 * H);      // (inference calls only: launch_fold_rg)
   x.bytes = (c.off + 255) & ~size_t(255);
   return x;
 }
@@ -525,6 +529,7 @@ static void bind_shadows(Ws& w) {                 // (after every carve() of a c
   Ws::F17& f = w.f;
   f.Wrg = x.Wrg; f.Wkg = x.Wkg; f.Wqkv_rg = x.Wqkv_rg; f.Wqkv_kg = x.Wqkv_kg; f.Wo1 = x.Wo1; f.Wo2 = x.Wo2; f.W1 = x.W1; f.W2 = x.W2;
   f.W1T = x.W1T; f.W2T = x.W2T; f.Wo1T = x.Wo1T; f.Wo2T = x.Wo2T; f.WcRgT = x.WcRgT; f.WcKgT = x.WcKgT;
+  f.Wf_rg = x.Wf_rg; f.bf_rg = x.bf_rg;
 }
 
 // Which tile family a fused forward takes (fused_rows.h): 0 = 32-row tiles, one per block of 4 waves (small batches: one tile
@@ -614,10 +619,17 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
       // (the one-launch tail's all-reduce buffers and counter words; the parameter-space block behind them belongs to the backward)
       zero(w.tailsum, ((size_t)B * 4 * H + ((tail_counter_words(B) + 3) & ~size_t(3))) * sizeof(float));
     }
+    // inference calls: the RG rows' folded in-projection rides with every rebuild of the forward set, and alone when the caller's valid
+    // shadows come from the optimizer call, which does not build it (camo_forward_cached, shadows_valid = 2)
+    const bool fold = !save && (build || t_fold_missing);
     if (build) {
       CK(launch_weight_shadows(sb, st), "weight shadows");
+      if (fold) CK(launch_fold_rg(P[CAMO_P_A1_IN_W], P[CAMO_P_A2_IN_W] + HH, P[CAMO_P_A1_IN_B], P[CAMO_P_A2_IN_B] + H, P[CAMO_P_RG_PROJ_W], P[CAMO_P_RG_PROJ_B],
+                                   f.Wf_rg, f.bf_rg, st), "folded in-projection");
       t_nzero_front = t_nzero_bwd1 = 0;
     } else {
+      if (fold) CK(launch_fold_rg(P[CAMO_P_A1_IN_W], P[CAMO_P_A2_IN_W] + HH, P[CAMO_P_A1_IN_B], P[CAMO_P_A2_IN_B] + H, P[CAMO_P_RG_PROJ_W], P[CAMO_P_RG_PROJ_B],
+                                  f.Wf_rg, f.bf_rg, st), "folded in-projection");
       // no shadow launch this step: the clears ride elsewhere -- the atomics block and d(mean H) at the end of the front
       // kernel's blocks (first use: the back kernel's pooled sums), the operand pad rows in extra blocks of the first backward
       // kernel (first use: the weight-gradient launch)
@@ -704,7 +716,7 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   ba.part = f.part; ba.tickets = w.tickets; ba.max_splits = (max_nr + 63) / 64;
   ba.drop = drop; ba.save = save ? 1 : 0; ba.exp = g_opt_exp;
   ba.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)g_dbg_stamp_blocks * 8 : nullptr;
-  if (w2) CK(launch_wide2_rgfwd(fa.s[0], fa.qscale, ba, max_nr, st), "fused forward, RG rows in one launch (64-row half-blocks)");
+  if (w2) CK(launch_wide2_rgfwd(fa.s[0], f.Wf_rg, f.bf_rg, fa.qscale, ba, max_nr, st), "fused forward, RG rows in one launch (64-row half-blocks)");
   else if (one) CK(launch_wide_rgfwd(fa.s[0], fa.qscale, ba, rt, max_nr, st), "fused forward, RG rows in one launch (wide tiles)");
   else if (rt) CK(launch_wide_back(ba, rt, max_nr, st), "fused forward, back half (wide tiles)");
   else CK(launch_fused_back(ba, g_opt_fused_variant, st), "fused forward, back half");
@@ -1103,10 +1115,10 @@ int camo_forward_cached(const camo_dims_t* dims, const float* const* params, con
   if (shadows && !(flags & CAMO_FWD_INFERENCE))
     return fail(CAMO_E_UNSUPPORTED, "camo_forward_cached with a shadow buffer serves inference calls only (flags must contain CAMO_FWD_INFERENCE)");
   if (shadows && (reinterpret_cast<uintptr_t>(shadows) & 255)) return fail(CAMO_E_ARG, "the shadow buffer must be 256-byte aligned");
-  t_shadows = shadows; t_shadows_valid = shadows && shadows_valid != 0; t_shadows_state = 0;
+  t_shadows = shadows; t_shadows_valid = shadows && shadows_valid != 0; t_fold_missing = shadows && shadows_valid == 2; t_shadows_state = 0;
   const int rc = forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
                               attn_rg2kg, attn_kg2rg, training, seed, precision, flags, stream, nullptr);
-  t_shadows = nullptr; t_shadows_valid = false;
+  t_shadows = nullptr; t_shadows_valid = false; t_fold_missing = false;
   if (rc == 0 && shadows_state) *shadows_state = t_shadows_state;
   return rc;
 }

@@ -99,6 +99,7 @@ class FusionEngine:
         self._shadows = None          # persistent bf16 weight shadows of the fused schedule (camo_shadow_bytes)
         self._shadows_version = None  # param_version() right after the call that left them current (optimizer step or forward)
         self._shadows_full = False    # they include the transposed set the backward needs (an inference call builds the forward set only)
+        self._shadows_fold = False    # they include the RG rows' folded in-projection (built by inference calls only; the optimizer's set lacks it)
         self._plist = None
         self._seed_base = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self._calls = 0
@@ -331,7 +332,9 @@ class FusionEngine:
         sh = self.shadow_buffer() if (inference and cache_shadows and a1 is None) else None
         with _on(self.device):
             if sh is not None:
-                valid = int(self.shadows_current())
+                # (1 = current including the folded in-projection, which only inference calls build; 2 = current but left by the
+                # optimizer call: this call adds the fold and leaves the rest -- the transposed set included -- alone)
+                valid = (1 if self._shadows_fold else 2) if self.shadows_current() else 0
                 state = C.c_int32(0)
                 rc = _lib.lib().camo_forward_cached(C.byref(self.dims), self._ptab, _ptr(batch.rg), _ptr(batch.offsets),
                                                     _ptr(batch.desc), _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(),
@@ -340,6 +343,7 @@ class FusionEngine:
                 if rc == 0 and state.value:
                     self._shadows_full = state.value == 2 or bool(valid and self._shadows_full)
                     self._shadows_version = self.param_version()
+                    self._shadows_fold = True
             else:
                 rc = _lib.lib().camo_forward(C.byref(self.dims), self._ptab, _ptr(batch.rg), _ptr(batch.offsets),
                                              _ptr(batch.desc), _ptr(batch.kg), batch.B, batch.T, batch.Nk, batch.max_nr, _ptr(ws), ws.numel(), _ptr(outs),

@@ -74,7 +74,7 @@ class FusedClipAdamW:
                                                      _ptr(ss), self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
                                                      self.weight_decay, self.step_count, int(bool(zero_grads)), _ptr(sh), st),
                            "camo_clip_adamw_shadows")
-                eng._shadows_version = eng.param_version(); eng._shadows_full = True
+                eng._shadows_version = eng.param_version(); eng._shadows_full = True; eng._shadows_fold = False
                 return
             eng._shadows_version = None
             _lib.check(L.camo_clip_adamw(_ptr(eng.flat_params), _ptr(g), _ptr(m), _ptr(v), g.numel(), _ptr(ss),

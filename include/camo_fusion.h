@@ -143,7 +143,9 @@ int camo_forward(const camo_dims_t* dims, const float* const* params,
  * shadows live in the caller's persistent buffer (camo_shadow_bytes() bytes, 256-byte aligned) instead of the per-batch
  * workspace, and a call with shadows_valid != 0 -- the caller's promise that the buffer holds the current parameters, i.e.
  * that nothing wrote them since the call that reported the buffer filled -- skips the shadow launch (3 launches instead of 4
- * per inference call).  *shadows_state (may be null) reports what the buffer holds after the call: 0 = untouched (the call
+ * per inference call).  shadows_valid == 2: valid, but left by camo_clip_adamw_shadows, whose set lacks the one piece only
+ * inference calls build -- the RG rows' folded in-projection Wf = [Wq; Wk'; Wv'] Wrg (csrc/fused_wide2.hip) -- which this call
+ * then builds alone (one small launch); afterwards the caller may pass 1.  *shadows_state (may be null) reports what the buffer holds after the call: 0 = untouched (the call
  * took a schedule without shadows: Nk > 16, attention maps, f32 ...; a promise is then simply not used), 1 = the forward
  * shadows (an inference call built them, or used valid ones); 2 is reported by camo_forward_loss_backward only (forward and
  * transposed shadows).  With a shadow buffer the call must be an inference call (flags contain CAMO_FWD_INFERENCE), else

@@ -103,3 +103,42 @@ def test_wide2_repeated_calls_and_shadow_cache(kg_real, opts):
         assert np.isfinite(o).all()
         first = o if first is None else first
         assert np.abs(o - first).max() < 2e-5
+
+
+def test_wide2_fold_follows_the_parameters(kg_real, opts):
+    """The folded in-projection Wf = [Wq; Wk'; Wv'] Wrg lives with the cached weight shadows and is built by inference calls only.
+    (1) after an optimizer step the optimizer's shadows are current but carry no fold: the next inference call builds the fold alone
+    (shadows_valid = 2) and leaves the transposed set usable; (2) after load_state_dict everything is rebuilt; in both cases the
+    cached call equals an uncached one on the same parameters."""
+    import copy
+    from camouflage_multimodal_amd import NativeTrainer
+    opts("wide2", 1)
+    cfg = OP.full_cfg()
+    nrs = [303, 64, 33, 530, 17]
+    rg = torch.from_numpy(np.concatenate([OP.make_rg(n, 128, seed=60 + i) for i, n in enumerate(nrs)])).cuda()
+    kg = torch.from_numpy(np.stack([kg_real] * len(nrs))).cuda()
+    y, e, s = (torch.from_numpy(v) for v in OP.make_labels(len(nrs), seed=5))
+    m = make_model(cfg, 3, "bf16")
+    tr = NativeTrainer(m)
+    eng = m._engine
+
+    def uncached():
+        b = eng.make_batch(rg, nrs, kg)
+        outs, _ = eng.forward_raw(b, eng.workspace(b, private=True), False, 0, inference=True, cache_shadows=False)
+        return t2n(outs)
+
+    m.eval()
+    o0 = t2n(tr.evaluate(rg, nrs, kg))
+    assert eng._shadows_fold and np.abs(o0 - uncached()).max() < 2e-5
+    m.train()
+    tr.step(rg, nrs, kg, y, e, s, seed=1)
+    assert eng.shadows_current() and eng._shadows_full and not eng._shadows_fold
+    m.eval()
+    o1 = t2n(tr.evaluate(rg, nrs, kg))                       # builds the fold alone
+    assert eng.shadows_current() and eng._shadows_full and eng._shadows_fold
+    assert np.abs(o1 - uncached()).max() < 2e-5 and np.abs(o1 - o0).max() > 1e-5
+    o1b = t2n(tr.evaluate(rg, nrs, kg))                      # reuses everything
+    assert np.abs(o1b - o1).max() < 2e-5
+    m.load_state_dict(copy.deepcopy(make_model(cfg, 4, "bf16").state_dict()))
+    o2 = t2n(tr.evaluate(rg, nrs, kg))
+    assert np.abs(o2 - uncached()).max() < 2e-5 and np.abs(o2 - o1).max() > 1e-3

@@ -10,7 +10,7 @@ def main():
     path, frag = sys.argv[1], sys.argv[2]
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if frag in l and not l.startswith(("\t", ".")) and ":" in l.split(";")[0])
-    end = int(sys.argv[3]) if len(sys.argv) > 3 else next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    end = int(sys.argv[3]) if len(sys.argv) > 3 else next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     c, ops = {}, {}
     for l in lines[start:end]:
         t = l.strip().split()
