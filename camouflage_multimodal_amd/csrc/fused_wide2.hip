@@ -100,12 +100,19 @@ struct Stage {
   static constexpr int TOTAL = NT * KS;
   static constexpr int D = DEPTH < TOTAL ? DEPTH : TOTAL;
   u32x4 buf[D];
-  const u32x4* wp;
-  __device__ __forceinline__ const u32x4* wptr(int i) const { return wp + 64 * ((i / NT) * KST + (i % NT)); }
-  __device__ __forceinline__ void prefetch(const u32x4* __restrict__ wp_) {
-    wp = wp_;
+  // weight fragments come through buffer loads: a wave-uniform descriptor and byte offset in SGPRs (advanced by scalar adds), ONE
+  // per-lane offset register for the whole kernel -- as 64-bit per-lane pointers every other fragment cost two vector adds
+  __amdgpu_buffer_rsrc_t rs;
+  int voff, soff;
+  __device__ __forceinline__ u32x4 load(int i) const {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + 1024 * ((i / NT) * KST + (i % NT)), 0);
+  }
+  // base: the shadow (wave-uniform pointer), frag0: this wave's first fragment (wave-uniform index, 1 KB units)
+  __device__ __forceinline__ void prefetch(const us16* base, int frag0, int lane) {
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<us16*>(base), 0, 0x7FFFFFFF, 0x00020000);
+    voff = 16 * lane; soff = 1024 * frag0;
 #pragma unroll
-    for (int i = 0; i < D; ++i) buf[i] = *wptr(i);
+    for (int i = 0; i < D; ++i) buf[i] = load(i);
   }
   // W_IS_A: the weights are the A operand (accumulator: lane = tile row, registers = features) -- else the B operand (lane = feature,
   // registers = tile rows).  init[t]: the first k step's C operand (a bias vector, or zeros).
@@ -118,7 +125,7 @@ struct Stage {
     for (int i = 0; i < TOTAL; ++i) {
       const int ks = i / NT, t = i % NT;
       const bf16x8 wf = as_frag(buf[i % D]);
-      if (i + D < TOTAL) buf[i % D] = *wptr(i + D);
+      if (i + D < TOTAL) buf[i % D] = load(i + D);
       if (t == 0) {
 #pragma unroll
         for (int s = 0; s < RS; ++s) x[s] = xn[s];
@@ -222,6 +229,18 @@ __device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS],
     }
   };
   Stage<RS, 2, 16, 4, DEPTH> stf;
+  // identity fragment of the 32x32x16 MFMA: I[k][col] (B operand, lane = col) or I[row][k] (A operand, lane = row) -- the same registers:
+  // lane (l31, h) holds k = 8 h + j of k step kk, 1.0 where 16 kk + 8 h + j == l31.  Two uses below: the residual rows enter the
+  // out-projection's accumulators as I . R (two MFMAs per tile instead of unpacking and adding 16 bf16 values per lane), and the mean
+  // pool of the LayerNorm output is Y . I.
+  u32x4 idf[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int j = l31 - 16 * kk - 8 * h;                          // the element of this lane's fragment that is 1.0 (if 0 <= j < 8)
+    const uint32_t one_lo = 0x3F80u, one_hi = 0x3F800000u;
+    idf[kk] = u32x4{j == 0 ? one_lo : (j == 1 ? one_hi : 0u), j == 2 ? one_lo : (j == 3 ? one_hi : 0u),
+                    j == 4 ? one_lo : (j == 5 ? one_hi : 0u), j == 6 ? one_lo : (j == 7 ? one_hi : 0u)};
+  }
   {
     f32x16 acc[RS][2];
     {
@@ -230,6 +249,15 @@ __device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS],
       for (int t = 0; t < 2; ++t) init[t] = feature_vec(cst + Cfg::C_BO + 32 * (2 * w + t), h);
       sto.template run_f<true>(ofrag, init, acc);
     }
+    // + residual: acc[feature][row] += sum_k I[feature][k] R[row][k] over the tile's own 32 features (exact: bf16 x 1.0 into fp32)
+#pragma unroll
+    for (int s = 0; s < RS; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const char* rp = bufY + (32 * s + l31) * PR + 2 * (32 * (2 * w + t)) + 16 * h;
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(idf[0]), *reinterpret_cast<const bf16x8*>(rp), acc[s][t], 0, 0, 0);
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(idf[1]), *reinterpret_cast<const bf16x8*>(rp + 32), acc[s][t], 0, 0, 0);
+      }
     stamp(stamps, 9);
     // u = out-projection + bias (C operand) + residual; one-pass statistics over this lane's 32 features, then the other lane half
 #pragma unroll
@@ -238,20 +266,12 @@ __device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS],
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const u32x2 rv = *reinterpret_cast<const u32x2*>(bufY + (32 * s + l31) * PR + 2 * (32 * (2 * w + t) + 8 * g + 4 * h));
-          const float a0 = acc[s][t][4 * g] + bf_lo(rv.x), a1 = acc[s][t][4 * g + 1] + bf_hi(rv.x);
-          const float a2 = acc[s][t][4 * g + 2] + bf_lo(rv.y), a3 = acc[s][t][4 * g + 3] + bf_hi(rv.y);
-          acc[s][t][4 * g] = a0; acc[s][t][4 * g + 1] = a1; acc[s][t][4 * g + 2] = a2; acc[s][t][4 * g + 3] = a3;
-          sm += (a0 + a1) + (a2 + a3);
-          sq = fmaf(a0, a0, sq); sq = fmaf(a1, a1, sq); sq = fmaf(a2, a2, sq); sq = fmaf(a3, a3, sq);
-        }
+        for (int i = 0; i < 16; ++i) { sm += acc[s][t][i]; sq = fmaf(acc[s][t][i], acc[s][t][i], sq); }
       sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
       if (h == 0) *reinterpret_cast<float2*>(red + 2 * (w * ROWS + 32 * s + l31)) = make_float2(sm, sq);
-      __builtin_amdgcn_sched_barrier(0);                          // (one sub-tile's residual reads at a time: registers)
     }
     __syncthreads();
-    stf.prefetch(reinterpret_cast<const u32x4*>(S.W1) + (size_t)(w * (16 * 4)) * 64 + lane);      // (flows during the normalisation and the pooling products)
+    stf.prefetch(S.W1, w * (16 * 4), lane);                       // (flows during the normalisation and the pooling products)
 #pragma unroll
     for (int s = 0; s < RS; ++s) {
       float ts = 0.f, tq = 0.f;
@@ -283,15 +303,6 @@ __device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS],
   // ---- mean pool of the LayerNorm output: column sums of the bf16 Y tile as MFMAs against an identity fragment.  Product
   // Y_s [32 rows][32 features of tile (2w + t)] . I: lane = feature, registers = rows -> 16 in-lane adds + the other lane half.
   {
-    // B operand I [k][col]: lane (col = l31, h) holds k = 8 h + j of k step kk: 1.0 where 16 kk + 8 h + j == col
-    u32x4 idf[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int j = l31 - 16 * kk - 8 * h;                        // the element of this lane's fragment that is 1.0 (if 0 <= j < 8)
-      const uint32_t one_lo = 0x3F80u, one_hi = 0x3F800000u;
-      idf[kk] = u32x4{j == 0 ? one_lo : (j == 1 ? one_hi : 0u), j == 2 ? one_lo : (j == 3 ? one_hi : 0u),
-                      j == 4 ? one_lo : (j == 5 ? one_hi : 0u), j == 6 ? one_lo : (j == 7 ? one_hi : 0u)};
-    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f32x16 p[RS];
@@ -312,7 +323,7 @@ __device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS],
       f32x16 init[2] = {splat16(0.f), splat16(0.f)};
       stf.template run<false>(bufY + l31 * PR + 16 * h, 32 * PR, init, acc);
     }
-    if (p == 0) stf.prefetch(reinterpret_cast<const u32x4*>(S.W1) + (size_t)(w * (16 * 4) + 2) * 64 + lane);
+    if (p == 0) stf.prefetch(S.W1, w * (16 * 4) + 2, lane);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int f = 128 * w + 64 * p + 32 * t + l31;
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(NTH, 2) void kgchain_kernel(const KgChainArgs g) {
   stamp(a.stamps, 0);
   const int ta0 = a.tile_off[b0], ta1 = a.tile_off[b0 + 1], tb1 = pair2 ? a.tile_off[b0 + 2] : ta1;
   Stage<1, 2, 16, 2, DEPTH> stk;
-  stk.prefetch(reinterpret_cast<const u32x4*>(K.Wo) + (size_t)(w * (16 * 2)) * 64 + lane);
+  stk.prefetch(K.Wo, w * (16 * 2), lane);
   // constants: the KG->RG values' bias (added by the combine) | bo | ln_g | ln_b | b1 of the KG stream
   for (int i = tid; i < 384; i += NTH) {
     const float* src = i < 64 ? g.bv2 + 4 * i : (i < 128 ? K.bo + 4 * (i - 64) : (i < 192 ? K.ln_g + 4 * (i - 128) : (i < 256 ? K.ln_b + 4 * (i - 192) : K.b1 + 4 * (i - 256))));
@@ -511,16 +522,19 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
   stamp(a.stamps, 0);
   const bool same = sub[1].nr > 0 && sub[1].b == sub[0].b;        // (wave-uniform) both sub-tiles belong to one sample
   Stage<RT, 2, 8, 2, DEPTH> st0;
-  st0.prefetch(reinterpret_cast<const u32x4*>(F.W0) + (size_t)(w * (8 * 2)) * 64 + lane);
+  st0.prefetch(F.W0, w * (8 * 2), lane);
   // ---- input rows: fp32 -> bf16 tile (rows past a sub-tile's end cleared)
   {
     constexpr int XIT = ROWS * 8 / NTH;
     float4 xv[XIT][4];
 #pragma unroll
     for (int it = 0; it < XIT; ++it) {
-      const int idx = tid + NTH * it, r = idx >> 3, c = idx & 7;
-      const int srow = r < 32 ? sub[0].row0 : sub[1].row0, snr = r < 32 ? sub[0].nr : sub[1].nr;
-      const float4* src = reinterpret_cast<const float4*>(F.X + ((size_t)srow + max(0, min(r & 31, snr - 1))) * 128 + 16 * c);
+      // (XIT = 2: iteration `it` covers exactly sub-tile `it`'s 32 rows, so the row base is a scalar and the lane part a 32-bit offset)
+      static_assert(ROWS * 8 / NTH == RT, "one sub-tile per iteration");
+      const int r = tid >> 3, c = tid & 7;
+      const float* xbase = F.X + (size_t)sub[it].row0 * 128;
+      const unsigned xoff = (unsigned)max(0, min(r, sub[it].nr - 1)) * 128u + 16u * (unsigned)c;
+      const float4* src = reinterpret_cast<const float4*>(xbase + xoff);
 #pragma unroll
       for (int q = 0; q < 4; ++q) xv[it][q] = src[q];
     }
@@ -533,9 +547,8 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
     }
 #pragma unroll
     for (int it = 0; it < XIT; ++it) {
-      const int idx = tid + NTH * it, r = idx >> 3, c = idx & 7;
-      const int snr = r < 32 ? sub[0].nr : sub[1].nr;
-      const bool ok = (r & 31) < snr;
+      const int r = 32 * it + (tid >> 3), c = tid & 7;
+      const bool ok = (tid >> 3) < sub[it].nr;
       const float4 v0 = xv[it][0], v1 = xv[it][1], v2 = xv[it][2], v3 = xv[it][3];
       u32x4 p0 = u32x4{pack2(v0.x, v0.y), pack2(v0.z, v0.w), pack2(v1.x, v1.y), pack2(v1.z, v1.w)};
       u32x4 p1 = u32x4{pack2(v2.x, v2.y), pack2(v2.z, v2.w), pack2(v3.x, v3.y), pack2(v3.z, v3.w)};
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
   // the in-projections read the INPUT tile: [q | k2 | v2] = x Wf^T + bf with Wf = [Wq; Wk2; Wv2] Wrg (768 x 128: half the k steps and
   // half the weight bytes of the unfolded 256 -> 768 product; launch_fold_rg)
   Stage<RT, 2, 8, 6, DEPTH> st1;
-  auto w1pair = [&](int tg) { return reinterpret_cast<const u32x4*>(g.Wf) + (size_t)((tg / 6) * (8 * 6) + tg % 6) * 64 + lane; };   // tiles tg, tg + 1 (tg even)
+  auto w1pair = [&](int tg) { return (tg / 6) * (8 * 6) + tg % 6; };      // first fragment of tiles tg, tg + 1 (tg even) in the [768 x 128] shadow
   {
     f32x16 acc[RT][2];
     {
@@ -559,7 +572,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
       for (int t = 0; t < 2; ++t) init[t] = feature_vec(cst + Cfg::C_B0 + 32 * (2 * w + t), h);
       st0.template run<true>(bufX + l31 * PX + 16 * h, 32 * PX, init, acc);
     }
-    st1.prefetch(w1pair(8 + 2 * w));
+    st1.prefetch(g.Wf, w1pair(8 + 2 * w), lane);
 #pragma unroll
     for (int s = 0; s < RT; ++s)
 #pragma unroll
@@ -584,7 +597,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
       for (int s = 0; s < RT; ++s)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const us16* q2p = a.Q2_16 + ((size_t)sub[s].b * Nk + min(l31, Nk - 1)) * 256 + 32 * (2 * w + t) + 4 * h;
+          const us16* q2p = (a.Q2_16 + ((size_t)sub[s].b * Nk * 256 + 32 * (2 * w + t))) + ((unsigned)min(l31, Nk - 1) * 256u + 4u * (unsigned)h);      // (scalar base + 32-bit lane offset)
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
             const u32x2 lo = *reinterpret_cast<const u32x2*>(q2p + 16 * kk), hi = *reinterpret_cast<const u32x2*>(q2p + 16 * kk + 8);
@@ -596,7 +609,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
         f32x16 init[2] = {splat16(0.f), splat16(0.f)};            // (no key bias: a constant per query cancels in its softmax)
         st1.template run<true>(bufX + l31 * PX + 16 * h, 32 * PX, init, acc);
       }
-      st1.prefetch(w1pair(16 + 2 * w));
+      st1.prefetch(g.Wf, w1pair(16 + 2 * w), lane);
       stamp(a.stamps, 3);
       float mx[RT][2];
       f32x16 S2[RT][2];
@@ -651,31 +664,33 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
       f32x16 init[2] = {splat16(0.f), splat16(0.f)};              // (the values' bias is added by the combine)
       st1.template run<false>(bufX + l31 * PX + 16 * h, 32 * PX, init, vacc);      // same fragments, operands swapped: lane = feature
     }
-    st1.prefetch(w1pair(2 * w));
+    st1.prefetch(g.Wf, w1pair(2 * w), lane);
     stamp(a.stamps, 4);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f32x16 Z = splat16(0.f);
-      float L = 0.f;
-      int seg_first = g0;
+    // one partial per run of sub-tiles of one sample: {max (log2 units), sum, Z[query][feature] = E^T . V2 as bf16} at the run's first tile
+    auto store_part = [&](int tile, int t, const f32x16& Z, float L, float m) {
+      L += __shfl_xor(L, 32, 64);
+      float* part = a.part + ((size_t)tile * 8 + (2 * w + t)) * PART_FLOATS;
+      if (lane < 16) { part[lane] = m * LOG2E; part[16 + lane] = L; }
       us16* zt = reinterpret_cast<us16*>(scr + 1024 * t);            // [16 queries][32 features] bf16
 #pragma unroll
-      for (int s = 0; s < RT; ++s) {
-        if (sub[s].nr <= 0) continue;                             // (wave-uniform)
-        L += Lsub[s][t];
+      for (int i = 0; i < 8; ++i) zt[acc_row(i, h) * 32 + l31] = f2bf(Z[i]);
+      // (the wave's own LDS writes: program order) rows j < Nk leave as one 16-byte store per lane: lane -> row lane >> 2, chunk lane & 3
+      if ((lane >> 2) < Nk) *reinterpret_cast<u32x4*>(reinterpret_cast<us16*>(part + 32) + 8 * lane) = *reinterpret_cast<const u32x4*>(zt + 8 * lane);
+    };
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-          Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ef[s][t][k]), as_frag(pack8(vacc[s][t], k)), Z, 0, 0, 0);      // Z[query][feature] += E^T . V2
-        const bool seg_end = s == RT - 1 || sub[s + 1].nr <= 0 || sub[s + 1].b != sub[s].b;      // (wave-uniform)
-        if (seg_end) {
-          L += __shfl_xor(L, 32, 64);
-          float* part = a.part + ((size_t)seg_first * 8 + (2 * w + t)) * PART_FLOATS;
-          if (lane < 16) { part[lane] = mseg[s][t] * LOG2E; part[16 + lane] = L; }      // (log2 units: the combine runs in exp2)
-#pragma unroll
-          for (int i = 0; i < 8; ++i) zt[acc_row(i, h) * 32 + l31] = f2bf(Z[i]);
-          // (the wave's own LDS writes: program order) rows j < Nk leave as one 16-byte store per lane: lane -> row lane >> 2, chunk lane & 3
-          if ((lane >> 2) < Nk) *reinterpret_cast<u32x4*>(reinterpret_cast<us16*>(part + 32) + 8 * lane) = *reinterpret_cast<const u32x4*>(zt + 8 * lane);
-          if (s + 1 < RT) { Z = splat16(0.f); L = 0.f; seg_first = g0 + s + 1; }
+    for (int t = 0; t < 2; ++t) {
+      f32x16 Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ef[0][t][0]), as_frag(pack8(vacc[0][t], 0)), splat16(0.f), 0, 0, 0);
+      Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ef[0][t][1]), as_frag(pack8(vacc[0][t], 1)), Z, 0, 0, 0);
+      if (same) {                                                 // (wave-uniform) the common case: both sub-tiles, one partial
+        Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ef[1][t][0]), as_frag(pack8(vacc[1][t], 0)), Z, 0, 0, 0);
+        Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ef[1][t][1]), as_frag(pack8(vacc[1][t], 1)), Z, 0, 0, 0);
+        store_part(g0, t, Z, Lsub[0][t] + Lsub[1][t], mseg[0][t]);
+      } else {
+        store_part(g0, t, Z, Lsub[0][t], mseg[0][t]);
+        if (sub[1].nr > 0) {
+          f32x16 Z1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ef[1][t][0]), as_frag(pack8(vacc[1][t], 0)), splat16(0.f), 0, 0, 0);
+          Z1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(ef[1][t][1]), as_frag(pack8(vacc[1][t], 1)), Z1, 0, 0, 0);
+          store_part(g0 + 1, t, Z1, Lsub[1][t], mseg[1][t]);
         }
       }
     }
@@ -692,7 +707,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int jk = l31 & 15;
-        const us16* kp = a.KV16 + ((size_t)sub[s].b * Nk + min(jk, Nk - 1)) * 512 + 32 * (2 * w + t) + 4 * h;
+        const us16* kp = (a.KV16 + ((size_t)sub[s].b * Nk * 512 + 32 * (2 * w + t))) + ((unsigned)min(jk, Nk - 1) * 512u + 4u * (unsigned)h);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const u32x2 lo = *reinterpret_cast<const u32x2*>(kp + 16 * kk), hi = *reinterpret_cast<const u32x2*>(kp + 16 * kk + 8);
@@ -700,7 +715,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
         }
         const int j = lane >> 2, c = lane & 3;
         vkg[s][t] = u32x4{0u, 0u, 0u, 0u};
-        if (j < Nk) vkg[s][t] = *reinterpret_cast<const u32x4*>(a.KV16 + ((size_t)sub[s].b * Nk + j) * 512 + 256 + 32 * (2 * w + t) + 8 * c);
+        if (j < Nk) vkg[s][t] = *reinterpret_cast<const u32x4*>((a.KV16 + ((size_t)sub[s].b * Nk * 512 + 256 + 32 * (2 * w + t))) + ((unsigned)j * 512u + 8u * (unsigned)c));
       }
     f32x16 acc[RT][2];
     {
@@ -709,7 +724,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
       for (int t = 0; t < 2; ++t) init[t] = feature_vec(cst + Cfg::C_BQ + 32 * (2 * w + t), h);
       st1.template run<true>(bufX + l31 * PX + 16 * h, 32 * PX, init, acc);
     }
-    sto.prefetch(reinterpret_cast<const u32x4*>(S.Wo) + (size_t)(w * (16 * 2)) * 64 + lane);
+    sto.prefetch(S.Wo, w * (16 * 2), lane);
     stamp(a.stamps, 6);
     // invalid keys (Nk .. 15) leave the softmax through the score product's C operand
     f32x16 kmask;
