@@ -545,12 +545,14 @@ static int wide_rt(int T, int max_nr, bool save = false) {
   return rt;
 }
 
-// Inference calls: the RG rows' whole forward in one launch of 64-row half-blocks, two independent blocks per CU (fused_wide2.hip).
-// By size from 13 312 packed rows (where the 8-wave wide kernels start too); a forced fused_rt selects the 8-wave kernels.
+// The RG rows' whole forward in one launch of 64-row half-blocks, two independent blocks per CU, + the KG rows' launch behind it
+// (fused_wide2.hip).  By size from 13 312 packed rows (where the 8-wave wide kernels start too), for inference AND training calls
+// (the saving / dropout variants write the backward's saved set); a forced fused_rt selects the 8-wave / 32-row kernels.
 static bool wide2_taken(int T, int max_nr, bool save, bool dropping) {
-  if (save || dropping || g_opt_wide2 == 0 || g_opt_fused_one == 0 || max_nr > wide2_max_rows()) return false;
+  (void)save; (void)dropping;
+  if (g_opt_wide2 == 0 || g_opt_fused_one == 0 || max_nr > wide2_max_rows()) return false;
   if (g_opt_wide2 > 0) return true;
-  return g_opt_fused_rt < 0 && T >= 13312;
+  return g_opt_fused_rt < 0 && g_opt_wide_front_rt == 0 && T >= 13312;
 }
 
 // Training calls (save): the front half alone on wide blocks -- 64-row blocks from 10 240 packed rows (front 21 -> 17 us at B = 24,

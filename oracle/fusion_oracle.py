@@ -133,7 +133,10 @@ class FusionOracle:
         # another order may land on the other side of zero there, and ONE such unit moves a head's gradient by percent.
         # ``relu_flip``: set of (site, sample, unit) whose ReLU decision is inverted -- tests enumerate the admissible sign
         # patterns of the recorded units instead of picking inputs that happen to have none (tests/helpers.py).
-        self.kg_block = 64                  # keys per flash block of the KG->RG attention in the fused 32-row kernels (bf16 mode only)
+        self.kg_block = 64                  # keys per flash block of the KG->RG attention in the fused kernels (bf16 mode only)
+        # sample index -> keys in its FIRST block where that differs from kg_block: the 64-row forward (csrc/fused_wide2.hip) cuts blocks
+        # from the batch's global table of 32-row tiles, two per block, so a sample that starts on an odd tile has a 32-key first block
+        self.kg_first_block = {}
         self.near = None
         self.near_eps = 2e-4
         self.relu_flip = frozenset()
@@ -210,8 +213,9 @@ class FusionOracle:
             kb = int(self.kg_block)
             M = S2.max(axis=0)                                                # [nh, Nk]
             num = np.zeros((Nk, nh, dh), f32); den = np.zeros((nh, Nk), f32)
-            for t0 in range(0, Nr, kb):
-                sl = slice(t0, min(Nr, t0 + kb))
+            first = int(self.kg_first_block.get(b_index, kb))
+            for t0 in [0] + list(range(first, Nr, kb)):
+                sl = slice(t0, min(Nr, first if t0 == 0 else t0 + kb))
                 mb = S2[sl].max(axis=0)
                 eb = np.exp(S2[sl] - mb).astype(f32)
                 ed = eb if m_a2 is None else eb * m_a2[sl]

@@ -144,3 +144,20 @@ def oracle_batch_step(make_oracle, rg_list, kg, y, e, s, seed, got_grads=None, t
     assert len(res["flips"]) <= max_flips, f"{len(res['flips'])} ReLU decisions taken flipped (allowed {max_flips}): {res['flips']}"
     res["raw_grads"] = g
     return res
+
+
+def first_blocks_64row_forward(nrs):
+    """FusionOracle.kg_first_block for a batch whose forward runs on the 64-row half-blocks of csrc/fused_wide2.hip: blocks are cut
+    from the batch's global table of 32-row tiles, two per block, so a sample that starts on an odd tile has a 32-key first flash
+    block in its KG->RG attention (the bf16-operand oracle rounds the exponentials per block: the partition is part of the model)."""
+    tiles = np.cumsum([0] + [(int(n) + 31) // 32 for n in nrs])
+    return {b: 32 for b in range(len(nrs)) if tiles[b] % 2 == 1}
+
+
+def bf16_oracle(cfg, params, nrs=None, wide2=False):
+    """The oracle in its bf16-operand mode; ``wide2``: with the flash-block partition of the 64-row forward for this batch."""
+    from oracle import fusion_oracle as FO
+    o = FO.FusionOracle(cfg, params, bf16_operands=True)
+    if wide2:
+        o.kg_first_block = first_blocks_64row_forward(nrs)
+    return o

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close, oracle_step_at_relu_thresholds
+from helpers import assert_close, bf16_oracle, oracle_step_at_relu_thresholds
 from oracle import fusion_oracle as FO
 from oracle import params as OP
 from test_fragment_maps import frag_order
@@ -26,7 +26,7 @@ def _opt(name, value):
 @pytest.fixture
 def fused_opts():
     yield _opt
-    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1); _opt("fused_rt", -1); _opt("tailw", -1); _opt("fused_one", 1); _opt("tn_big", -1); _opt("param_space", -1); _opt("tailw_bwd", -1)
+    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1); _opt("fused_rt", -1); _opt("tailw", -1); _opt("fused_one", 1); _opt("tn_big", -1); _opt("param_space", -1); _opt("tailw_bwd", -1); _opt("wide2", -1)
 
 
 def bf16_round(x):
@@ -70,12 +70,16 @@ def close_rel(got, want, rel, what, mean_rel=None, flips=0.0):
 NRS = [303, 64, 1, 530, 65, 127, 31, 32, 33]
 
 
-@pytest.mark.parametrize("rt", [0, 1, 2, 4])
+@pytest.mark.parametrize("rt", [0, 1, 2, 4, 64])
 @pytest.mark.parametrize("training", [False, True])
 def test_fused_forward_stage_by_stage(training, rt, kg_real, fused_opts):
     """rt = 0: the 32-row tile kernels (fused_rows.hip); rt = 1, 2, 4: the wide-tile kernels (fused_wide.hip) with that many
-    32-row tiles per block -- the same saved tensors, pooled sums and logits."""
-    fused_opts("fused_rt", rt)
+    32-row tiles per block; rt = 64: the 64-row half-blocks of 4 waves + the KG rows' launch (fused_wide2.hip, saving / dropout
+    variants) -- the same saved tensors, pooled sums and logits."""
+    if rt == 64:
+        fused_opts("wide2", 1)
+    else:
+        fused_opts("fused_rt", rt); fused_opts("wide2", 0)
     cfg = OP.full_cfg()
     prm = OP.make_params(cfg, 0)
     m = make_model(cfg, 0, "bf16")
@@ -160,11 +164,13 @@ def test_fused_forward_shapes(nrs, nk, rt, fused_opts):
     assert_close(got, outs6(ref), 1e-3, 0, f"nrs={nrs[:4]} nk={nk}")
 
 
+@pytest.mark.parametrize("wide2", [0, 1])
 @pytest.mark.parametrize("training", [False, True])
-def test_fused_backward_stage_by_stage(training, kg_real, fused_opts):
+def test_fused_backward_stage_by_stage(training, wide2, kg_real, fused_opts):
     """The fused backward kernels against the intermediate activation gradients of the oracle in its bf16-operand mode, then every
     parameter gradient: absolute bounds (global relative error < 0.2 %, every tensor that carries weight < 1 %; measured 0.002-0.01 %
     and <= 0.1 %), no other HIP schedule as a yardstick."""
+    fused_opts("wide2", wide2)                  # (1: the forward that saves for these backward kernels is the 64-row one, fused_wide2.hip)
     cfg = OP.full_cfg()
     prm = OP.make_params(cfg, 0)
     m = make_model(cfg, 0, "bf16")
@@ -180,7 +186,7 @@ def test_fused_backward_stage_by_stage(training, kg_real, fused_opts):
     ws.zero_()
     g = eng.ensure_flat_grads(attach=True)
     g.zero_()
-    orc = FO.FusionOracle(cfg, OP.make_params(cfg, 0), bf16_operands=True)      # rounds what the kernels round (oracle/fusion_oracle.py)
+    orc = bf16_oracle(cfg, OP.make_params(cfg, 0), NRS, wide2)                  # rounds what the kernels round (oracle/fusion_oracle.py)
     ref = FO.train_step(orc, FO.AdamW(orc.p), rg, kg, y, e, s, training=training, seed=seed, debug=True)
     # forward on the HIP path, then backward from the ORACLE's loss gradient: the focal term's gradient is steep in the
     # logits, and this test is about the backward kernels, not about how logit noise moves d(loss)/d(logits)
@@ -194,6 +200,14 @@ def test_fused_backward_stage_by_stage(training, kg_real, fused_opts):
     d_outs = torch.from_numpy(np.stack(d_outs).astype(np.float32)).cuda()
     eng.backward_raw(batch, ws, outs, d_outs, training, seed, eng._gtab)
     torch.cuda.synchronize()
+    # tail units whose pre-activation is within 5e-5 of the ReLU threshold may land on either side (helpers.py bounds how many): this
+    # batch has three, and which side the kernels take moves with the summation order of the pooled means in front of them
+    got_grads = {k: t2n(p.grad).copy() for k, p in m.named_parameters()}
+    ref, near, flipped = oracle_step_at_relu_thresholds(
+        lambda: bf16_oracle(cfg, OP.make_params(cfg, 0), NRS, wide2),
+        lambda o: FO.train_step(o, FO.AdamW(o.p), rg, kg, y, e, s, training=training, seed=seed, debug=True), got_grads)
+    if near:
+        print("tail units at the ReLU threshold (site, sample, unit, pre-activation):", near, "taken flipped:", flipped)
     dbg, caches = ref["dbg"], ref["caches"]
     failures = []
 
@@ -284,6 +298,18 @@ def test_one_launch_tail_matches_separate_launches(training, B, ncls, kg_real, f
                                           ([33, 31, 1, 2, 530, 96], 13, 7), ([33, 31, 1, 2, 530, 96], 13, 8), ([1500, 17], 7, 6),
                                           ([420 + 5 * i for i in range(24)], 13, 6), ([128] * 3 + [127, 129, 256, 64, 192], 13, 6)])
 def test_fused_training_step_shape_envelope(nrs, nk, pseed, fused_opts):
+    _training_step_shape_envelope(nrs, nk, pseed, fused_opts, wide2=0)
+
+
+@pytest.mark.parametrize("nrs,nk,pseed", [([5, 700, 32], 16, 6), ([33, 31, 1, 2, 530, 96], 13, 7), ([1500, 17], 7, 6), ([128] * 3 + [127, 129, 256, 64, 192], 13, 6),
+                                          ([420 + 5 * i for i in range(24)], 13, 8)])
+def test_fused_training_step_shape_envelope_64row_forward(nrs, nk, pseed, fused_opts):
+    """The same envelope with the forward on 64-row half-blocks (fused_wide2.hip, saving + dropout variants) in front of the same
+    backward kernels: same oracle, same bounds."""
+    _training_step_shape_envelope(nrs, nk, pseed, fused_opts, wide2=1)
+
+
+def _training_step_shape_envelope(nrs, nk, pseed, fused_opts, wide2):
     """Envelope of the fused BACKWARD (and of the one-launch tail where B <= 16): one-node samples, Nk = 1 / 7 / 16, samples
     that end exactly on a 32-, 64- or 128-row boundary, B = 17 (multi-launch tail behind fused node kernels), a 1500-node sample,
     24 samples with 11 460 rows (the weight-gradient launch's split-K ladder picks a 24-tile chunk: not a power of two) --
@@ -292,6 +318,7 @@ def test_fused_training_step_shape_envelope(nrs, nk, pseed, fused_opts):
     seed 6 the six-sample case has head units whose pre-activation sits within bf16 noise of zero in three samples: against
     the reference-exact f32 oracle one such ReLU flip moves instance_head.0.bias by 18 % (tools/dev/dev_relu_flip.py); the bf16-operand
     oracle rounds what the kernels round and lands on the same side.  The f32 oracle still bounds the logits (north_star: 1e-3)."""
+    fused_opts("wide2", wide2)
     cfg = OP.full_cfg()
     m = make_model(cfg, pseed, "bf16").train()
     eng = m._engine
@@ -311,7 +338,7 @@ def test_fused_training_step_shape_envelope(nrs, nk, pseed, fused_opts):
     assert np.isfinite(t2n(outs)).all() and all(np.isfinite(v).all() for v in grads.values())
     # (tail units whose pre-activation is within 5e-5 of the ReLU threshold may land on either side: helpers.py bounds how many)
     ref, near, flipped = oracle_step_at_relu_thresholds(
-        lambda: FO.FusionOracle(cfg, OP.make_params(cfg, pseed), bf16_operands=True),
+        lambda: bf16_oracle(cfg, OP.make_params(cfg, pseed), nrs, wide2 or sum(nrs) >= 13312),      # (by size the 64-row forward from 13 312 packed rows)
         lambda o: FO.train_step(o, FO.AdamW(o.p), rgl, kg, y, e, s, training=True, seed=dseed), grads)
     if near:
         print("tail units at the ReLU threshold (site, sample, unit, pre-activation):", near, "taken flipped:", flipped)
@@ -373,6 +400,8 @@ def test_large_batch_training_takes_the_wide_front_half(kg_real, fused_opts):
     samples the per-sample tail's forward and input-gradient chain on two-plane MFMA launches (tail_wide.hip), and keep the
     32-row back half: the same bf16 tensors leave the front launch, so outputs and loss terms agree to rounding and every parameter
     gradient to a few 1e-4 of its tensor against the all-32-row schedule (fused_rt = 0) on the same masks."""
+    fused_opts("wide2", 0)      # (by size a batch like this now runs its forward on the 64-row half-blocks -- tests/test_hip_large_batch.py holds that
+                                # to the oracle; the wide front half + 32-row back half is what training calls of 10 240 .. 13 311 rows take)
     cfg = OP.full_cfg()
     m = make_model(cfg, 4, "bf16")
     m.train()

@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from helpers import assert_close, oracle_batch_step
+from helpers import assert_close, bf16_oracle, oracle_batch_step
 from oracle import fusion_oracle as FO
 from oracle import params as OP
 from test_hip_parity import make_model, outs6, t2n
@@ -120,7 +120,8 @@ def _train_step_vs_bf16_oracle(B, pseed, kg_real, nrs=None):
     torch.cuda.synchronize()
     grads = {k: t2n(p.grad).copy() for k, p in m.named_parameters()}
     assert np.isfinite(t2n(outs)).all() and all(np.isfinite(v).all() for v in grads.values())
-    ref = oracle_batch_step(lambda: FO.FusionOracle(cfg, OP.make_params(cfg, pseed), bf16_operands=True), rg, kg, y, e, s, dseed, grads)
+    # (training calls of this size run their forward on the 64-row half-blocks: the oracle takes that kernel's flash-block partition)
+    ref = oracle_batch_step(lambda: bf16_oracle(cfg, OP.make_params(cfg, pseed), nrs, wide2=True), rg, kg, y, e, s, dseed, grads)
     if ref["near"]:
         print(f"B = {B}: tail units at the ReLU threshold (site, sample, unit, pre-activation): {ref['near']}; taken flipped: {ref['flips']}")
     assert_close(t2n(outs), outs6(ref["outs"]), 5e-4, 0, "outputs vs the bf16-operand oracle")
