@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcamo_fusion.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 FWD_INFERENCE = 1
 FLAG_ATTN_MAPS = 2
 SUMSQ_FLOATS = 257
@@ -23,7 +23,7 @@ NPARAMS_CROSS, NPARAMS_LATE = 44, 22
 # every symbol include/camo_fusion.h declares
 SYMBOLS = ("camo_abi_version", "camo_last_error", "camo_workspace_bytes", "camo_batch_desc_bytes", "camo_prepare_batch", "camo_gather_batch", "camo_forward", "camo_forward_cached", "camo_backward", "camo_forward_loss_backward",
            "camo_loss", "camo_grad_sumsq", "camo_clip_adamw", "camo_shadow_bytes", "camo_clip_adamw_shadows", "camo_debug_gemm", "camo_debug_gemm16", "camo_debug_ws_offset",
-           "camo_debug_set_option", "camo_debug_set_stamps", "camo_prof_begin", "camo_prof_end", "camo_prof_kind", "camo_tail_timeouts", "camo_tail_poison_to_grads")
+           "camo_options_init", "camo_options_set", "camo_debug_set_stamps", "camo_prof_begin", "camo_prof_end", "camo_prof_kind", "camo_tail_timeouts", "camo_tail_poison_to_grads")
 
 
 # every symbol include/camo_rg_gnn.h declares
@@ -38,9 +38,30 @@ class CamoRgDims(C.Structure):
     _fields_ = [("in_channels", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32)]
 
 
+OPTION_NAMES = ("sched16", "fused", "tail17", "fused_rt", "wide2", "fused_one", "wide_front_rt", "tailw", "tailw_bwd", "param_space", "tn_big",
+                "fused_variant", "back_lead", "tn_balance", "tn_kcap", "tn_exp", "exp", "fused_save", "tail_skip_arrival")
+
+
+class CamoOptions(C.Structure):
+    """camo_options_t (include/camo_fusion.h): the schedule options of ONE engine -- caller-owned, reached through CamoDims.options."""
+    _fields_ = [(n, C.c_int32) for n in OPTION_NAMES]
+
+
+# camo_options_init's values (a CPU test holds the two to each other): an engine can be constructed before the library is loadable
+OPTION_DEFAULTS = dict(sched16=-1, fused=-1, tail17=-1, fused_rt=-1, wide2=-1, fused_one=1, wide_front_rt=0, tailw=-1, tailw_bwd=-1, param_space=-1, tn_big=-1,
+                       fused_variant=1, back_lead=1, tn_balance=1, tn_kcap=0, tn_exp=0, exp=0, fused_save=0, tail_skip_arrival=0)
+
+
+def default_options():
+    o = CamoOptions()
+    for k, v in OPTION_DEFAULTS.items():
+        setattr(o, k, v)
+    return o
+
+
 class CamoDims(C.Structure):
     _fields_ = [("rg_dim", C.c_int32), ("kg_dim", C.c_int32), ("hidden_dim", C.c_int32), ("num_heads", C.c_int32),
-                ("num_classes", C.c_int32), ("fusion_type", C.c_int32), ("dropout", C.c_float)]
+                ("num_classes", C.c_int32), ("fusion_type", C.c_int32), ("dropout", C.c_float), ("options", C.POINTER(CamoOptions))]
 
 
 class CamoError(RuntimeError):
@@ -48,6 +69,11 @@ class CamoError(RuntimeError):
 
 
 _lib = None
+
+
+def _set_option_everywhere(name, value):
+    from . import engine
+    return engine.set_option_all(name.decode() if isinstance(name, bytes) else name, int(value))
 
 
 def lib():
@@ -112,8 +138,13 @@ def lib():
     L.camo_debug_gemm16.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp]
     L.camo_debug_ws_offset.restype = C.c_int64
     L.camo_debug_ws_offset.argtypes = [C.POINTER(CamoDims), i32, i32, i32, C.c_char_p]
-    L.camo_debug_set_option.restype = C.c_int
-    L.camo_debug_set_option.argtypes = [C.c_char_p, i32]
+    L.camo_options_init.restype = C.c_int
+    L.camo_options_init.argtypes = [C.POINTER(CamoOptions)]
+    L.camo_options_set.restype = C.c_int
+    L.camo_options_set.argtypes = [C.POINTER(CamoOptions), C.c_char_p, i32]
+    # tests and developer tools switch schedules "for the process": a Python-side convenience that sets the option on every live
+    # engine and on the defaults of engines created later (engine.set_option_all) -- the library itself keeps no option state
+    L.camo_debug_set_option = _set_option_everywhere
     L.camo_debug_set_stamps.restype = C.c_int
     L.camo_debug_set_stamps.argtypes = [vp, i32]
     L.camo_prof_begin.restype = C.c_int

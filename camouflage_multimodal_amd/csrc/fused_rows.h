@@ -70,7 +70,7 @@ struct BackArgs {
   DropCfg drop; int save; int exp;
   unsigned long long* stamps;                  // developer timeline (null in product calls)
 };
-extern int g_back_lead_mode;                   // developer A/B: 0 = KG split blocks always first
+extern thread_local int g_back_lead_mode;                   // developer A/B: 0 = KG split blocks always first
 int launch_fused_back(BackArgs& a, int variant, hipStream_t stream);
 
 // ---- backward, first half (see fused_rows.hip)
@@ -136,5 +136,6 @@ int wide_max_rows(int rt);
 // Wf / bf: the folded in-projection [q | k2 | v2] = x Wf^T + bf (Wf = [Wq1; Wk2; Wv2] Wrg as a [768 x 128] shadow, bf [768] fp32), built by
 // launch_fold_rg whenever the parameters changed; f.W1 / f.bq / f.bkv (the unfolded in-projection) are not read.
 int launch_fold_rg(const float* Wq, const float* Wkv, const float* bq, const float* bkv, const float* Wrg, const float* brg, us16* Wf, float* bf, hipStream_t stream);
-int launch_wide2_rgfwd(const FrontStream& f, const us16* Wf, const float* bf, float qscale, BackArgs& b, int max_nr, hipStream_t stream);
+// save_r16 (saving calls): 0 when the backward takes the projections' weight gradients in parameter space (nothing reads R16 then)
+int launch_wide2_rgfwd(const FrontStream& f, const us16* Wf, const float* bf, float qscale, BackArgs& b, int max_nr, int save_r16, hipStream_t stream);
 int wide2_max_rows();

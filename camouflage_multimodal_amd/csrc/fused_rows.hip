@@ -1461,7 +1461,7 @@ int launch_fused_front(FrontArgs& a, int variant, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-int g_back_lead_mode = 1;
+thread_local int g_back_lead_mode = 1;
 int launch_fused_back(BackArgs& a, int variant, hipStream_t stream) {
   if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q16 || !a.KV16 || !a.Q2_16 || !a.KV2_16 || !a.off || !a.tile_off || !a.tile_desc || !a.inv_nr ||
       !a.part || !a.tickets || a.max_splits < 1 || a.max_splits > FUSED_MAX_SPLITS)

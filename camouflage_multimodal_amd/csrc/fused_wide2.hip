@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void fold_rg_kernel(const float* __restrict__ 
   }
 }
 
-struct RgFwd2Args { FrontStream f; BackArgs b; float qscale; const us16* Wf; const float* bf; };      // Wf / bf: the folded in-projection (launch_fold_rg)
+struct RgFwd2Args { FrontStream f; BackArgs b; float qscale; const us16* Wf; const float* bf; int save_r16; };      // Wf / bf: the folded in-projection (launch_fold_rg)
 
 // FOLD: the in-projections read the input tile through the folded weights (inference calls); otherwise the R tile through the
 // unfolded [768 x 256] shadow, bit for bit what the backward kernels and the bf16-operand oracle assume.  DROP / SAVE (training
@@ -604,7 +604,9 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* bufR = smem + Cfg::BUFR; char* strips = smem + Cfg::BUFO; char* bufX = strips;
   char* strip = strips + w * Cfg::STRIP;                          // this wave's strip (the attention output)
-  char* scr = strips + Cfg::SCR + w * 4096;                       // this wave's scratch while the input tile still occupies the strips' space
+  // this wave's scratch: beside the input tile while the folded passes still read it; otherwise the wave's own strip (free until the
+  // attention output; training calls also stage their saved keys / queries there for 16-byte row stores)
+  char* scr = FOLD ? strips + Cfg::SCR + w * 4096 : strip;
   float* red = reinterpret_cast<float*>(smem + Cfg::RED);
   float* cst = reinterpret_cast<float*>(smem + Cfg::CST);
   const int g0 = (int)blockIdx.x * RT;
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
   }
   __syncthreads();                                                // R tile complete
   stamp(a.stamps, 2);
-  if constexpr (SAVE) {                                           // R16: the tile's rows as 16-byte stores (they flow under the passes below)
+  if (SAVE && g.save_r16) {                                       // R16 (read by the row-space weight gradients only): the tile's rows as 16-byte stores
 #pragma unroll 2
     for (int it = 0; it < RT * 4; ++it) {                         // (two in flight at a time: fully unrolled, hipcc hoists all eight reads over the pass's own prefetches)
       const int c = tid + NTH * it, r = c >> 5, k = c & 31, gr = grow(r);
@@ -744,12 +746,10 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
 #pragma unroll
         for (int s = 0; s < RT; ++s) {
           const u32x4 k0 = pack8(acc[s][t], 0), k1 = pack8(acc[s][t], 1);
-          if constexpr (SAVE) {                                   // K2: lane = row; features 16 kk + 4 h .. + 3 and 16 kk + 8 + 4 h .. + 3 of the head
-            if (l31 < sub[s].nr) {
-              us16* kd = F.KV16 + ((size_t)sub[s].row0 + l31) * 512 + 32 * (2 * w + t) + 4 * h;
-              *reinterpret_cast<u32x2*>(kd) = u32x2{k0.x, k0.y}; *reinterpret_cast<u32x2*>(kd + 8) = u32x2{k0.z, k0.w};
-              *reinterpret_cast<u32x2*>(kd + 16) = u32x2{k1.x, k1.y}; *reinterpret_cast<u32x2*>(kd + 24) = u32x2{k1.z, k1.w};
-            }
+          if constexpr (SAVE) {                                   // K2 -> the wave's strip [row][64 features]: lane = row; features 16 kk + 4 h .. + 3 and 16 kk + 8 + 4 h .. + 3 of head t
+            char* kd = strip + (32 * s + l31) * PS + 2 * (32 * t + 4 * h);
+            *reinterpret_cast<u32x2*>(kd) = u32x2{k0.x, k0.y}; *reinterpret_cast<u32x2*>(kd + 16) = u32x2{k0.z, k0.w};
+            *reinterpret_cast<u32x2*>(kd + 32) = u32x2{k1.x, k1.y}; *reinterpret_cast<u32x2*>(kd + 48) = u32x2{k1.z, k1.w};
           }
           S2[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(k0), as_frag(q2f[s][t][0]), splat16(0.f), 0, 0, 0);   // [key row][query]: lane = query
           S2[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(k1), as_frag(q2f[s][t][1]), S2[s], 0, 0, 0);
@@ -790,6 +790,13 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
           for (int k = 0; k < 2; ++k)
             ef[s][t][k] = u32x4{pack2(e[8 * k], e[8 * k + 1]), pack2(e[8 * k + 2], e[8 * k + 3]), pack2(e[8 * k + 4], e[8 * k + 5]), pack2(e[8 * k + 6], e[8 * k + 7])};
         }
+      }
+    }
+    if constexpr (SAVE) {                                         // K2: the strip's rows (128 bytes each) as 16-byte stores (the wave's own LDS writes: program order)
+#pragma unroll 2
+      for (int it = 0; it < 8; ++it) {
+        const int idx = lane + 64 * it, r = idx >> 3, k = idx & 7, gr = grow(r);
+        if (gr >= 0) *reinterpret_cast<u32x4*>(F.KV16 + (size_t)gr * 512 + 64 * w + 8 * k) = *reinterpret_cast<const u32x4*>(strip + r * PS + 16 * k);
       }
     }
     f32x16 vacc[RT][2];
@@ -909,11 +916,15 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
           for (int i = 0; i < 16; ++i) acc[s][t][i] *= g.qscale;
         }
         const u32x4 q0 = pack8(acc[s][t], 0), q1 = pack8(acc[s][t], 1);
-        if constexpr (SAVE) {
-          if (l31 < sub[s].nr) {
-            us16* qd = F.Q16 + ((size_t)sub[s].row0 + l31) * 256 + 32 * (2 * w + t) + 4 * h;
-            *reinterpret_cast<u32x2*>(qd) = u32x2{q0.x, q0.y}; *reinterpret_cast<u32x2*>(qd + 8) = u32x2{q0.z, q0.w};
-            *reinterpret_cast<u32x2*>(qd + 16) = u32x2{q1.x, q1.y}; *reinterpret_cast<u32x2*>(qd + 24) = u32x2{q1.z, q1.w};
+        if constexpr (SAVE) {                                     // Q16 (pre-scaled) -> 2 KB of the wave's scratch [32 rows][32 features] -> 16-byte stores
+          char* qs = scr + 4096 + 2048 * ((2 * s + t) & 1);          // (two slots, alternating: beyond the value scratch's 4 KB)
+          char* qd = qs + l31 * 64 + 2 * (4 * h);
+          *reinterpret_cast<u32x2*>(qd) = u32x2{q0.x, q0.y}; *reinterpret_cast<u32x2*>(qd + 16) = u32x2{q0.z, q0.w};
+          *reinterpret_cast<u32x2*>(qd + 32) = u32x2{q1.x, q1.y}; *reinterpret_cast<u32x2*>(qd + 48) = u32x2{q1.z, q1.w};
+#pragma unroll
+          for (int r2 = 0; r2 < 2; ++r2) {
+            const int idx = lane + 64 * r2, row = idx >> 2, ch = idx & 3;
+            if (row < sub[s].nr) *reinterpret_cast<u32x4*>(F.Q16 + ((size_t)sub[s].row0 + row) * 256 + 32 * (2 * w + t) + 8 * ch) = *reinterpret_cast<const u32x4*>(qs + 64 * row + 16 * ch);
           }
         }
         f32x16 Sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf[s][t][0]), as_frag(q0), kmask, 0, 0, 0);     // S^T[key][row]: lane = row
@@ -940,7 +951,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
         const bf16x8 vf = join(lds_tr16(vp), lds_tr16(vp + 8 * 64));
         acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, splat16(0.f), 0, 0, 0);       // O^T[feature][row]
       }
-    __syncthreads();                                              // every wave is done with the input tile and with its scratch: the strips may be written
+    if constexpr (FOLD) __syncthreads();                          // every wave is done with the input tile (the folded passes' operand): the strips may be written
 #pragma unroll
     for (int s = 0; s < RT; ++s)
 #pragma unroll
@@ -1003,7 +1014,7 @@ int launch_fold_rg(const float* Wq, const float* Wkv, const float* bq, const flo
   return (int)hipGetLastError();
 }
 
-int launch_wide2_rgfwd(const FrontStream& f, const us16* Wf, const float* bf, float qscale, BackArgs& b, int max_nr, hipStream_t stream) {
+int launch_wide2_rgfwd(const FrontStream& f, const us16* Wf, const float* bf, float qscale, BackArgs& b, int max_nr, int save_r16, hipStream_t stream) {
   if (b.B < 1 || b.Nk < 1 || b.Nk > 16 || b.rg_tiles_max < 1 || !b.KV16 || !b.Q2_16 || !b.off || !b.tile_off || !b.tile_desc || !b.inv_nr || !b.part)
     return (int)hipErrorInvalidValue;
   if (max_nr > wide2_max_rows()) return (int)hipErrorInvalidValue;
@@ -1018,7 +1029,7 @@ int launch_wide2_rgfwd(const FrontStream& f, const us16* Wf, const float* bf, fl
     if (!al16(S.bo) || !al16(S.ln_g) || !al16(S.ln_b) || !al16(S.b1) || !al16(S.Wo) || !al16(S.W1) || (i == 1 && !al16(S.R16))) return (int)hipErrorInvalidValue;
     if (save && (!S.O16 || !S.Y16 || !S.XH16 || !S.rstd || !S.mask || !al16(S.O16) || !al16(S.Y16) || !al16(S.XH16))) return (int)hipErrorInvalidValue;
   }
-  RgFwd2Args g; g.f = f; g.b = b; g.qscale = qscale; g.Wf = Wf; g.bf = bf;
+  RgFwd2Args g; g.f = f; g.b = b; g.qscale = qscale; g.Wf = Wf; g.bf = bf; g.save_r16 = save_r16;
   KgChainArgs k; k.b = b; k.bv2 = fold ? bf + 512 : nullptr;      // (unfolded: the values carry their bias)
   k.b.stamps = b.stamps ? b.stamps + (size_t)(b.rg_tiles_max + RT - 1) / RT * 8 * 16 : nullptr;      // (timeline: the KG blocks' rows follow the RG blocks')
   // executed FLOPs per RG row: 128 -> 256, 128 | 256 -> 768, 256 -> 256, 256 -> 512 and both attention directions

@@ -33,24 +33,38 @@
 namespace {
 
 thread_local std::string g_err;
-// testing hook (camo_debug_set_option): -1 = choose the schedule from the configuration, 0 = never take the bf16-resident
-// schedule.  Set by tests that A/B the schedules in one process; never read from the environment.
-int g_opt_sched16 = -1;
-int g_opt_fused = -1;      // likewise for the fused row-tile schedule (fused_rows.h): 0 = never take it
-unsigned long long* g_dbg_stamps = nullptr;   // testing hook: timeline buffer of the fused kernels ([2][blocks][8] 100 MHz ticks)
+// Schedule options: the CALLER's (camo_options_t behind camo_dims_t::options), bound for the duration of one entry-point call.  No
+// option state lives in the library: two engines in one process cannot change each other's schedule.
+constexpr camo_options_t k_default_options = {/*sched16*/ -1, /*fused*/ -1, /*tail17*/ -1, /*fused_rt*/ -1, /*wide2*/ -1, /*fused_one*/ 1, /*wide_front_rt*/ 0,
+                                              /*tailw*/ -1, /*tailw_bwd*/ -1, /*param_space*/ -1, /*tn_big*/ -1, /*fused_variant*/ 1, /*back_lead*/ 1,
+                                              /*tn_balance*/ 1, /*tn_kcap*/ 0, /*tn_exp*/ 0, /*exp*/ 0, /*fused_save*/ 0, /*tail_skip_arrival*/ 0};
+static thread_local const camo_options_t* t_opt = &k_default_options;
+struct OptScope {                     // binds the caller's options (and the other translation units' per-call copies) for one entry-point call
+  const camo_options_t* prev;
+  explicit OptScope(const camo_dims_t* d) : prev(t_opt) {
+    t_opt = (d && d->options) ? d->options : &k_default_options;
+    g_back_lead_mode = t_opt->back_lead; g_gemm16_balance = t_opt->tn_balance; g_gemm16_tn_kcap = t_opt->tn_kcap; g_gemm16_exp = t_opt->tn_exp;
+    g_gemm16_tn_big = t_opt->tn_big;
+    if (d && d->options && d->options->tail_skip_arrival) { g_tail_debug_skip = d->options->tail_skip_arrival; d->options->tail_skip_arrival = 0; }
+  }
+  ~OptScope() { t_opt = prev; }
+};
+#define g_opt_sched16 (t_opt->sched16)
+#define g_opt_fused (t_opt->fused)
+#define g_opt_param_space (t_opt->param_space)
+#define g_opt_tail17 (t_opt->tail17)
+#define g_opt_fused_variant (t_opt->fused_variant)
+#define g_opt_fused_rt (t_opt->fused_rt)
+#define g_opt_wide2 (t_opt->wide2)
+#define g_opt_fused_one (t_opt->fused_one)
+#define g_opt_wide_front_rt (t_opt->wide_front_rt)
+#define g_opt_tailw_bwd (t_opt->tailw_bwd)
+#define g_opt_tailw (t_opt->tailw)
+#define g_opt_exp (t_opt->exp)
+#define g_opt_fused_save (t_opt->fused_save)
+unsigned long long* g_dbg_stamps = nullptr;   // developer timeline buffer of the fused kernels (camo_debug_set_stamps; like camo_prof_*: a profiling facility, not a schedule option)
 int g_dbg_stamp_blocks = 0;
-int g_opt_param_space = -1;                   // -1 by size, 0 / 1: the fused backward's parameter-space weight gradients (backward_nodes17)
-int g_opt_tail17 = -1;                        // 0 = never take the one-launch tail (misc.hip, tail_fused_kernel)
-int g_opt_fused_variant = 1;                  // developer A/B of the fused kernels' weight streaming (fused_rows.h)
-int g_opt_fused_rt = -1;     // wide row tiles (fused_wide.hip): -1 = by batch size, 0 = never, 1 / 2 / 4 = that many 32-row tiles per block
-int g_opt_wide2 = -1;        // the RG rows' forward on 64-row half-blocks, two per CU (fused_wide2.hip): -1 = by size (inference calls), 0 = never, 1 = whenever the shape allows
-int g_opt_fused_one = 1;     // wide tiles: 1 = the RG rows' forward as ONE launch behind the KG rows' front half (rgfwd_kernel), 0 = front + back launches
 static thread_local bool t_tailw_bwd_planes = false;   // set by a training forward that built the tail's transposed planes (this call's workspace)
-int g_opt_wide_front_rt = 0;                  // developer A/B: > 0 forces the wide front half of training calls with that many sub-tiles per block, < 0 never
-int g_opt_tailw_bwd = -1;                     // 0: the tail's backward stays on the four GEMM launches (developer A/B)
-int g_opt_tailw = -1;        // the per-sample tail of wide-tile inference calls as one launch (tail_wide.h): 0 = never
-int g_opt_exp = 0;           // developer experiments inside the wide kernels (timing only)
-int g_opt_fused_save = 0;  // 1 = inference calls of the fused schedule also write what a backward would need (tests read it back)
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 int fail_hip(int e, const char* where) {
@@ -718,7 +732,11 @@ int forward_nodes17(const camo_dims_t& d, const float* const* P, const float* rg
   ba.part = f.part; ba.tickets = w.tickets; ba.max_splits = (max_nr + 63) / 64;
   ba.drop = drop; ba.save = save ? 1 : 0; ba.exp = g_opt_exp;
   ba.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)g_dbg_stamp_blocks * 8 : nullptr;
-  if (w2) CK(launch_wide2_rgfwd(fa.s[0], f.Wf_rg, f.bf_rg, fa.qscale, ba, max_nr, st), "fused forward, RG rows in one launch (64-row half-blocks)");
+  // (R16 is read by the row-space form of the projections' weight gradients only: the same predicate as backward_nodes17's; tests that
+  // read it back run an inference call with fused_save)
+  const bool param_space_bwd = g_opt_param_space < 0 ? T >= 10240 : g_opt_param_space > 0;
+  if (w2) CK(launch_wide2_rgfwd(fa.s[0], f.Wf_rg, f.bf_rg, fa.qscale, ba, max_nr, (!param_space_bwd || g_opt_fused_save != 0) ? 1 : 0, st),
+             "fused forward, RG rows in one launch (64-row half-blocks)");
   else if (one) CK(launch_wide_rgfwd(fa.s[0], fa.qscale, ba, rt, max_nr, st), "fused forward, RG rows in one launch (wide tiles)");
   else if (rt) CK(launch_wide_back(ba, rt, max_nr, st), "fused forward, back half (wide tiles)");
   else CK(launch_fused_back(ba, g_opt_fused_variant, st), "fused forward, back half");
@@ -939,6 +957,7 @@ int camo_abi_version(void) { return CAMO_ABI_VERSION; }
 const char* camo_last_error(void) { return g_err.c_str(); }
 
 size_t camo_workspace_bytes(const camo_dims_t* dims, int32_t B, int32_t T, int32_t Nk) {
+  OptScope opt_scope(dims);
   if (check_dims(dims, B, T, Nk)) return 0;
   return carve(*dims, B, T, Nk, nullptr).bytes;
 }
@@ -1100,6 +1119,7 @@ int camo_forward(const camo_dims_t* dims, const float* const* params, const floa
                  const float* kg, int32_t B, int32_t T, int32_t Nk, int32_t max_nr, void* workspace,
                  size_t workspace_bytes, float* outs, float* attn_rg2kg, float* attn_kg2rg, int32_t training,
                  uint64_t seed, int32_t precision, int32_t flags, void* stream) {
+  OptScope opt_scope(dims);
   return forward_impl(dims, params, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
                       attn_rg2kg, attn_kg2rg, training, seed, precision, flags, stream, nullptr);
 }
@@ -1109,6 +1129,7 @@ int camo_forward_cached(const camo_dims_t* dims, const float* const* params, con
                         size_t workspace_bytes, float* outs, float* attn_rg2kg, float* attn_kg2rg, int32_t training,
                         uint64_t seed, int32_t precision, int32_t flags, void* shadows, int32_t shadows_valid, int32_t* shadows_state,
                         void* stream) {
+  OptScope opt_scope(dims);
   if (shadows_state) *shadows_state = 0;
   if (shadows_valid && !shadows) return fail(CAMO_E_ARG, "shadows_valid without a shadow buffer");
   // A call that saves for camo_backward would leave the backward's transposed shadows in the caller's buffer, where camo_backward
@@ -1269,6 +1290,7 @@ int camo_backward(const camo_dims_t* dims, const float* const* params, float* co
                   int32_t T, int32_t Nk, int32_t max_nr, void* workspace, size_t workspace_bytes, const float* outs,
                   const float* d_outs, int32_t d_outs_pre_activation, int32_t training, uint64_t seed, int32_t precision,
                   int32_t flags, void* stream) {
+  OptScope opt_scope(dims);
   return backward_impl(dims, params, grads, rg, rg_offsets, batch_desc, kg, B, T, Nk, max_nr, workspace, workspace_bytes, outs,
                        d_outs, d_outs_pre_activation, training, seed, precision, flags, stream, false);
 }
@@ -1285,6 +1307,7 @@ int camo_forward_loss_backward(const camo_dims_t* dims, const float* const* para
                                const int64_t* y, const float* e, const float* s, float* outs, float* loss_terms, int32_t* pred,
                                int32_t training, uint64_t seed, int32_t precision, void* tail_event, void* shadows,
                                int32_t shadows_valid, void* stream) {
+  OptScope opt_scope(dims);
   if (!dims || !grads || !y || !e || !s || !outs || !loss_terms) return fail(CAMO_E_ARG, "null pointer argument");
   if (shadows_valid && !shadows) return fail(CAMO_E_ARG, "shadows_valid without a shadow buffer");
   // external shadows are used by the fused schedule only; whether the call takes it is known from its arguments
@@ -1355,6 +1378,7 @@ int camo_grad_sumsq(const float* g, size_t n, float* sumsq, void* stream) {
 }
 
 size_t camo_shadow_bytes(const camo_dims_t* dims) {
+  OptScope opt_scope(dims);
   if (!dims || !fused17_dims(*dims)) return 0;
   return shadow_carve(nullptr).bytes;
 }
@@ -1362,6 +1386,7 @@ size_t camo_shadow_bytes(const camo_dims_t* dims) {
 int camo_clip_adamw_shadows(const camo_dims_t* dims, const float* const* params, float* p, float* g, float* m, float* v, size_t n,
                             float* sumsq, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                             int32_t step, int32_t zero_grads, void* shadows, void* stream) {
+  OptScope opt_scope(dims);
   if (!dims || !params || !p || !g || !m || !v || !sumsq || !shadows || n == 0) return fail(CAMO_E_ARG, "null pointer or empty buffer");
   if (step < 1) return fail(CAMO_E_ARG, "step is 1-based");
   if (!fused17_dims(*dims)) return fail(CAMO_E_UNSUPPORTED, "weight shadows exist for the fused schedule's configuration only");
@@ -1446,27 +1471,24 @@ int camo_debug_gemm16(const void* A16, int32_t lda, const void* B16, int32_t ldb
   return 0;
 }
 
-int camo_debug_set_option(const char* name, int32_t value) {
-  if (!name) return fail(CAMO_E_ARG, "option name is null");
-  if (std::strcmp(name, "sched16") == 0) { g_opt_sched16 = value; return 0; }
-  if (std::strcmp(name, "fused") == 0) { g_opt_fused = value; return 0; }
-  if (std::strcmp(name, "fused_save") == 0) { g_opt_fused_save = value; return 0; }
-  if (std::strcmp(name, "fused_rt") == 0) { g_opt_fused_rt = value; return 0; }
-  if (std::strcmp(name, "exp") == 0) { g_opt_exp = value; return 0; }
-  if (std::strcmp(name, "fused_one") == 0) { g_opt_fused_one = value; return 0; }
-  if (std::strcmp(name, "wide2") == 0) { g_opt_wide2 = value; return 0; }
-  if (std::strcmp(name, "tailw") == 0) { g_opt_tailw = value; return 0; }
-  if (std::strcmp(name, "tailw_bwd") == 0) { g_opt_tailw_bwd = value; return 0; }
-  if (std::strcmp(name, "wide_front_rt") == 0) { g_opt_wide_front_rt = value; return 0; }
-  if (std::strcmp(name, "tail_skip_arrival") == 0) { g_tail_debug_skip = value; return 0; }
-  if (std::strcmp(name, "fused_variant") == 0) { g_opt_fused_variant = value; return 0; }
-  if (std::strcmp(name, "tail17") == 0) { g_opt_tail17 = value; return 0; }
-  if (std::strcmp(name, "back_lead") == 0) { g_back_lead_mode = value; return 0; }
-  if (std::strcmp(name, "tn_balance") == 0) { g_gemm16_balance = value; return 0; }
-  if (std::strcmp(name, "tn_kcap") == 0) { g_gemm16_tn_kcap = value; return 0; }
-  if (std::strcmp(name, "tn_exp") == 0) { g_gemm16_exp = value; return 0; }
-  if (std::strcmp(name, "param_space") == 0) { g_opt_param_space = value; return 0; }
-  if (std::strcmp(name, "tn_big") == 0) { g_gemm16_tn_big = value; return 0; }
+int camo_options_init(camo_options_t* o) {
+  if (!o) return fail(CAMO_E_ARG, "options is null");
+  *o = k_default_options;
+  return 0;
+}
+
+int camo_options_set(camo_options_t* o, const char* name, int32_t value) {
+  if (!o || !name) return fail(CAMO_E_ARG, "options or option name is null");
+  struct Field { const char* name; int32_t camo_options_t::*m; };
+  static const Field fields[] = {
+      {"sched16", &camo_options_t::sched16}, {"fused", &camo_options_t::fused}, {"tail17", &camo_options_t::tail17}, {"fused_rt", &camo_options_t::fused_rt},
+      {"wide2", &camo_options_t::wide2}, {"fused_one", &camo_options_t::fused_one}, {"wide_front_rt", &camo_options_t::wide_front_rt}, {"tailw", &camo_options_t::tailw},
+      {"tailw_bwd", &camo_options_t::tailw_bwd}, {"param_space", &camo_options_t::param_space}, {"tn_big", &camo_options_t::tn_big},
+      {"fused_variant", &camo_options_t::fused_variant}, {"back_lead", &camo_options_t::back_lead}, {"tn_balance", &camo_options_t::tn_balance},
+      {"tn_kcap", &camo_options_t::tn_kcap}, {"tn_exp", &camo_options_t::tn_exp}, {"exp", &camo_options_t::exp}, {"fused_save", &camo_options_t::fused_save},
+      {"tail_skip_arrival", &camo_options_t::tail_skip_arrival}};
+  for (const Field& f : fields)
+    if (std::strcmp(name, f.name) == 0) { o->*(f.m) = value; return 0; }
   return fail(CAMO_E_ARG, std::string("unknown option ") + name);
 }
 
@@ -1509,6 +1531,7 @@ int camo_prof_end(double* gemm_ms, int32_t* gemm_launches, double* gemm_flops) {
 }
 
 int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int32_t Nk, const char* name) {
+  OptScope opt_scope(dims);
   if (check_dims(dims, B, T, Nk) || !name) return -1;
   char* base = reinterpret_cast<char*>(4096);
   const Ws w = carve(*dims, B, T, Nk, base);

@@ -60,8 +60,8 @@ struct Gemm16Batch {
 };
 
 // Returns hipError_t as int; hipErrorInvalidValue for an unsupported problem.
-extern int g_gemm16_exp;
-extern int g_gemm16_tn_big;          // developer A/B: -1 by size, 0 never, 1 always (weight-gradient-only launches)
-extern int g_gemm16_balance;         // developer A/B: 0 = plain contiguous XCD remap
-extern int g_gemm16_tn_kcap;         // developer A/B: > 0 pins the split-K depth (64-row tiles per block) of weight-gradient problems
+extern thread_local int g_gemm16_exp;
+extern thread_local int g_gemm16_tn_big;          // developer A/B: -1 by size, 0 never, 1 always (weight-gradient-only launches)
+extern thread_local int g_gemm16_balance;         // developer A/B: 0 = plain contiguous XCD remap
+extern thread_local int g_gemm16_tn_kcap;         // developer A/B: > 0 pins the split-K depth (64-row tiles per block) of weight-gradient problems
 int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream);

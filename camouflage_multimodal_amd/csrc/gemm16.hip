@@ -751,8 +751,8 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
-int g_gemm16_exp = 0;
-int g_gemm16_tn_big = -1;             // developer A/B ("tn_big"): -1 by size, 0 never, 1 whenever the launch is weight gradients only
+thread_local int g_gemm16_exp = 0;
+thread_local int g_gemm16_tn_big = -1;             // developer A/B ("tn_big"): -1 by size, 0 never, 1 whenever the launch is weight gradients only
 static int launch_tnbig(Gemm16Batch& gb, hipStream_t stream) {
   int total = 0;
   static const int kcaps[] = {512, 384, 256, 192, 128, 96, 64, 48, 32, 24, 16, 12, 8, 6, 4};
@@ -790,8 +790,8 @@ static int launch_tnbig(Gemm16Batch& gb, hipStream_t stream) {
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }
-int g_gemm16_balance = 1;             // developer A/B ("tn_balance")
-int g_gemm16_tn_kcap = 0;             // developer A/B (camo_debug_set_option "tn_kcap"): > 0 pins the split-K depth
+thread_local int g_gemm16_balance = 1;             // developer A/B ("tn_balance")
+thread_local int g_gemm16_tn_kcap = 0;             // developer A/B (camo_debug_set_option "tn_kcap"): > 0 pins the split-K depth
 int launch_gemm16_batch(Gemm16Batch& gb, hipStream_t stream) {
   if (gb.n <= 0) return 0;
   if (gb.n > GEMM16_MAXP) return (int)hipErrorInvalidValue;

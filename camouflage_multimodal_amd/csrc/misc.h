@@ -73,7 +73,7 @@ struct TailFusedArgs {
   unsigned long long* stamps;                               // developer timeline (null in product calls)
   int debug_skip;                                           // (launcher) developer hook: block id + 1 that skips its first arrival
 };
-extern int g_tail_debug_skip;
+extern thread_local int g_tail_debug_skip;      // (set per call from the caller's camo_options_t: fusion_abi.hip, OptScope)
 int tail_fused_ok(int B, int C);
 int launch_tail_fused(const TailFusedArgs& a, hipStream_t stream);
 int tail_timeouts(unsigned int* out);

@@ -1531,7 +1531,7 @@ int launch_heads_loss(const float* hid, const HeadsOut& hp, const long long* y, 
 
 // developer hook (camo_debug_set_option "tail_skip_arrival" = block id + 1): that block of the NEXT one-launch tail skips its first
 // arrival, so the others' wait times out deterministically -- the only way to test the give-up path without sharing the GPU
-int g_tail_debug_skip = 0;
+thread_local int g_tail_debug_skip = 0;
 
 int tail_fused_ok(int B, int C) {
   // every block of the launch waits for the other 63: all of them must be resident at once, one per CU (1024 threads, 148 KB of

@@ -78,14 +78,37 @@ class Batch:
         self.B, self.T, self.Nk, self.max_nr = len(nrs), rg.shape[0], kg.shape[1], max(nrs)
 
 
+# Schedule options are per ENGINE (camo_options_t, owned here, reached by the library through dims.options).  Tests and developer
+# tools that want "the whole process" on one schedule go through set_option_all: every live engine + the defaults of later ones.
+_LIVE_ENGINES = weakref.WeakSet()
+_OPTION_DEFAULTS = {}
+
+
+def set_option_all(name, value):
+    """Set one schedule option (include/camo_fusion.h, camo_options_t) on every live engine and for engines created from now on.
+    Returns 0, or raises CamoError for an unknown name."""
+    if name not in _lib.OPTION_NAMES:
+        raise _lib.CamoError(f"unknown option {name}")
+    if name == "tail_skip_arrival":
+        raise _lib.CamoError("tail_skip_arrival is a one-shot hook of ONE engine's next call: use engine.set_option")
+    _OPTION_DEFAULTS[name] = int(value)
+    for eng in list(_LIVE_ENGINES):
+        eng.set_option(name, value)
+    return 0
+
+
 class FusionEngine:
     def __init__(self, module):
         self._mod = weakref.ref(module)
         c = module.config
         self.cross = c["fusion_type"] == "cross_attention"
         self.slots = CROSS_SLOTS if self.cross else LATE_SLOTS
+        self.options = _lib.default_options()                  # this engine's schedule options: nothing of the kind lives in the library
         self.dims = _lib.CamoDims(c["rg_dim"], c["kg_dim"], c["hidden_dim"], c["num_heads"], c["num_classes"],
-                                  _lib.FUSION_CROSS_ATTENTION if self.cross else _lib.FUSION_LATE, c["dropout"])
+                                  _lib.FUSION_CROSS_ATTENTION if self.cross else _lib.FUSION_LATE, c["dropout"], C.pointer(self.options))
+        for k, v in _OPTION_DEFAULTS.items():
+            setattr(self.options, k, v)
+        _LIVE_ENGINES.add(self)
         self.out_width = 2 * c["num_classes"] + 2
         self.flat_params = None
         self.flat_grads = None
@@ -204,6 +227,10 @@ class FusionEngine:
         """Data parallelism: give every rank its own dropout mask stream (the mask index of an element is its LOCAL
         position in the rank's packed batch, so identically seeded ranks would draw identical masks)."""
         self._seed_base = (int(torch.initial_seed()) ^ ((int(rank) + 1) * 0xD1B54A32D192ED03)) & 0xFFFFFFFFFFFFFFFF
+
+    def set_option(self, name, value):
+        """One schedule option of THIS engine (developer / test switch; product code leaves the defaults)."""
+        _lib.check(_lib.lib().camo_options_set(C.byref(self.options), name.encode(), int(value)), "camo_options_set")
 
     def make_batch(self, rg_packed, nrs, kg):
         """rg_packed [T, rg_dim], nrs: host ints, kg [B, Nk, kg_dim] -> Batch (device, fp32, contiguous)."""

@@ -18,7 +18,7 @@
  *  - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*); no
  *    allocation, no synchronisation, and the environment is never read.  The only
  *    process-global state is the two testing/measurement hooks at the end of this
- *    file (camo_debug_set_option, camo_prof_begin/end); without them the calls are
+ *    file (camo_options_t, camo_prof_begin/end); without them the calls are
  *    graph-capturable and thread-compatible;
  *  - return value: 0 on success, a negative CAMO_E_* code otherwise; no C++
  *    exception crosses the boundary; camo_last_error() gives a thread-local
@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CAMO_ABI_VERSION 9
+#define CAMO_ABI_VERSION 10
 
 enum {
   CAMO_OK = 0,
@@ -50,10 +50,32 @@ enum { CAMO_PREC_F32 = 0,  /* f32-input MFMA: bit-faithful fp32 FMA chains      
 
 /* Model dimensions = the keys build_multimodal_model() reads
  * (models/multimodal/fusion_model.py:249-259). */
+/* Schedule options of ONE caller (engine): which of the library's kernel schedules its calls take where several compute the same
+ * function.  Caller-owned, reached through camo_dims_t::options -- the library keeps no option state of its own, so two engines in
+ * one process (or two threads) cannot change each other's schedule.  Product callers leave every field at its default
+ * (camo_options_init; options == NULL means the same): the schedule then follows from the call's arguments alone.
+ * Tests and developer tools set fields by name (camo_options_set) to run two schedules of the same call in one process:
+ *   sched16  -1 choose from the configuration, 0 never take the bf16-resident schedule
+ *   fused    -1 choose from the configuration, 0 never take the fused row-tile schedule
+ *   tail17   -1 the per-sample tail runs as one launch where the fused schedule does (B <= 16; groups up to 48), 0 never
+ *   fused_rt -1 wide row tiles by size, 0 never, 1 / 2 / 4 that many 32-row tiles per 8-wave block (csrc/fused_wide.hip)
+ *   wide2    -1 the 64-row half-block forward by size (csrc/fused_wide2.hip), 0 never, 1 whenever the shape allows
+ *   fused_one, wide_front_rt, tailw, tailw_bwd, param_space, tn_big, fused_variant, back_lead, tn_balance, tn_kcap, tn_exp, exp: developer A/Bs
+ *   fused_save  1 makes inference calls of the fused schedule also write the tensors a backward would read (names for
+ *            camo_debug_ws_offset: R16 G16 Q16 Q2_16 KV16 KV2_16 O16 O2_16 Y16 Y2_16 XH16 XH2_16 rstd1 rstd2 mask1 mask2 lse2 X16
+ *            Wqkv_rg W1s Ymean H1mean Y2mean H2mean)
+ *   tail_skip_arrival  block id + 1 of the NEXT one-launch tail that skips its first arrival (the give-up path's test); one shot:
+ *            the call that consumes it writes 0 back. */
+typedef struct camo_options {
+  int32_t sched16, fused, tail17, fused_rt, wide2, fused_one, wide_front_rt, tailw, tailw_bwd, param_space, tn_big, fused_variant,
+          back_lead, tn_balance, tn_kcap, tn_exp, exp, fused_save, tail_skip_arrival;
+} camo_options_t;
+
 typedef struct camo_dims {
   int32_t rg_dim, kg_dim, hidden_dim, num_heads, num_classes;
   int32_t fusion_type; /* CAMO_FUSION_* */
   float dropout;
+  camo_options_t* options;   /* NULL: defaults.  Caller-owned; read at every call that takes these dims */
 } camo_dims_t;
 
 /* Parameter table: an array of CAMO_NPARAMS_* device pointers in the order of the
@@ -256,15 +278,9 @@ int camo_debug_gemm16(const void* A16, int32_t lda, const void* B16, int32_t ldb
                       void* C16, int32_t ldc16, const float* bias, const float* res, int32_t ldr, float* bias_grad,
                       int32_t M, int32_t N, int32_t K, int32_t flags, void* stream);
 int64_t camo_debug_ws_offset(const camo_dims_t* dims, int32_t B, int32_t T, int32_t Nk, const char* name);
-/* camo_debug_set_option: lets a test run two schedules of the same call in one process.
- *   "sched16": -1 (default) choose from the configuration, 0 never take the bf16-resident schedule;
- *   "fused":   -1 (default) choose from the configuration, 0 never take the fused row-tile schedule;
- *   "tail17":  -1 (default) the per-sample tail runs as one launch where the fused schedule does (B <= 16), 0 never;
- *   "fused_variant": developer A/B of the fused kernels' weight streaming (0, 1 = default, 2);
- *   "fused_save": 1 makes inference calls of the fused schedule also write the tensors a backward would read
- *              (names for camo_debug_ws_offset: R16 G16 Q16 Q2_16 KV16 KV2_16 O16 O2_16 Y16 Y2_16 XH16 XH2_16 rstd1 rstd2
- *              mask1 mask2 lse2 X16 Wqkv_rg W1s Ymean H1mean Y2mean H2mean). */
-int camo_debug_set_option(const char* name, int32_t value);
+/* camo_options_init: every field to its default.  camo_options_set: one field by name (CAMO_E_ARG for an unknown name). */
+int camo_options_init(camo_options_t* options);
+int camo_options_set(camo_options_t* options, const char* name, int32_t value);
 /* camo_debug_set_stamps: developer timeline of the fused kernels.  buf = device buffer of 2 * blocks_per_kernel * 8 uint64
  * (or NULL to switch it off): wave 0 of every block stores the 100 MHz wall clock at its phase boundaries. */
 int camo_debug_set_stamps(void* buf, int32_t blocks_per_kernel);

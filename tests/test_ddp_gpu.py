@@ -88,7 +88,7 @@ def _poison_worker(rank, world, port, q, reducer):
         snaps, norms = [], []
         for step in range(3):
             if step == 1 and rank == 1:
-                _lib.check(_lib.lib().camo_debug_set_option(b"tail_skip_arrival", 6), "hook")
+                m._engine.set_option("tail_skip_arrival", 6)     # (one shot, this engine's next call)
             _step(tr, mine, step)
             torch.cuda.synchronize()
             snaps.append(m._engine.flat_params.cpu().numpy().copy()); norms.append(float(tr.opt.grad_norm().item()))

@@ -359,7 +359,7 @@ def test_tail_timeout_is_not_applied(kg_real):
     torch.cuda.synchronize()
     before = m._engine.flat_params.clone()
     t0 = _lib.tail_timeouts()
-    _lib.check(_lib.lib().camo_debug_set_option(b"tail_skip_arrival", 6), "hook")
+    m._engine.set_option("tail_skip_arrival", 6)                     # (one shot, this engine's next call)
     terms, _ = tr.step(rg, nrs, kg, y, e, s)
     torch.cuda.synchronize()
     assert _lib.tail_timeouts() > t0

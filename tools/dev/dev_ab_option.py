@@ -19,7 +19,7 @@ for B in sizes:
         losses = [float(tr.step(*bt[i % 4])[0].sum()) for i in range(12)]
         for i in range(20): tr.step(*bt[i % 4])
         torch.cuda.synchronize()
-        n = 1500 if B <= 16 else 400
+        n = 1500 if B <= 16 else (400 if B <= 64 else 100)
         t0 = time.perf_counter()
         for i in range(n): tr.step(*bt[i % 4])
         torch.cuda.synchronize()

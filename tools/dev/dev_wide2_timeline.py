@@ -1,4 +1,4 @@
-"""Developer aid: per-wave phase timeline of rgfwd2_kernel (csrc/fused_wide2.hip).   python tools/dev/dev_wide2_timeline.py B [option=value ...]"""
+"""Developer aid: per-wave phase timeline of rgfwd2_kernel (csrc/fused_wide2.hip).   python tools/dev/dev_wide2_timeline.py B [train] [option=value ...]"""
 import os
 import sys
 
@@ -10,7 +10,8 @@ from bench import make_batches  # noqa: E402
 from camouflage_multimodal_amd import NativeTrainer, _lib, build_multimodal_model  # noqa: E402
 
 B = int(sys.argv[1])
-model = build_multimodal_model({}).cuda().set_precision("bf16").eval()
+train = "train" in sys.argv[2:]
+model = build_multimodal_model({}).cuda().set_precision("bf16").train(train)
 tr = NativeTrainer(model)
 b0 = make_batches(1, B, 0)[0]
 rg, nrs, kg = torch.from_numpy(b0[0]).cuda(), b0[1], torch.from_numpy(b0[2]).cuda()
@@ -21,7 +22,11 @@ grid = (sum(nrs) // 32 + B + 1) // 2                         # rgfwd2's grid; th
 blocks = grid + (B + 1) // 2 + 8
 NB = 16 * (1 << int(np.ceil(np.log2(blocks))))                 # stamp slots per kernel (16 per wave x 8 wave rows per block)
 buf = torch.zeros(5 * NB * 8, dtype=torch.int64, device="cuda")
-step = lambda: tr.evaluate(rg, nrs, kg)
+if train:
+    yl, el, sl = (torch.from_numpy(x).cuda() for x in b0[3:])
+    step = lambda: tr.step(rg, nrs, kg, yl, el, sl)
+else:
+    step = lambda: tr.evaluate(rg, nrs, kg)
 for i in range(5):
     step()
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
@@ -29,7 +34,7 @@ t0.record()
 for i in range(10):
     step()
 t1.record(); torch.cuda.synchronize()
-print(f"B = {B}, T = {sum(nrs)}: eval forward {t0.elapsed_time(t1) / 10 * 1e3:.1f} us per call (unstamped)")
+print(f"B = {B}, T = {sum(nrs)}: {'training step' if train else 'eval forward'} {t0.elapsed_time(t1) / 10 * 1e3:.1f} us per call (unstamped)")
 _lib.lib().camo_debug_set_stamps(buf.data_ptr(), NB)
 step()
 torch.cuda.synchronize()
