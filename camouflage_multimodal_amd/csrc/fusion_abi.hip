@@ -560,13 +560,17 @@ static int wide_rt(int T, int max_nr, bool save = false) {
 }
 
 // The RG rows' whole forward in one launch of 64-row half-blocks, two independent blocks per CU, + the KG rows' launch behind it
-// (fused_wide2.hip).  By size from 13 312 packed rows (where the 8-wave wide kernels start too), for inference AND training calls
-// (the saving / dropout variants write the backward's saved set); a forced fused_rt selects the 8-wave / 32-row kernels.
+// (fused_wide2.hip).  By size for inference AND training calls (the saving / dropout variants write the backward's saved set); a forced
+// fused_rt selects the 8-wave / 32-row kernels.
 static bool wide2_taken(int T, int max_nr, bool save, bool dropping) {
-  (void)save; (void)dropping;
+  (void)dropping;
   if (g_opt_wide2 == 0 || g_opt_fused_one == 0 || max_nr > wide2_max_rows()) return false;
   if (g_opt_wide2 > 0) return true;
-  return g_opt_fused_rt < 0 && g_opt_wide_front_rt == 0 && T >= 13312;
+  // training calls from 57 344 rows: their blocks are twice as long (the saved set, the dropout hashes), so the second round of blocks
+  // must be nearly full before they beat the 32-row back half (measured, ms per step without / with: B = 96 0.517 / 0.540, B = 128
+  // 0.637 / 0.621, B = 192 0.864 / 0.804, B = 256 1.076 / 0.979)
+  // inference calls from 10 240 rows (eval forward, us without / with: B = 16 59 / 66, B = 24 72.5 / 69.8, B = 32 77 / 71, B = 48 101 / 82)
+  return g_opt_fused_rt < 0 && g_opt_wide_front_rt == 0 && T >= (save ? 57344 : 10240);
 }
 
 // Training calls (save): the front half alone on wide blocks -- 64-row blocks from 10 240 packed rows (front 21 -> 17 us at B = 24,

@@ -338,7 +338,7 @@ def _training_step_shape_envelope(nrs, nk, pseed, fused_opts, wide2):
     assert np.isfinite(t2n(outs)).all() and all(np.isfinite(v).all() for v in grads.values())
     # (tail units whose pre-activation is within 5e-5 of the ReLU threshold may land on either side: helpers.py bounds how many)
     ref, near, flipped = oracle_step_at_relu_thresholds(
-        lambda: bf16_oracle(cfg, OP.make_params(cfg, pseed), nrs, wide2 or sum(nrs) >= 13312),      # (by size the 64-row forward from 13 312 packed rows)
+        lambda: bf16_oracle(cfg, OP.make_params(cfg, pseed), nrs, wide2 or sum(nrs) >= 57344),      # (by size training calls take the 64-row forward from 57 344 packed rows)
         lambda o: FO.train_step(o, FO.AdamW(o.p), rgl, kg, y, e, s, training=True, seed=dseed), grads)
     if near:
         print("tail units at the ReLU threshold (site, sample, unit, pre-activation):", near, "taken flipped:", flipped)

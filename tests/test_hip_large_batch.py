@@ -120,8 +120,8 @@ def _train_step_vs_bf16_oracle(B, pseed, kg_real, nrs=None):
     torch.cuda.synchronize()
     grads = {k: t2n(p.grad).copy() for k, p in m.named_parameters()}
     assert np.isfinite(t2n(outs)).all() and all(np.isfinite(v).all() for v in grads.values())
-    # (training calls of this size run their forward on the 64-row half-blocks: the oracle takes that kernel's flash-block partition)
-    ref = oracle_batch_step(lambda: bf16_oracle(cfg, OP.make_params(cfg, pseed), nrs, wide2=True), rg, kg, y, e, s, dseed, grads)
+    # (training calls from 57 344 packed rows run their forward on the 64-row half-blocks: the oracle then takes that kernel's flash-block partition)
+    ref = oracle_batch_step(lambda: bf16_oracle(cfg, OP.make_params(cfg, pseed), nrs, wide2=sum(nrs) >= 57344), rg, kg, y, e, s, dseed, grads)
     if ref["near"]:
         print(f"B = {B}: tail units at the ReLU threshold (site, sample, unit, pre-activation): {ref['near']}; taken flipped: {ref['flips']}")
     assert_close(t2n(outs), outs6(ref["outs"]), 5e-4, 0, "outputs vs the bf16-operand oracle")
@@ -161,3 +161,13 @@ def test_training_step_b100_every_by_size_path_against_bf16_oracle(kg_real):
     missing = [k for k in named if k not in got]
     assert not missing, f"tensors without weight in the gradient (cannot be judged): {missing}"
     assert all(got[k] < 1e-2 for k in named), {k: got[k] for k in named}
+
+
+def test_training_step_b124_takes_the_64row_forward_by_size(kg_real):
+    """B = 124 of the real histogram (T ~ 59.6 k >= 57 344): by size the training call's forward is rgfwd2_kernel + kgchain_kernel in their saving +
+    dropout variants (csrc/fused_wide2.hip) with two blocks per CU, in front of the same backward kernels -- against the oracle's
+    train step with the kernel's flash-block partition, same bounds."""
+    B = 124
+    nrs, _, _ = _histogram_batch(B, 16, kg_real)
+    assert sum(nrs) >= 57344, sum(nrs)
+    _train_step_vs_bf16_oracle(B, 6, kg_real)
