@@ -50,6 +50,14 @@ __device__ __forceinline__ float drop_mult(const DropCfg& d, uint32_t site, uint
   return x >= d.thr ? d.scale : 0.0f;
 }
 
+// lane `i` of the VGPR `v` <- the wave-uniform 32-bit value `s`: one v_writelane_b32.  This hipcc declares no writelane builtin, so
+// the LLVM intrinsic is bound by its name -- NOT inline assembly: gfx950 wants two wait states between a VALU instruction writing an
+// SGPR (the ballot's v_cmp) and a VALU instruction reading it, which the compiler's hazard pass provides for its own instructions only.
+// Used to hand the halves of 16 ballots to 16 lanes: a `lane == i` select per ballot keeps 16 compare masks and 16 ballots (64 SGPRs)
+// alive instead.
+extern "C" __device__ int camo_writelane_i32(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+#define SET_LANE(v, s, i) (v) = (uint32_t)camo_writelane_i32((int)(s), (i), (int)(v))
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256, OCC) void back_kernel(const BackArgs a) {
         colsum += v;
         if (a.save) {
           const unsigned long long bal = __ballot(v > 0.f);
-          if (lane == i) { wlo = (uint32_t)bal; whi = (uint32_t)(bal >> 32); }
+          SET_LANE(wlo, (uint32_t)bal, i); SET_LANE(whi, (uint32_t)(bal >> 32), i);      // lane i <- the ballot's halves (common.h)
         }
       }
       colsum += __shfl_xor(colsum, 32, 64);

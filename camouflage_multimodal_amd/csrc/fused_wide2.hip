@@ -168,6 +168,21 @@ __device__ __forceinline__ f32x16 feature_vec(const float* c, int h) {
 
 struct Sub { int b; int row0; int nr; float inv_n; };          // one 32-row sub-tile (wave-uniform)
 
+// A pointer of the kernel's argument block re-read from the kernarg segment AT ITS POINT OF USE (the block is the kernel's only
+// argument: byte offset = offsetof in it).  The training variants write nine saved tensors, each through its own 64-bit pointer, once;
+// held in SGPRs from the kernel's entry those pointers overflow the scalar file and come back as v_readlane / v_writelane traffic all
+// over the kernel.  The opaque offset keeps hipcc from hoisting the load back to the entry.
+template <class T>
+__device__ __forceinline__ T* karg(int byte_off) {
+  asm volatile("" : "+s"(byte_off));
+  typedef const char __attribute__((address_space(4))) kchar;
+  typedef T* const __attribute__((address_space(4))) kptr;
+  kchar* ka = (kchar*)__builtin_amdgcn_kernarg_segment_ptr();
+  return *(kptr*)(ka + byte_off);
+}
+#define KOFF(Args, path) ((int)__builtin_offsetof(Args, path))
+#define LATEP(cond, T, off, expr) ((cond) ? karg<T>(off) : (expr))      // the training variants (cond) take the pointer late
+
 // LDS map (bytes).  The attention output lives in per-wave STRIPS [wave][rows][64 features of the wave's two heads] (pitch PS): a
 // wave writes only its own strip, whose space it used before as scratch (the KG partial's Z, the transposing value reads), so
 // nothing but the "attention output complete" barrier orders the waves there.  The input tile lives in the strips' space first.
@@ -201,8 +216,8 @@ struct Cfg {
 // residual plane bf16(y - bf16(y)) of the LayerNorm output, so that the pooled mean of training calls is exact to 2^-17 (the per-sample
 // tail's ReLU decisions sit behind it, and the tests bound how far a pre-activation may be from the oracle's: tests/helpers.py).
 template <int RS, int DEPTH, bool PAIR, bool DROP, bool SAVE, class OF, class GR>
-__device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS], OF&& ofrag, GR&& grow, const DropCfg& drop, char* bufY, char* bufLo, float* red, const float* cst,
-                                      int w, int lane, Stage<RS, 2, 16, 2, DEPTH>& sto, unsigned long long* stamps, bool pair2 = false) {
+__device__ __forceinline__ void chain(const BackStream& S, int sbase, const Sub (&sub)[RS], OF&& ofrag, GR&& grow, const DropCfg& drop, char* bufY, char* bufLo, float* red, const float* cst,
+                                      int w, int lane, Stage<RS, 2, 16, 2, DEPTH>& sto, unsigned long long* stamps, bool pair2 = false) {      // sbase: byte offset of S in the kernel's argument block (karg)
   static_assert(!PAIR || RS == 1, "pair mode: one tile");
   const int l31 = lane & 31, h = lane >> 5;
   const bool same = RS == 2 && sub[RS - 1].nr > 0 && sub[RS - 1].b == sub[0].b;      // (wave-uniform) both sub-tiles of one sample: one atomic per column
@@ -281,7 +296,7 @@ __device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS],
       if (h == 0) *reinterpret_cast<float2*>(red + 2 * (w * ROWS + 32 * s + l31)) = make_float2(sm, sq);
     }
     __syncthreads();
-    stf.prefetch(S.W1, w * (16 * 4), lane);                       // (flows during the normalisation and the pooling products)
+    stf.prefetch(LATEP(SAVE, const us16, sbase + KOFF(BackStream, W1), S.W1), w * (16 * 4), lane);                       // (flows during the normalisation and the pooling products)
 #pragma unroll
     for (int s = 0; s < RS; ++s) {
       float ts = 0.f, tq = 0.f;
@@ -311,14 +326,14 @@ __device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS],
           }
           if constexpr (SAVE) {                                 // normalised LayerNorm input, straight from the registers (8 bytes per row and lane half)
             const int gr = grow(32 * s + l31);
-            if (gr >= 0) *reinterpret_cast<u32x2*>(S.XH16 + (size_t)gr * 256 + c0) = u32x2{pack2(x0, x1), pack2(x2, x3)};
+            if (gr >= 0) *reinterpret_cast<u32x2*>(karg<us16>(sbase + KOFF(BackStream, XH16)) + (size_t)gr * 256 + c0) = u32x2{pack2(x0, x1), pack2(x2, x3)};
           }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (SAVE) {
         const int gr = grow(32 * s + l31);
-        if (w == 0 && h == 0 && gr >= 0) S.rstd[gr] = rstd;
+        if (w == 0 && h == 0 && gr >= 0) karg<float>(sbase + KOFF(BackStream, rstd))[gr] = rstd;
       }
     }
   }
@@ -329,7 +344,7 @@ __device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS],
     for (int it = 0; it < RS * 4; ++it) {
       const int c = (int)threadIdx.x + NTH * it, r = c >> 5, k = c & 31;
       const int gr = grow(r);
-      if (gr >= 0) *reinterpret_cast<u32x4*>(S.Y16 + (size_t)gr * 256 + 8 * k) = *reinterpret_cast<const u32x4*>(bufY + r * PR + 16 * k);
+      if (gr >= 0) *reinterpret_cast<u32x4*>(karg<us16>(sbase + KOFF(BackStream, Y16)) + (size_t)gr * 256 + 8 * k) = *reinterpret_cast<const u32x4*>(bufY + r * PR + 16 * k);
     }
   }
   // ---- mean pool of the LayerNorm output: column sums of the bf16 Y tile as MFMAs against an identity fragment.  Product
@@ -349,7 +364,7 @@ __device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS],
           p[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(lp + 32), as_frag(idf[1]), p[s], 0, 0, 0);
         }
       }
-      pooled(p, 0.f, S.Ymean + 32 * (2 * w + t) + l31, 256);
+      pooled(p, 0.f, LATEP(SAVE, float, sbase + KOFF(BackStream, Ymean), S.Ymean) + 32 * (2 * w + t) + l31, 256);
     }
   }
   // ---- FFN layer 0 + ReLU, pooled over the rows (lane = feature): two passes of 64 features per wave
@@ -360,7 +375,7 @@ __device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS],
       f32x16 init[2] = {splat16(0.f), splat16(0.f)};
       stf.template run<false>(bufY + l31 * PR + 16 * h, 32 * PR, init, acc);
     }
-    if (p == 0) stf.prefetch(S.W1, w * (16 * 4) + 2, lane);
+    if (p == 0) stf.prefetch(LATEP(SAVE, const us16, sbase + KOFF(BackStream, W1), S.W1), w * (16 * 4) + 2, lane);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int f = 128 * w + 64 * p + 32 * t + l31;
@@ -372,7 +387,7 @@ __device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS],
         for (int s = 0; s < RS; ++s)
 #pragma unroll
           for (int i = 0; i < 16; ++i) r[s][i] = fmaxf(acc[s][t][i], nb);
-        pooled(r, bias, S.Hmean + f, 512);
+        pooled(r, bias, LATEP(SAVE, float, sbase + KOFF(BackStream, Hmean), S.Hmean) + f, 512);
       } else {
 #pragma unroll
         for (int s = 0; s < RS; ++s) {
@@ -389,19 +404,23 @@ __device__ __forceinline__ void chain(const BackStream& S, const Sub (&sub)[RS],
             r[s][i] = v;
             if constexpr (SAVE) {
               const unsigned long long bal = __ballot(v > 0.f);
-              if (lane == i) { wlo = (uint32_t)bal; whi = (uint32_t)(bal >> 32); }
+              // (the ballot is a scalar pair: v_writelane drops each half into lane i directly -- a `lane == i` select per register
+              // keeps 16 compare masks + 16 ballots = 64 SGPRs alive and was the training variants' main source of SGPR spills)
+              SET_LANE(wlo, (uint32_t)bal, i);
+              SET_LANE(whi, (uint32_t)(bal >> 32), i);
             }
           }
           if constexpr (SAVE) {                                 // lane i < 16 holds the words of tile rows acc_row(i, 0) and acc_row(i, 1) = + 4, features 32 (4 w + 2 p + t) ..
             if (lane < 16) {
               const int ra = 32 * s + acc_row(lane, 0);
               const int g0r = grow(ra), g1r = grow(ra + 4);
-              if (g0r >= 0) S.mask[(size_t)g0r * 16 + 4 * w + 2 * p + t] = wlo;
-              if (g1r >= 0) S.mask[(size_t)g1r * 16 + 4 * w + 2 * p + t] = whi;
+              uint32_t* mk = karg<uint32_t>(sbase + KOFF(BackStream, mask));
+              if (g0r >= 0) mk[(size_t)g0r * 16 + 4 * w + 2 * p + t] = wlo;
+              if (g1r >= 0) mk[(size_t)g1r * 16 + 4 * w + 2 * p + t] = whi;
             }
           }
         }
-        pooled(r, 0.f, S.Hmean + f, 512);
+        pooled(r, 0.f, LATEP(SAVE, float, sbase + KOFF(BackStream, Hmean), S.Hmean) + f, 512);
       }
     }
   }
@@ -435,7 +454,8 @@ __device__ __forceinline__ void kg_combine2(const BackArgs& a, const float* bv2,
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int sg = max(0, min(s0 + k, nseg[smp] - 1));
-        const float* p = a.part + ((size_t)(sg == 0 ? t0[smp] : (t0[smp] / RT + sg) * RT) * 8 + hd) * (SAVE ? PART_FLOATS_F32 : PART_FLOATS);
+        const float* p = LATEP(SAVE, const float, KOFF(BackArgs, part), a.part)      /* (BackArgs leads KgChainArgs) */
+             + ((size_t)(sg == 0 ? t0[smp] : (t0[smp] / RT + sg) * RT) * 8 + hd) * (SAVE ? PART_FLOATS_F32 : PART_FLOATS);
         mm[it][k] = p[jl]; ll[it][k] = p[16 + jl];
         if constexpr (SAVE) {
           zz[it][k] = *reinterpret_cast<const u32x4*>(p + 32 + jl * 32 + 8 * f8); zz1[it][k] = *reinterpret_cast<const u32x4*>(p + 32 + jl * 32 + 8 * f8 + 4);
@@ -511,7 +531,7 @@ __global__ __launch_bounds__(NTH, 2) void kgchain_kernel(const KgChainArgs g) {
   stamp(a.stamps, 0);
   const int ta0 = a.tile_off[b0], ta1 = a.tile_off[b0 + 1], tb1 = pair2 ? a.tile_off[b0 + 2] : ta1;
   Stage<1, 2, 16, 2, DEPTH> stk;
-  stk.prefetch(K.Wo, w * (16 * 2), lane);
+  stk.prefetch(LATEP(SAVE, const us16, KOFF(KgChainArgs, b.s[1].Wo), K.Wo), w * (16 * 2), lane);
   // constants: the KG->RG values' bias (added by the combine) | bo | ln_g | ln_b | b1 of the KG stream
   for (int i = tid; i < 384; i += NTH) {
     if (i < 64 && !g.bv2) continue;
@@ -525,7 +545,7 @@ __global__ __launch_bounds__(NTH, 2) void kgchain_kernel(const KgChainArgs g) {
   for (int c = tid; c < 32 * 32; c += NTH) {
     const int r = c >> 5, k = c & 31, gr = grow(r);
     u32x4 v = u32x4{0u, 0u, 0u, 0u};
-    if (gr >= 0) v = *reinterpret_cast<const u32x4*>(K.R16 + (size_t)gr * 256 + 8 * k);
+    if (gr >= 0) v = *reinterpret_cast<const u32x4*>(LATEP(SAVE, const us16, KOFF(KgChainArgs, b.s[1].R16), K.R16) + (size_t)gr * 256 + 8 * k);
     *reinterpret_cast<u32x4*>(kbufY + r * PR + 16 * k) = v;
   }
   __syncthreads();
@@ -540,11 +560,11 @@ __global__ __launch_bounds__(NTH, 2) void kgchain_kernel(const KgChainArgs g) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int c = tid + NTH * it, r = c >> 5, k = c & 31, gr = grow(r);
-      if (gr >= 0) *reinterpret_cast<u32x4*>(K.O16 + (size_t)gr * 256 + 8 * k) = *reinterpret_cast<const u32x4*>(kbufO + r * PR + 16 * k);
+      if (gr >= 0) *reinterpret_cast<u32x4*>(karg<us16>(KOFF(KgChainArgs, b.s[1].O16)) + (size_t)gr * 256 + 8 * k) = *reinterpret_cast<const u32x4*>(kbufO + r * PR + 16 * k);
     }
   }
   const Sub ksub[1] = {Sub{b0, b0 * Nk, Nk, 1.0f / (float)Nk}};
-  chain<1, DEPTH, true, DROP, SAVE>(K, ksub, [&](int, int ks) { return *reinterpret_cast<const bf16x8*>(kbufO + l31 * PR + 32 * ks + 16 * h); }, grow, a.drop,
+  chain<1, DEPTH, true, DROP, SAVE>(K, KOFF(KgChainArgs, b.s[1]), ksub, [&](int, int ks) { return *reinterpret_cast<const bf16x8*>(kbufO + l31 * PR + 32 * ks + 16 * h); }, grow, a.drop,
                                     kbufY, kbufO, red, cst, w, lane, stk, nullptr, pair2);
   stamp(a.stamps, 12);
 }
@@ -623,7 +643,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
   stamp(a.stamps, 0);
   const bool same = sub[1].nr > 0 && sub[1].b == sub[0].b;        // (wave-uniform) both sub-tiles belong to one sample
   Stage<RT, 2, 8, 2, DEPTH> st0;
-  st0.prefetch(F.W0, w * (8 * 2), lane);
+  st0.prefetch(LATEP(SAVE, const us16, KOFF(RgFwd2Args, f.W0), F.W0), w * (8 * 2), lane);
   // ---- input rows: fp32 -> bf16 tile (rows past a sub-tile's end cleared)
   {
     constexpr int XIT = ROWS * 8 / NTH;
@@ -662,7 +682,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
       *reinterpret_cast<u32x4*>(bufX + r * PX + 32 * c) = p0;
       *reinterpret_cast<u32x4*>(bufX + r * PX + 32 * c + 16) = p1;
       if constexpr (SAVE) {
-        if (ok) { u32x4* d = reinterpret_cast<u32x4*>(F.X16 + ((size_t)sub[it].row0 + (tid >> 3)) * 128 + 16 * c); d[0] = p0; d[1] = p1; }
+        if (ok) { u32x4* d = reinterpret_cast<u32x4*>(karg<us16>(KOFF(RgFwd2Args, f.X16)) + ((size_t)sub[it].row0 + (tid >> 3)) * 128 + 16 * c); d[0] = p0; d[1] = p1; }
       }
     }
   }
@@ -675,7 +695,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
   // half the weight bytes of the unfolded 256 -> 768 product; launch_fold_rg)
   constexpr int KS1 = FOLD ? 8 : 16;                               // k steps of an in-projection pass: over the input tile (128) or the R tile (256)
   Stage<RT, 2, KS1, 6, DEPTH> st1;
-  const us16* W1s = FOLD ? g.Wf : F.W1;
+  auto W1s = [&]() -> const us16* { return FOLD ? g.Wf : LATEP(SAVE, const us16, KOFF(RgFwd2Args, f.W1), F.W1); };
   const char* act1 = FOLD ? bufX + l31 * PX + 16 * h : bufR + l31 * PR + 16 * h;
   constexpr int sub1 = FOLD ? 32 * PX : 32 * PR;
   auto w1pair = [&](int tg) { return (tg / 6) * (KS1 * 6) + tg % 6; };    // first fragment of tiles tg, tg + 1 (tg even) in the [768 x 128 | 256] shadow
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
       for (int t = 0; t < 2; ++t) init[t] = feature_vec(cst + Cfg::C_B0 + 32 * (2 * w + t), h);
       st0.template run<true>(bufX + l31 * PX + 16 * h, 32 * PX, init, acc);
     }
-    st1.prefetch(W1s, w1pair(8 + 2 * w), lane);
+    st1.prefetch(W1s(), w1pair(8 + 2 * w), lane);
 #pragma unroll
     for (int s = 0; s < RT; ++s)
 #pragma unroll
@@ -703,7 +723,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
 #pragma unroll 2
     for (int it = 0; it < RT * 4; ++it) {                         // (two in flight at a time: fully unrolled, hipcc hoists all eight reads over the pass's own prefetches)
       const int c = tid + NTH * it, r = c >> 5, k = c & 31, gr = grow(r);
-      if (gr >= 0) *reinterpret_cast<u32x4*>(F.R16 + (size_t)gr * 256 + 8 * k) = *reinterpret_cast<const u32x4*>(bufR + r * PR + 16 * k);
+      if (gr >= 0) *reinterpret_cast<u32x4*>(karg<us16>(KOFF(RgFwd2Args, f.R16)) + (size_t)gr * 256 + 8 * k) = *reinterpret_cast<const u32x4*>(bufR + r * PR + 16 * k);
     }
   }
   // RG->KG scores -> log2 units: the folded queries are NOT pre-scaled; the unfolded ones are (and are saved so)
@@ -720,7 +740,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
       for (int s = 0; s < RT; ++s)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const us16* q2p = (a.Q2_16 + ((size_t)sub[s].b * Nk * 256 + 32 * (2 * w + t))) + ((unsigned)min(l31, Nk - 1) * 256u + 4u * (unsigned)h);      // (scalar base + 32-bit lane offset)
+          const us16* q2p = (LATEP(SAVE, const us16, KOFF(RgFwd2Args, b.Q2_16), a.Q2_16) + ((size_t)sub[s].b * Nk * 256 + 32 * (2 * w + t))) + ((unsigned)min(l31, Nk - 1) * 256u + 4u * (unsigned)h);      // (scalar base + 32-bit lane offset)
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
             const u32x2 lo = *reinterpret_cast<const u32x2*>(q2p + 16 * kk), hi = *reinterpret_cast<const u32x2*>(q2p + 16 * kk + 8);
@@ -735,7 +755,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
         for (int t = 0; t < 2; ++t) init[t] = FOLD ? splat16(0.f) : feature_vec(cst + Cfg::C_BK + 32 * (2 * w + t), h);
         st1.template run<true>(act1, sub1, init, acc);
       }
-      st1.prefetch(W1s, w1pair(16 + 2 * w), lane);
+      st1.prefetch(W1s(), w1pair(16 + 2 * w), lane);
       stamp(a.stamps, 3);
       // one head (feature tile t) at a time: scores of both sub-tiles, their maxima (a run of one sample shares its maximum), the
       // exponentials -- 32 score registers live instead of 64
@@ -796,7 +816,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
 #pragma unroll 2
       for (int it = 0; it < 8; ++it) {
         const int idx = lane + 64 * it, r = idx >> 3, k = idx & 7, gr = grow(r);
-        if (gr >= 0) *reinterpret_cast<u32x4*>(F.KV16 + (size_t)gr * 512 + 64 * w + 8 * k) = *reinterpret_cast<const u32x4*>(strip + r * PS + 16 * k);
+        if (gr >= 0) *reinterpret_cast<u32x4*>(karg<us16>(KOFF(RgFwd2Args, f.KV16)) + (size_t)gr * 512 + 64 * w + 8 * k) = *reinterpret_cast<const u32x4*>(strip + r * PS + 16 * k);
       }
     }
     f32x16 vacc[RT][2];
@@ -804,7 +824,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
       f32x16 init[2] = {splat16(0.f), splat16(0.f)};              // (inference: the values' bias is added by the combine; training: below)
       st1.template run<false>(act1, sub1, init, vacc);              // same fragments, operands swapped: lane = feature
     }
-    st1.prefetch(W1s, w1pair(2 * w), lane);
+    st1.prefetch(W1s(), w1pair(2 * w), lane);
     stamp(a.stamps, 4);
     if constexpr (!FOLD) {                                        // training: the values carry their bias (lane = feature) ...
 #pragma unroll
@@ -828,14 +848,14 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
           for (int r2 = 0; r2 < 2; ++r2) {
             const int idx = lane + 64 * r2, row = idx >> 2, ch = idx & 3;
             const u32x4 v = *reinterpret_cast<const u32x4*>(vt + 8 * idx);
-            if (row < sub[s].nr) *reinterpret_cast<u32x4*>(F.KV16 + ((size_t)sub[s].row0 + row) * 512 + 256 + 32 * (2 * w + t) + 8 * ch) = v;
+            if (row < sub[s].nr) *reinterpret_cast<u32x4*>(karg<us16>(KOFF(RgFwd2Args, f.KV16)) + ((size_t)sub[s].row0 + row) * 512 + 256 + 32 * (2 * w + t) + 8 * ch) = v;
           }
         }
     }
     // one partial per run of sub-tiles of one sample: {max (log2 units), sum, Z[query][feature] = E^T . V2 as bf16} at the run's first tile
     auto store_part = [&](int tile, int t, const f32x16& Z, float L, float m) {
       L += __shfl_xor(L, 32, 64);
-      float* part = a.part + ((size_t)tile * 8 + (2 * w + t)) * (SAVE ? PART_FLOATS_F32 : PART_FLOATS);
+      float* part = LATEP(SAVE, float, KOFF(RgFwd2Args, b.part), a.part) + ((size_t)tile * 8 + (2 * w + t)) * (SAVE ? PART_FLOATS_F32 : PART_FLOATS);
       if (lane < 16) { part[lane] = m * LOG2E; part[16 + lane] = L; }
       // rows j < Nk leave as 16-byte stores through the wave's scratch (its own LDS writes: program order)
       if constexpr (SAVE) {
@@ -884,7 +904,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int jk = l31 & 15;
-        const us16* kp = (a.KV16 + ((size_t)sub[s].b * Nk * 512 + 32 * (2 * w + t))) + ((unsigned)min(jk, Nk - 1) * 512u + 4u * (unsigned)h);
+        const us16* kp = (LATEP(SAVE, const us16, KOFF(RgFwd2Args, b.KV16), a.KV16) + ((size_t)sub[s].b * Nk * 512 + 32 * (2 * w + t))) + ((unsigned)min(jk, Nk - 1) * 512u + 4u * (unsigned)h);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const u32x2 lo = *reinterpret_cast<const u32x2*>(kp + 16 * kk), hi = *reinterpret_cast<const u32x2*>(kp + 16 * kk + 8);
@@ -892,7 +912,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
         }
         const int j = lane >> 2, c = lane & 3;
         vkg[s][t] = u32x4{0u, 0u, 0u, 0u};
-        if (j < Nk) vkg[s][t] = *reinterpret_cast<const u32x4*>((a.KV16 + ((size_t)sub[s].b * Nk * 512 + 256 + 32 * (2 * w + t))) + ((unsigned)j * 512u + 8u * (unsigned)c));
+        if (j < Nk) vkg[s][t] = *reinterpret_cast<const u32x4*>((LATEP(SAVE, const us16, KOFF(RgFwd2Args, b.KV16), a.KV16) + ((size_t)sub[s].b * Nk * 512 + 256 + 32 * (2 * w + t))) + ((unsigned)j * 512u + 8u * (unsigned)c));
       }
     f32x16 acc[RT][2];
     {
@@ -901,7 +921,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
       for (int t = 0; t < 2; ++t) init[t] = feature_vec(cst + Cfg::C_BQ + 32 * (2 * w + t), h);
       st1.template run<true>(act1, sub1, init, acc);
     }
-    sto.prefetch(S.Wo, w * (16 * 2), lane);
+    sto.prefetch(LATEP(SAVE, const us16, KOFF(RgFwd2Args, b.s[0].Wo), S.Wo), w * (16 * 2), lane);
     stamp(a.stamps, 6);
     // invalid keys (Nk .. 15) leave the softmax through the score product's C operand
     f32x16 kmask;
@@ -924,7 +944,7 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
 #pragma unroll
           for (int r2 = 0; r2 < 2; ++r2) {
             const int idx = lane + 64 * r2, row = idx >> 2, ch = idx & 3;
-            if (row < sub[s].nr) *reinterpret_cast<u32x4*>(F.Q16 + ((size_t)sub[s].row0 + row) * 256 + 32 * (2 * w + t) + 8 * ch) = *reinterpret_cast<const u32x4*>(qs + 64 * row + 16 * ch);
+            if (row < sub[s].nr) *reinterpret_cast<u32x4*>(karg<us16>(KOFF(RgFwd2Args, f.Q16)) + ((size_t)sub[s].row0 + row) * 256 + 32 * (2 * w + t) + 8 * ch) = *reinterpret_cast<const u32x4*>(qs + 64 * row + 16 * ch);
           }
         }
         f32x16 Sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf[s][t][0]), as_frag(q0), kmask, 0, 0, 0);     // S^T[key][row]: lane = row
@@ -968,11 +988,11 @@ __global__ __launch_bounds__(NTH, 2) void rgfwd2_kernel(const RgFwd2Args g) {
 #pragma unroll 2
     for (int it = 0; it < 8; ++it) {
       const int idx = lane + 64 * it, r = idx >> 3, k = idx & 7, gr = grow(r);
-      if (gr >= 0) *reinterpret_cast<u32x4*>(S.O16 + (size_t)gr * 256 + 64 * w + 8 * k) = *reinterpret_cast<const u32x4*>(strip + r * PS + 16 * k);
+      if (gr >= 0) *reinterpret_cast<u32x4*>(karg<us16>(KOFF(RgFwd2Args, b.s[0].O16)) + (size_t)gr * 256 + 64 * w + 8 * k) = *reinterpret_cast<const u32x4*>(strip + r * PS + 16 * k);
     }
   }
   // attention output fragment of sub-tile s, k step ks (features 16 ks ..): strip ks >> 2, byte 32 (ks & 3) of the row
-  chain<RT, DEPTH, false, DROP, SAVE>(S, sub, [&](int s, int ks) { return *reinterpret_cast<const bf16x8*>(strips + (ks >> 2) * Cfg::STRIP + (32 * s + l31) * PS + 32 * (ks & 3) + 16 * h); },
+  chain<RT, DEPTH, false, DROP, SAVE>(S, KOFF(RgFwd2Args, b.s[0]), sub, [&](int s, int ks) { return *reinterpret_cast<const bf16x8*>(strips + (ks >> 2) * Cfg::STRIP + (32 * s + l31) * PS + 32 * (ks & 3) + 16 * h); },
                                       grow, a.drop, bufR, strips, red, cst, w, lane, sto, a.stamps);
   stamp(a.stamps, 12);
 }

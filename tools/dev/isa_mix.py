@@ -23,8 +23,14 @@ def main():
         if k == "valu":
             ops[op] = ops.get(op, 0) + 1
     print(f"lines {start}..{end}: {c}  VALU : MFMA = {c.get('valu', 0) / max(c.get('mfma', 1), 1):.2f}")
-    print("lane spills (v_readlane / v_writelane):", sum(v for k, v in ops.items() if "readlane" in k or "writelane" in k),
-          " scratch ops:", sum(1 for l in lines[start:end] if "scratch_" in l))
+    # SGPR spills go to VGPRs the compiler names in a comment ("; implicit-def: $vgpr246 : SGPR spill to VGPR lane"); the other
+    # v_writelane instructions are the source's own (SET_LANE: a ballot's halves into lane i of the saved ReLU mask words)
+    import re
+    spill_regs = {m.group(1) for l in lines[start:end] for m in [re.search(r"implicit-def: \$vgpr(\d+) : SGPR spill", l)] if m}
+    lane_ops = [l.split(";")[0] for l in lines[start:end] if l.strip().startswith(("v_readlane", "v_writelane"))]
+    spills = sum(1 for l in lane_ops if any(re.search(rf"\bv{r}\b", l) for r in spill_regs))
+    print(f"lane spills (v_readlane / v_writelane on the SGPR-spill VGPRs {sorted(spill_regs)}): {spills}   other lane ops (SET_LANE etc.): {len(lane_ops) - spills}",
+          "  scratch ops:", sum(1 for l in lines[start:end] if "scratch_" in l))
     print(sorted(ops.items(), key=lambda kv: -kv[1])[:30])
 
 
