@@ -39,7 +39,7 @@ class CamoRgDims(C.Structure):
 
 
 OPTION_NAMES = ("sched16", "fused", "tail17", "fused_rt", "wide2", "fused_one", "wide_front_rt", "tailw", "tailw_bwd", "param_space", "tn_big",
-                "fused_variant", "back_lead", "tn_balance", "tn_kcap", "tn_exp", "exp", "fused_save", "tail_skip_arrival")
+                "fused_variant", "back_lead", "tn_balance", "tn_kcap", "tn_exp", "exp", "fused_save", "tail_skip_arrival", "wide2_bwd")
 
 
 class CamoOptions(C.Structure):
@@ -49,7 +49,7 @@ class CamoOptions(C.Structure):
 
 # camo_options_init's values (a CPU test holds the two to each other): an engine can be constructed before the library is loadable
 OPTION_DEFAULTS = dict(sched16=-1, fused=-1, tail17=-1, fused_rt=-1, wide2=-1, fused_one=1, wide_front_rt=0, tailw=-1, tailw_bwd=-1, param_space=-1, tn_big=-1,
-                       fused_variant=1, back_lead=1, tn_balance=1, tn_kcap=0, tn_exp=0, exp=0, fused_save=0, tail_skip_arrival=0)
+                       fused_variant=1, back_lead=1, tn_balance=1, tn_kcap=0, tn_exp=0, exp=0, fused_save=0, tail_skip_arrival=0, wide2_bwd=-1)
 
 
 def default_options():

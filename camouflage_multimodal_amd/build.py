@@ -17,13 +17,13 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcamo_fusion.so")
-SOURCES = ("gemm.hip", "gemm16.hip", "attn.hip", "attn_fast.hip", "attn_mfma.hip", "misc.hip", "rg_gnn.hip", "rg_features.hip", "fused_rows.hip", "fused_wide.hip", "fused_wide2.hip", "tail_wide.hip", "fusion_abi.hip")
-HEADERS = ("common.h", "gemm.h", "gemm16.h", "attn.h", "misc.h", "rg_gnn.h", "rg_features.h", "fused_rows.h", "shadow_inl.h", "tail_wide.h", os.path.join("..", "..", "include", "camo_fusion.h"), os.path.join("..", "..", "include", "camo_rg_gnn.h"), os.path.join("..", "..", "include", "camo_rg_features.h"))
+SOURCES = ("gemm.hip", "gemm16.hip", "attn.hip", "attn_fast.hip", "attn_mfma.hip", "misc.hip", "rg_gnn.hip", "rg_features.hip", "fused_rows.hip", "fused_wide.hip", "fused_wide2.hip", "bwd_wide2.hip", "tail_wide.hip", "fusion_abi.hip")
+HEADERS = ("common.h", "gemm.h", "gemm16.h", "attn.h", "misc.h", "rg_gnn.h", "rg_features.h", "fused_rows.h", "shadow_inl.h", "wide2_inl.h", "tail_wide.h", os.path.join("..", "..", "include", "camo_fusion.h"), os.path.join("..", "..", "include", "camo_rg_gnn.h"), os.path.join("..", "..", "include", "camo_rg_features.h"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file additions.  fused_wide2.hip: no SLP vectorisation (v_pk_*_f32 beside MFMAs cost more issue time than the two scalar
 # instructions they replace: MI355X guide, cycle constants) and no NaN canonicalisation in front of every v_max_f32 (the kernel
 # compares finite scores; a NaN input still comes out as a NaN through the sums)
-EXTRA_FLAGS = {"fused_wide2.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
+EXTRA_FLAGS = {"fused_wide2.hip": ["-fno-slp-vectorize", "-fno-honor-nans"], "bwd_wide2.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
 
 
 def _hipcc():

@@ -1,0 +1,397 @@
+// Backward, first half, for the RG rows of large batches (gfx950): 64-row half-blocks of 4 waves, two independent blocks per CU -- the
+// layout of fused_wide2.hip (forward) applied to bwd1_kernel of fused_rows.hip, whose contract (Bwd1Args, fused_rows.h), weight shadows
+// (W1T, WoT), saved set and outputs it keeps bit-compatible:
+//   dH = mask(H) * d(mean H) / n (* dropout scale)      -> dH16 (the weight-gradient operand), and the first product's activation
+//   dY = d(mean Z) / n + dH . W1 ;  dU = LayerNorm_backward(dY) (+ dgamma, dbeta) -> dU16 ;  dO = dU . Wo
+//   RG->KG attention backward (probabilities recomputed from the saved queries): dQ -> dQKV16[:, 0..255], dK | dV += (fp32 atomics)
+// The KG rows, and the dH16 rows of the KG stream, stay with bwd1_kernel (launched for them alone: launch_fused_bwd1's rg_tiles = 0 form).
+//
+// Why.  bwd1_kernel is the largest kernel of a large-batch training step (32 % at B = 1024) at ~10 % MFMA issue: a
+// 32-row tile streams 384 KB of weights, every one of its 8 waves expands the same 512 mask bits per row into dH fragments (24 vector
+// instructions per fragment: 6 per MFMA) and separate writer blocks expand them once more for dH16.  Here
+//   * a block owns two 32-row sub-tiles: a weight fragment feeds two MFMAs (half the L2 weight traffic per row), and two blocks per CU
+//     drift through their phases independently;
+//   * the dH tile [64][512] (bf16) is built ONCE per block in LDS, cooperatively (4 vector instructions per feature pair, one pass),
+//     read by every wave as an ordinary activation tile, and written to dH16 from LDS as whole-row 16-byte stores: no writer blocks
+//     for the RG rows, no second read of the mask;
+//   * d(mean Z) / n enters as the first MFMA's C operand;
+//   * the LayerNorm gradient's column sums (dgamma, dbeta) are MFMAs against an identity fragment on hi / lo bf16 planes (exact to
+//     2^-17) of the wave's own 64 features, instead of an fp32 tile in LDS summed by one thread per column;
+//   * the attention backward runs per sub-tile out of per-wave strips (queries, dO: the wave's 64 features only).
+#include "fused_rows.h"
+#include "gemm.h"      // launch timing hooks
+#include "wide2_inl.h"
+
+namespace {
+
+constexpr int PH = 1040;     // row pitch (bytes) of the [rows][512] bf16 dH tile (65 x 16 bytes: 8 consecutive rows on 8 distinct 16-byte slots)
+
+struct CfgB {
+  static constexpr int GT = 0;                                   // [RT][512] bf16: d(mean H) / n * dropout scale of each sub-tile's sample
+  static constexpr int CST = GT + RT * 1024;                     // floats: ln_g [256] | d(mean Z) / n of sub-tile 0 [256] | of sub-tile 1 [256]
+  static constexpr int RED = CST + 3 * 1024;                     // LayerNorm gradient partials {sum g, sum g xhat} per (wave, row)
+  static constexpr int DU = RED + NW * ROWS * 8;                 // dU tile [ROWS][256] bf16 (pitch PR); then per-wave attention scratch (WSCR each)
+  static constexpr int ST = DU + ROWS * PR;                      // per-wave strips [ROWS][64] (pitch PS): column-sum planes; then queries | dO
+  static constexpr int STRIP = ROWS * PS;
+  static constexpr int LDS = ST + NW * STRIP;
+  static constexpr int WSCR = ROWS * PR / NW;                    // 8448 bytes: keys [16][64] | values [16][64] (pitch PS) | dS, Pd images [32][16] of one head
+  static constexpr int W_KS = 0, W_VS = 16 * PS, W_IMG = 32 * PS;
+  static_assert(ROWS * PH <= ROWS * PR + NW * STRIP, "the dH tile aliases [dU tile | strips]");
+  static_assert(W_IMG + 2048 <= WSCR, "per-wave attention scratch");
+  static_assert(LDS <= 81920, "two blocks per CU");
+};
+
+// Softmax over the <= 16 keys of one RG row -- the code of fused_rows.hip (rg_softmax), which the saved probabilities' consumers share
+__device__ __forceinline__ void rg_softmax(const f32x16& Sc, int h, int Nk, float (&p)[8]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { p[i] = acc_row(i, h) < Nk ? Sc[i] : -INFINITY; m = fmaxf(m, p[i]); }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { p[i] = __expf(p[i] - m); sum += p[i]; }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] *= inv;
+}
+
+template <int DEPTH, bool DROP>
+__global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Bwd1Stream& S = a.s[0];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5, Nk = a.Nk;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  us16* gtab = reinterpret_cast<us16*>(smem + CfgB::GT);
+  float* cst = reinterpret_cast<float*>(smem + CfgB::CST);
+  float* red = reinterpret_cast<float*>(smem + CfgB::RED);
+  char* tileH = smem + CfgB::DU;                                  // dH tile (first product), aliasing [dU tile | strips]
+  char* bufdU = smem + CfgB::DU;
+  char* strip = smem + CfgB::ST + w * CfgB::STRIP;
+  const int g0 = (int)blockIdx.x * RT;
+  Sub sub[RT];
+#pragma unroll
+  for (int s = 0; s < RT; ++s) {
+    int4 td = make_int4(-1, 0, 0, 0);
+    if (g0 + s < a.rg_tiles_max) td = a.tile_desc[g0 + s];
+    const int tb = __builtin_amdgcn_readfirstlane(td.x);
+    sub[s].b = tb < 0 ? 0 : tb; sub[s].row0 = tb < 0 ? 0 : __builtin_amdgcn_readfirstlane(td.y); sub[s].nr = tb < 0 ? 0 : __builtin_amdgcn_readfirstlane(td.z);
+    sub[s].inv_n = tb < 0 ? 0.f : __int_as_float(__builtin_amdgcn_readfirstlane(td.w));
+  }
+  if (sub[0].nr == 0) return;                                     // (tiles are dense from 0: the whole group is past the end)
+  stamp(a.stamps, 0);
+  Stage<RT, 2, 32, 2, DEPTH> st1;
+  st1.prefetch(S.W1T, w * (32 * 2), lane);
+  // ---- per-sample tables: the FFN gradient row as bf16 (what a set mask bit selects), d(mean Z) / n, gamma
+  {
+    const float gsc = a.drop.scale;
+#pragma unroll
+    for (int it = 0; it < RT * 2; ++it) {
+      const int s = it >> 1, f = tid + NTH * (it & 1);
+      gtab[512 * s + f] = f2bf(S.dHm[(size_t)sub[s].b * S.ld_dHm + f] * (sub[s].inv_n * gsc));
+    }
+    cst[tid] = S.ln_g[tid];
+#pragma unroll
+    for (int s = 0; s < RT; ++s) cst[256 + 256 * s + tid] = S.dcomb[(size_t)sub[s].b * S.ld_dcomb + tid] * sub[s].inv_n;
+  }
+  // this thread's share of the mask: row tid >> 2 of the block (wave w: rows 16 w .. + 15, all in sub-tile w >> 1), words 4 q .. + 3
+  const int hs_row0 = w < 2 ? sub[0].row0 : sub[1].row0, hs_nr = w < 2 ? sub[0].nr : sub[1].nr;
+  const int hr = tid >> 2, hq = tid & 3, hrr = hr & 31;
+  u32x4 mwq = u32x4{0u, 0u, 0u, 0u};
+  if (hrr < hs_nr) mwq = *reinterpret_cast<const u32x4*>(S.mask + ((size_t)hs_row0 + hrr) * 16 + 4 * hq);
+  // this lane's rows of the two sub-tiles (clamped into the tile), their saved normalised LayerNorm inputs and 1 / std
+  bool rok[RT]; u32x2 xv[RT][2][4]; float rstd[RT];
+#pragma unroll
+  for (int s = 0; s < RT; ++s) {
+    rok[s] = l31 < sub[s].nr;
+    const size_t vrow = (size_t)sub[s].row0 + max(0, min(l31, sub[s].nr - 1));
+    const us16* xp = S.XH16 + vrow * 256 + 64 * w + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xv[s][t][g] = *reinterpret_cast<const u32x2*>(xp + 32 * t + 8 * g);
+    rstd[s] = S.rstd[vrow];
+  }
+  __syncthreads();                                                // tables complete
+  // ---- dH tile: feature pair (2 d, 2 d + 1) of a 16-byte chunk <- the table's pair where the mask bits are set
+  {
+    const char* gt = reinterpret_cast<const char*>(gtab) + 1024 * (w >> 1) + 256 * hq;
+    char* dst = tileH + hr * PH + 256 * hq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t bits = mwq[j] >> (8 * i);
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(gt + 64 * j + 16 * i);
+        u32x4 fr;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const uint32_t lo = (uint32_t)((int)(bits << (31 - 2 * d)) >> 31), hi = (uint32_t)((int)(bits << (30 - 2 * d)) >> 31);
+          fr[d] = gv[d] & ((lo & 0xFFFFu) | (hi & 0xFFFF0000u));
+        }
+        *reinterpret_cast<u32x4*>(dst + 64 * j + 16 * i) = fr;
+      }
+  }
+  __syncthreads();                                                // dH tile complete
+  stamp(a.stamps, 1);
+  // dH16: whole rows as 16-byte stores (a wave writes one 1 KB row per instruction)
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int r = w + 4 * it, rr = r & 31, nr_s = it < 8 ? sub[0].nr : sub[1].nr, row0_s = it < 8 ? sub[0].row0 : sub[1].row0;      // (scalar selects: no indexed sub[])
+    if (rr < nr_s) *reinterpret_cast<u32x4*>(S.dH16 + ((size_t)row0_s + rr) * 512 + 8 * lane) = *reinterpret_cast<const u32x4*>(tileH + r * PH + 16 * lane);
+  }
+  // ---- dY = d(mean Z) / n + dH . W1 (lane = row, registers = features 64 w + 32 t + acc_row)
+  f32x16 acc1[RT][2];
+  st1.template run_fi<true>([&](int s, int ks) { return *reinterpret_cast<const bf16x8*>(tileH + (32 * s + l31) * PH + 16 * h + 32 * ks); },
+                            [&](int s, int t) { return feature_vec(cst + 256 + 256 * s + 32 * (2 * w + t), h); }, acc1);
+  stamp(a.stamps, 2);
+  Stage<RT, 2, 16, 2, DEPTH> st2;
+  // ---- LayerNorm backward: g = dy gamma; du = (g - mean(g) - xhat mean(g xhat)) / std; dgamma += dy xhat, dbeta += dy
+#pragma unroll
+  for (int s = 0; s < RT; ++s) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(cst + 32 * (2 * w + t) + 8 * g + 4 * h);
+        const u32x2 x = xv[s][t][g];
+        const float X[4] = {bf_lo(x.x), bf_hi(x.x), bf_lo(x.y), bf_hi(x.y)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float G = acc1[s][t][4 * g + j] * gm[j]; s1 += G; s2 = fmaf(G, X[j], s2); }
+      }
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (h == 0) *reinterpret_cast<float2*>(red + 2 * (w * ROWS + 32 * s + l31)) = make_float2(s1, s2);
+  }
+  __syncthreads();                                                // partials complete; every wave is done with the dH tile
+#pragma unroll
+  for (int s = 0; s < RT; ++s) {
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+      const float2 p = *reinterpret_cast<const float2*>(red + 2 * (ww * ROWS + 32 * s + l31));
+      m1 += p.x; m2 += p.y;
+    }
+    m1 *= (1.0f / 256.0f); m2 *= (1.0f / 256.0f);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 32 * (2 * w + t) + 8 * g + 4 * h;
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(cst + c0);
+        const u32x2 x = xv[s][t][g];
+        const float X[4] = {bf_lo(x.x), bf_hi(x.x), bf_lo(x.y), bf_hi(x.y)};
+        float du[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) du[j] = rok[s] ? (acc1[s][t][4 * g + j] * gm[j] - m1 - X[j] * m2) * rstd[s] : 0.f;
+        *reinterpret_cast<u32x2*>(bufdU + (32 * s + l31) * PR + 2 * c0) = u32x2{pack2(du[0], du[1]), pack2(du[2], du[3])};
+      }
+  }
+  // column sums over the block's valid rows of dy xhat (q = 0: dgamma) and dy (q = 1: dbeta), this wave's 64 features: the values go
+  // through the wave's strip as bf16 hi and lo planes and come back as MFMAs against the identity (lane = feature, registers = rows)
+  {
+    u32x4 idf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int j = l31 - 16 * kk - 8 * h;
+      const uint32_t one_lo = 0x3F80u, one_hi = 0x3F800000u;
+      idf[kk] = u32x4{j == 0 ? one_lo : (j == 1 ? one_hi : 0u), j == 2 ? one_lo : (j == 3 ? one_hi : 0u),
+                      j == 4 ? one_lo : (j == 5 ? one_hi : 0u), j == 6 ? one_lo : (j == 7 ? one_hi : 0u)};
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x16 p[2] = {splat16(0.f), splat16(0.f)};
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+        for (int s = 0; s < RT; ++s)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const u32x2 x = xv[s][t][g];
+              const float X[4] = {bf_lo(x.x), bf_hi(x.x), bf_lo(x.y), bf_hi(x.y)};
+              float v[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = rok[s] ? (q == 0 ? acc1[s][t][4 * g + j] * X[j] : acc1[s][t][4 * g + j]) : 0.f;
+              u32x2 o = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+              if (pl == 1) o = u32x2{pack2(v[0] - bf_lo(o.x), v[1] - bf_hi(o.x)), pack2(v[2] - bf_lo(o.y), v[3] - bf_hi(o.y))};
+              *reinterpret_cast<u32x2*>(strip + (32 * s + l31) * PS + 2 * (32 * t + 8 * g + 4 * h)) = o;
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int s = 0; s < RT; ++s) {
+            const char* yp = strip + (32 * s + l31) * PS + 64 * t + 16 * h;
+            p[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(yp), as_frag(idf[0]), p[t], 0, 0, 0);
+            p[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(yp + 32), as_frag(idf[1]), p[t], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float c = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c += p[t][i];
+        c += __shfl_xor(c, 32, 64);
+        if (h == 0) atomicAdd((q == 0 ? S.dgamma : S.dbeta) + 64 * w + 32 * t + l31, c);
+      }
+    }
+  }
+  st2.prefetch(S.WoT, w * (16 * 2), lane);                        // (in front of the barrier: the column sums above need the registers)
+  __syncthreads();                                                // dU tile complete
+  stamp(a.stamps, 3);
+  // ---- dO = dU . Wo (lane = row, registers = the features of heads 2 w, 2 w + 1)
+  f32x16 acc2[RT][2];
+  {
+    const f32x16 init[2] = {splat16(0.f), splat16(0.f)};
+    st2.template run<true>(bufdU + l31 * PR + 16 * h, 32 * PR, init, acc2);
+  }
+  __syncthreads();                                                // every wave is done reading the dU tile
+  stamp(a.stamps, 4);
+#pragma unroll 4
+  for (int it = 0; it < 8; ++it) {                                // dU16: the tile's rows as 16-byte stores (behind the block's last weight stream)
+    const int r = (tid >> 5) + 8 * it, rr = r & 31, k = tid & 31, nr_s = it < 4 ? sub[0].nr : sub[1].nr, row0_s = it < 4 ? sub[0].row0 : sub[1].row0;
+    if (rr < nr_s) store16_wt(S.dU16 + ((size_t)row0_s + rr) * 256 + 8 * k, *reinterpret_cast<const u32x4*>(bufdU + r * PR + 16 * k));
+  }
+  __syncthreads();                                                // the dU tile's space becomes per-wave scratch
+  // ---- RG->KG attention backward, one sub-tile at a time, out of this wave's own LDS (no block barriers from here on)
+  char* Qs = strip; char* dOs = strip + 32 * PS;
+  char* wscr = smem + CfgB::DU + w * CfgB::WSCR;
+  char* Ks = wscr + CfgB::W_KS; char* Vs = wscr + CfgB::W_VS; char* imS = wscr + CfgB::W_IMG; char* imP = imS + 1024;
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+  for (int s = 0; s < RT; ++s) {
+    if (sub[s].nr == 0) break;
+    const size_t rowg0 = (size_t)sub[s].row0;
+    {
+      u32x4 qreg[4], kreg[2], vreg[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                               // queries: the wave's 64 features of 32 rows (8 chunks of 16 bytes per row)
+        const int c = lane + 64 * i;
+        qreg[i] = *reinterpret_cast<const u32x4*>(a.Q16 + (rowg0 + min(c >> 3, sub[s].nr - 1)) * 256 + 64 * w + 8 * (c & 7));
+      }
+      if (s == 0 || sub[s].b != sub[0].b) {                       // (wave-uniform) the sample's keys | values, rows Nk .. 15 cleared
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int c = lane + 64 * i, j = c >> 3;
+          const us16* kp = a.KV16 + ((size_t)sub[s].b * Nk + min(j, Nk - 1)) * 512 + 64 * w + 8 * (c & 7);
+          kreg[i] = *reinterpret_cast<const u32x4*>(kp); vreg[i] = *reinterpret_cast<const u32x4*>(kp + 256);
+          if (j >= Nk) { kreg[i] = u32x4{0u, 0u, 0u, 0u}; vreg[i] = kreg[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int c = lane + 64 * i;
+          *reinterpret_cast<u32x4*>(Ks + (c >> 3) * PS + 16 * (c & 7)) = kreg[i];
+          *reinterpret_cast<u32x4*>(Vs + (c >> 3) * PS + 16 * (c & 7)) = vreg[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; *reinterpret_cast<u32x4*>(Qs + (c >> 3) * PS + 16 * (c & 7)) = qreg[i]; }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)                                  // dO strip (bf16): read back transposed for dV
+        *reinterpret_cast<u32x2*>(dOs + l31 * PS + 2 * (32 * t + 8 * g + 4 * h)) =
+            rok[s] ? u32x2{pack2(acc2[s][t][4 * g], acc2[s][t][4 * g + 1]), pack2(acc2[s][t][4 * g + 2], acc2[s][t][4 * g + 3])} : u32x2{0u, 0u};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int head = 2 * w + t;
+      // scores and probabilities, exactly as bwd1_kernel recomputes them
+      f32x16 Sc = splat16(0.f);
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (l31 & 15) * PS + 2 * (32 * t + 16 * ss + 8 * h));
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + l31 * PS + 2 * (32 * t + 16 * ss + 8 * h));
+        Sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, Sc, 0, 0, 0);
+      }
+      float pr[8], mm[8];
+      rg_softmax(Sc, h, Nk, pr);
+      const uint32_t ibase = ((uint32_t)(rowg0 + l31) * 8u + (uint32_t)head) * (uint32_t)Nk;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mm[i] = DROP ? drop_mult(a.drop, SITE_ATTN_RG2KG, ibase + (uint32_t)acc_row(i, h)) : 1.0f;
+      // dPd^T[j][row] = V_h[j] . dO_h[row]: the dO accumulator is the B operand (k order of its registers), so the A fragment takes
+      // features 16 ss + 4 h .. + 3 and 16 ss + 8 + 4 h .. + 3 of value row j
+      f32x16 dP = splat16(0.f);
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const char* vp = Vs + (l31 & 15) * PS + 2 * (32 * t + 16 * ss + 4 * h);
+        const u32x2 v0 = *reinterpret_cast<const u32x2*>(vp), v1 = *reinterpret_cast<const u32x2*>(vp + 16);
+        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(u32x4{v0.x, v0.y, v1.x, v1.y}), as_frag(pack8(acc2[s][t], ss)), dP, 0, 0, 0);
+      }
+      float ds[8], pd[8], delta = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { ds[i] = dP[i] * mm[i]; delta = fmaf(pr[i], ds[i], delta); pd[i] = pr[i] * mm[i]; }
+      delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { ds[i] = rok[s] ? pr[i] * (ds[i] - delta) : 0.f; if (!rok[s]) pd[i] = 0.f; }
+      const u32x4 dsf = u32x4{pack2(ds[0], ds[1]), pack2(ds[2], ds[3]), pack2(ds[4], ds[5]), pack2(ds[6], ds[7])};
+      const u32x4 pdf = u32x4{pack2(pd[0], pd[1]), pack2(pd[2], pd[3]), pack2(pd[4], pd[5]), pack2(pd[6], pd[7])};
+      {   // dQ^T = scale * K_h^T . dS^T: lane = row
+        const char* kp = Ks + (4 * h + q4) * PS + 2 * (32 * t + 16 * g1 + 4 * p4);
+        const bf16x8 kt = join(lds_tr16(kp), lds_tr16(kp + 8 * PS));
+        const f32x16 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, as_frag(dsf), splat16(0.f), 0, 0, 0);
+        if (rok[s]) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<u32x2*>(a.dQKV16 + (rowg0 + l31) * 768 + 32 * head + 8 * g + 4 * h) =
+                u32x2{pack2(dq[4 * g] * a.qscale, dq[4 * g + 1] * a.qscale), pack2(dq[4 * g + 2] * a.qscale, dq[4 * g + 3] * a.qscale)};
+        }
+      }
+      // dS / Pd images [row][16 keys] (bf16): keys 4 h .. + 3 at byte 8 h, keys 8 + 4 h .. at byte 16 + 8 h
+      *reinterpret_cast<u32x2*>(imS + l31 * 32 + 8 * h) = u32x2{dsf.x, dsf.y};
+      *reinterpret_cast<u32x2*>(imS + l31 * 32 + 16 + 8 * h) = u32x2{dsf.z, dsf.w};
+      *reinterpret_cast<u32x2*>(imP + l31 * 32 + 8 * h) = u32x2{pdf.x, pdf.y};
+      *reinterpret_cast<u32x2*>(imP + l31 * 32 + 16 + 8 * h) = u32x2{pdf.z, pdf.w};
+      // dK_h[j][f] += sum_rows dS[j][row] Qs[row][f];  dV_h[j][f] += sum_rows Pd[j][row] dO[row][f]  (lane = f, registers = j)
+      f32x16 dK = splat16(0.f), dV = splat16(0.f);
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const int r0 = 16 * ss + 8 * h + q4;
+        const bf16x8 sA = join(lds_tr16(imS + r0 * 32 + 8 * p4), lds_tr16(imS + (r0 + 4) * 32 + 8 * p4));
+        const bf16x8 pA = join(lds_tr16(imP + r0 * 32 + 8 * p4), lds_tr16(imP + (r0 + 4) * 32 + 8 * p4));
+        const int co = 2 * (32 * t + 16 * g1 + 4 * p4);
+        const bf16x8 qB = join(lds_tr16(Qs + r0 * PS + co), lds_tr16(Qs + (r0 + 4) * PS + co));
+        const bf16x8 oB = join(lds_tr16(dOs + r0 * PS + co), lds_tr16(dOs + (r0 + 4) * PS + co));
+        dK = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sA, qB, dK, 0, 0, 0);
+        dV = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA, oB, dV, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = acc_row(i, h);
+        if (j < Nk) {
+          float* dst = a.dKV + ((size_t)sub[s].b * Nk + j) * 512 + 32 * head + l31;
+          atomicAdd(dst, dK[i]);
+          atomicAdd(dst + 256, dV[i]);
+        }
+      }
+    }
+  }
+  stamp(a.stamps, 12);
+}
+
+template <int DEPTH, bool DROP>
+int bwd1w_launch(const Bwd1Args& a, hipStream_t stream) {
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd1w_kernel<DEPTH, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, CfgB::LDS);
+    return true;
+  }();
+  (void)attr;
+  hipLaunchKernelGGL((bwd1w_kernel<DEPTH, DROP>), dim3((a.rg_tiles_max + RT - 1) / RT), dim3(NTH), CfgB::LDS, stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// The RG rows of the backward's first half on 64-row half-blocks; the KG rows (and the KG stream's dH16) through bwd1_kernel.
+int launch_wide2_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
+  const int rc = launch_fused_bwd1(a, variant, stream, /*kg_only=*/1);      // validates the whole argument block
+  if (rc != 0) return rc;
+  const double rows = (double)a.rows_rg;
+  const int prof = gemm_prof_open(stream, 2.0 * rows * (512.0 * 256.0 + 256.0 * 256.0) + 10.0 * rows * a.Nk * 256.0, PROF_BWD1);
+  Bwd1Args k = a;
+  k.stamps = nullptr;                                                        // (the developer timeline of bwd1_kernel has another layout)
+  const int rc2 = a.drop.p > 0.f ? bwd1w_launch<8, true>(k, stream) : bwd1w_launch<8, false>(k, stream);
+  gemm_prof_close(prof, stream);
+  return rc2;
+}

@@ -90,11 +90,13 @@ struct Bwd1Args {
   const int* off; const int* tile_off; const float* inv_nr; const int4* tile_desc;
   const int* row_sample;                       // RG row -> sample (the batch descriptor's table)
   int B, Nk, rg_tiles_max, rows_rg; float qscale; DropCfg drop; unsigned long long* stamps;
-  int writer_blocks;                           // (filled by the launcher)
+  int writer_blocks, writer_first_row;         // (filled by the launcher) dH16 writer blocks and the first row of [RG rows | KG rows] they cover
   // clears for the weight-gradient launch (pad rows of its operands) when no shadow launch did them: one extra block each
   void* zero_ptr[FUSED_BWD1_MAXZ]; unsigned zero_bytes[FUSED_BWD1_MAXZ]; int nzero;
 };
-int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream);
+int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream, int kg_only = 0);   // kg_only: the KG rows' blocks alone (launch_wide2_bwd1)
+// the RG rows on 64-row half-blocks (bwd_wide2.hip) + the KG rows through launch_fused_bwd1(kg_only); same arguments, outputs and saved set
+int launch_wide2_bwd1(Bwd1Args& a, int variant, hipStream_t stream);
 size_t fused_bwd1_lds();
 
 // ---- backward, second half (see fused_rows.hip)

@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256, 2) void bwd1_kernel(const Bwd1Args a) {
     const int wb = (int)blockIdx.x - a.B - a.rg_tiles_max;
     const int total_rows = a.rows_rg + a.B * a.Nk;
     const float gscale = a.drop.scale;
-    for (int r0 = (wb * 4 + (tid >> 6)) * WR; r0 < total_rows; r0 += 4 * WR * a.writer_blocks) {
+    for (int r0 = a.writer_first_row + (wb * 4 + (tid >> 6)) * WR; r0 < total_rows; r0 += 4 * WR * a.writer_blocks) {
       int sb[WR]; uint32_t word[WR]; bool isk[WR]; int row[WR];
 #pragma unroll
       for (int k = 0; k < WR; ++k) {
@@ -1495,7 +1495,7 @@ int launch_fused_back(BackArgs& a, int variant, hipStream_t stream) {
 
 size_t fused_bwd1_lds() { return W_LDS; }
 
-int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
+int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream, int kg_only) {
   if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q16 || !a.KV16 || !a.dQKV16 || !a.dKV || !a.O2_16 || !a.dO2_16 || !a.delta2 ||
       !a.off || !a.tile_off || !a.tile_desc || !a.inv_nr || !a.row_sample)
     return (int)hipErrorInvalidValue;
@@ -1512,17 +1512,21 @@ int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
     return true;
   }();
   (void)attr;
-  a.writer_blocks = (a.rows_rg + a.B * a.Nk + 15) / 16;              // four rows per wave per pass (see the kernel; eight: the same at B = 64, -5 us at B = 256)
+  // kg_only (launch_wide2_bwd1 takes the RG rows, their dH16 included): no RG tile blocks, writer blocks for the KG stream's rows only
+  a.writer_first_row = kg_only ? a.rows_rg : 0;
+  a.writer_blocks = (a.rows_rg + a.B * a.Nk - a.writer_first_row + 15) / 16;   // four rows per wave per pass (see the kernel; eight: the same at B = 64, -5 us at B = 256)
   if (a.writer_blocks > 8192) a.writer_blocks = 8192;
   if (a.nzero < 0 || a.nzero > FUSED_BWD1_MAXZ) return (int)hipErrorInvalidValue;
   for (int i = 0; i < a.nzero; ++i)
     if (!a.zero_ptr[i] || !al16(a.zero_ptr[i]) || (a.zero_bytes[i] & 15)) return (int)hipErrorInvalidValue;
-  const dim3 grid(a.B + a.rg_tiles_max + a.writer_blocks + a.nzero);
+  Bwd1Args k = a;                                                    // (the kernel decodes a block's role from rg_tiles_max)
+  if (kg_only) k.rg_tiles_max = 0;
+  const dim3 grid(k.B + k.rg_tiles_max + k.writer_blocks + k.nzero);
   // executed FLOPs per row: dY (512 -> 256), dO (256 -> 256); RG rows: the RG->KG attention backward (5 products of Nk x 256)
-  const double rows = (double)a.rows_rg + (double)a.B * a.Nk;
-  const int prof = gemm_prof_open(stream, 2.0 * rows * (512.0 * 256.0 + 256.0 * 256.0) + 10.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BWD1);
-  if (variant == 0) hipLaunchKernelGGL((bwd1_kernel<12, false>), grid, dim3(256), W_LDS, stream, a);
-  else              hipLaunchKernelGGL((bwd1_kernel<12, true>), grid, dim3(256), W_LDS, stream, a);
+  const double rows = (kg_only ? 0.0 : (double)a.rows_rg) + (double)a.B * a.Nk;
+  const int prof = gemm_prof_open(stream, 2.0 * rows * (512.0 * 256.0 + 256.0 * 256.0) + (kg_only ? 0.0 : 10.0 * (double)a.rows_rg * a.Nk * 256.0), PROF_BWD1);
+  if (variant == 0) hipLaunchKernelGGL((bwd1_kernel<12, false>), grid, dim3(256), W_LDS, stream, k);
+  else              hipLaunchKernelGGL((bwd1_kernel<12, true>), grid, dim3(256), W_LDS, stream, k);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }

@@ -37,7 +37,7 @@ thread_local std::string g_err;
 // option state lives in the library: two engines in one process cannot change each other's schedule.
 constexpr camo_options_t k_default_options = {/*sched16*/ -1, /*fused*/ -1, /*tail17*/ -1, /*fused_rt*/ -1, /*wide2*/ -1, /*fused_one*/ 1, /*wide_front_rt*/ 0,
                                               /*tailw*/ -1, /*tailw_bwd*/ -1, /*param_space*/ -1, /*tn_big*/ -1, /*fused_variant*/ 1, /*back_lead*/ 1,
-                                              /*tn_balance*/ 1, /*tn_kcap*/ 0, /*tn_exp*/ 0, /*exp*/ 0, /*fused_save*/ 0, /*tail_skip_arrival*/ 0};
+                                              /*tn_balance*/ 1, /*tn_kcap*/ 0, /*tn_exp*/ 0, /*exp*/ 0, /*fused_save*/ 0, /*tail_skip_arrival*/ 0, /*wide2_bwd*/ -1};
 static thread_local const camo_options_t* t_opt = &k_default_options;
 struct OptScope {                     // binds the caller's options (and the other translation units' per-call copies) for one entry-point call
   const camo_options_t* prev;
@@ -56,6 +56,7 @@ struct OptScope {                     // binds the caller's options (and the oth
 #define g_opt_fused_variant (t_opt->fused_variant)
 #define g_opt_fused_rt (t_opt->fused_rt)
 #define g_opt_wide2 (t_opt->wide2)
+#define g_opt_wide2_bwd (t_opt->wide2_bwd)
 #define g_opt_fused_one (t_opt->fused_one)
 #define g_opt_wide_front_rt (t_opt->wide_front_rt)
 #define g_opt_tailw_bwd (t_opt->tailw_bwd)
@@ -898,7 +899,10 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   a1.nzero = t_nzero_bwd1;
   for (int i = 0; i < t_nzero_bwd1; ++i) { a1.zero_ptr[i] = t_zero_bwd1_ptr[i]; a1.zero_bytes[i] = t_zero_bwd1_bytes[i]; }
   t_nzero_bwd1 = 0;
-  CK(launch_fused_bwd1(a1, g_opt_fused_variant, st), "fused backward, first half");
+  // the RG rows of the first half on 64-row half-blocks (bwd_wide2.hip) by size -- the threshold of the 64-row training forward
+  const bool bwd1w = g_opt_wide2_bwd != 0 && (g_opt_wide2_bwd > 0 || (g_opt_fused_rt < 0 && T >= 57344));
+  if (bwd1w) CK(launch_wide2_bwd1(a1, g_opt_fused_variant, st), "fused backward, first half (64-row half-blocks)");
+  else       CK(launch_fused_bwd1(a1, g_opt_fused_variant, st), "fused backward, first half");
   Bwd2Args a2; std::memset(&a2, 0, sizeof(a2));
   a2.Q2_16 = f.Q2_16; a2.dO2_16 = f.dO2_16; a2.lse2 = f.lse2; a2.delta2 = f.delta2; a2.KV2_16 = f.KV2_16; a2.dQKV16 = f.dQKV16;
   a2.dU16 = f.dU16; a2.WcRgT = f.WcRgT; a2.dR16 = f.dR16; a2.dQ2acc = w.dQ2acc; a2.dKV = w.dKV;
@@ -1490,7 +1494,7 @@ int camo_options_set(camo_options_t* o, const char* name, int32_t value) {
       {"tailw_bwd", &camo_options_t::tailw_bwd}, {"param_space", &camo_options_t::param_space}, {"tn_big", &camo_options_t::tn_big},
       {"fused_variant", &camo_options_t::fused_variant}, {"back_lead", &camo_options_t::back_lead}, {"tn_balance", &camo_options_t::tn_balance},
       {"tn_kcap", &camo_options_t::tn_kcap}, {"tn_exp", &camo_options_t::tn_exp}, {"exp", &camo_options_t::exp}, {"fused_save", &camo_options_t::fused_save},
-      {"tail_skip_arrival", &camo_options_t::tail_skip_arrival}};
+      {"tail_skip_arrival", &camo_options_t::tail_skip_arrival}, {"wide2_bwd", &camo_options_t::wide2_bwd}};
   for (const Field& f : fields)
     if (std::strcmp(name, f.name) == 0) { o->*(f.m) = value; return 0; }
   return fail(CAMO_E_ARG, std::string("unknown option ") + name);

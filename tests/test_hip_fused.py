@@ -26,7 +26,7 @@ def _opt(name, value):
 @pytest.fixture
 def fused_opts():
     yield _opt
-    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1); _opt("fused_rt", -1); _opt("tailw", -1); _opt("fused_one", 1); _opt("tn_big", -1); _opt("param_space", -1); _opt("tailw_bwd", -1); _opt("wide2", -1)
+    _opt("fused", -1); _opt("fused_save", 0); _opt("sched16", -1); _opt("tail17", -1); _opt("fused_rt", -1); _opt("tailw", -1); _opt("fused_one", 1); _opt("tn_big", -1); _opt("param_space", -1); _opt("tailw_bwd", -1); _opt("wide2", -1); _opt("wide2_bwd", -1)
 
 
 def bf16_round(x):
@@ -164,13 +164,14 @@ def test_fused_forward_shapes(nrs, nk, rt, fused_opts):
     assert_close(got, outs6(ref), 1e-3, 0, f"nrs={nrs[:4]} nk={nk}")
 
 
-@pytest.mark.parametrize("wide2", [0, 1])
+@pytest.mark.parametrize("wide2", [0, 1, 2])
 @pytest.mark.parametrize("training", [False, True])
 def test_fused_backward_stage_by_stage(training, wide2, kg_real, fused_opts):
     """The fused backward kernels against the intermediate activation gradients of the oracle in its bf16-operand mode, then every
     parameter gradient: absolute bounds (global relative error < 0.2 %, every tensor that carries weight < 1 %; measured 0.002-0.01 %
     and <= 0.1 %), no other HIP schedule as a yardstick."""
-    fused_opts("wide2", wide2)                  # (1: the forward that saves for these backward kernels is the 64-row one, fused_wide2.hip)
+    fused_opts("wide2", min(wide2, 1))          # (1: the forward that saves for these backward kernels is the 64-row one, fused_wide2.hip)
+    fused_opts("wide2_bwd", 1 if wide2 == 2 else 0)      # (2: ... and the RG rows' first backward half runs on 64-row half-blocks too, bwd_wide2.hip)
     cfg = OP.full_cfg()
     prm = OP.make_params(cfg, 0)
     m = make_model(cfg, 0, "bf16")
@@ -318,7 +319,7 @@ def _training_step_shape_envelope(nrs, nk, pseed, fused_opts, wide2):
     seed 6 the six-sample case has head units whose pre-activation sits within bf16 noise of zero in three samples: against
     the reference-exact f32 oracle one such ReLU flip moves instance_head.0.bias by 18 % (tools/dev/dev_relu_flip.py); the bf16-operand
     oracle rounds what the kernels round and lands on the same side.  The f32 oracle still bounds the logits (north_star: 1e-3)."""
-    fused_opts("wide2", wide2)
+    fused_opts("wide2", wide2); fused_opts("wide2_bwd", wide2)      # (1: forward AND the backward's first half on 64-row half-blocks)
     cfg = OP.full_cfg()
     m = make_model(cfg, pseed, "bf16").train()
     eng = m._engine
