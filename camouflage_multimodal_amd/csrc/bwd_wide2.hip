@@ -34,10 +34,10 @@ struct CfgB {
   static constexpr int ST = DU + ROWS * PR;                      // per-wave strips [ROWS][64] (pitch PS): column-sum planes; then queries | dO
   static constexpr int STRIP = ROWS * PS;
   static constexpr int LDS = ST + NW * STRIP;
-  static constexpr int WSCR = ROWS * PR / NW;                    // 8448 bytes: keys [16][64] | values [16][64] (pitch PS) | dS, Pd images [32][16] of one head
-  static constexpr int W_KS = 0, W_VS = 16 * PS, W_IMG = 32 * PS;
+  static constexpr int WSCR = ROWS * PR / NW;                    // 8448 bytes: keys [16][64] (pitch PS) | dS, Pd images [32][16] of each of the wave's two heads
+  static constexpr int W_KS = 0, W_IMG = 16 * PS;
   static_assert(ROWS * PH <= ROWS * PR + NW * STRIP, "the dH tile aliases [dU tile | strips]");
-  static_assert(W_IMG + 2048 <= WSCR, "per-wave attention scratch");
+  static_assert(W_IMG + 4096 <= WSCR, "per-wave attention scratch");
   static_assert(LDS <= 81920, "two blocks per CU");
 };
 
@@ -147,6 +147,19 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
   stamp(a.stamps, 2);
   Stage<RT, 2, 16, 2, DEPTH> st2;
   // ---- LayerNorm backward: g = dy gamma; du = (g - mean(g) - xhat mean(g xhat)) / std; dgamma += dy xhat, dbeta += dy
+  // rows past a sub-tile's end: dy and xhat cleared once (then g, both row sums and du are exactly 0 there and the column sums skip
+  // them); full sub-tiles -- the common case -- carry no masks at all
+  if (sub[0].nr < 32 || sub[1].nr < 32) {                           // (wave-uniform)
+#pragma unroll
+    for (int s = 0; s < RT; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[s][t][i] = rok[s] ? acc1[s][t][i] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xv[s][t][g] = rok[s] ? xv[s][t][g] : u32x2{0u, 0u};
+      }
+  }
 #pragma unroll
   for (int s = 0; s < RT; ++s) {
     float s1 = 0.f, s2 = 0.f;
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
       const float2 p = *reinterpret_cast<const float2*>(red + 2 * (ww * ROWS + 32 * s + l31));
       m1 += p.x; m2 += p.y;
     }
-    m1 *= (1.0f / 256.0f); m2 *= (1.0f / 256.0f);
+    const float nm1 = -m1 * (1.0f / 256.0f), nm2 = -m2 * (1.0f / 256.0f);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -183,12 +196,14 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
         const float X[4] = {bf_lo(x.x), bf_hi(x.x), bf_lo(x.y), bf_hi(x.y)};
         float du[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) du[j] = rok[s] ? (acc1[s][t][4 * g + j] * gm[j] - m1 - X[j] * m2) * rstd[s] : 0.f;
+        for (int j = 0; j < 4; ++j) du[j] = fmaf(X[j], nm2, fmaf(acc1[s][t][4 * g + j], gm[j], nm1)) * rstd[s];
         *reinterpret_cast<u32x2*>(bufdU + (32 * s + l31) * PR + 2 * c0) = u32x2{pack2(du[0], du[1]), pack2(du[2], du[3])};
       }
   }
-  // column sums over the block's valid rows of dy xhat (q = 0: dgamma) and dy (q = 1: dbeta), this wave's 64 features: the values go
-  // through the wave's strip as bf16 hi and lo planes and come back as MFMAs against the identity (lane = feature, registers = rows)
+  // column sums over the block's rows of dy xhat (dgamma) and dy (dbeta), this wave's 64 features.  The two sub-tiles' values of one
+  // (row slot, feature) are added in the lane first; the sums go through the wave's strip as bf16 hi planes (dy xhat: strip rows
+  // 0 .. 31, dy: rows 32 .. 63), then lo planes (exact to 2^-17), and come back as MFMAs against the identity: lane = feature,
+  // registers = row slots -- an fp32 tile in LDS summed by one thread per column costs 64 KB for these rows
   {
     u32x4 idf[2];
 #pragma unroll
@@ -198,46 +213,89 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
       idf[kk] = u32x4{j == 0 ? one_lo : (j == 1 ? one_hi : 0u), j == 2 ? one_lo : (j == 3 ? one_hi : 0u),
                       j == 4 ? one_lo : (j == 5 ? one_hi : 0u), j == 6 ? one_lo : (j == 7 ? one_hi : 0u)};
     }
+    u32x2 lo[2][2][4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      f32x16 p[2] = {splat16(0.f), splat16(0.f)};
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
+      for (int g = 0; g < 4; ++g) {
+        const u32x2 x0 = xv[0][t][g], x1 = xv[1][t][g];
+        const float X0[4] = {bf_lo(x0.x), bf_hi(x0.x), bf_lo(x0.y), bf_hi(x0.y)}, X1[4] = {bf_lo(x1.x), bf_hi(x1.x), bf_lo(x1.y), bf_hi(x1.y)};
+        float v0[4], v1[4];
 #pragma unroll
-        for (int s = 0; s < RT; ++s)
+        for (int j = 0; j < 4; ++j) {
+          v0[j] = fmaf(acc1[0][t][4 * g + j], X0[j], acc1[1][t][4 * g + j] * X1[j]);
+          v1[j] = acc1[0][t][4 * g + j] + acc1[1][t][4 * g + j];
+        }
+        const u32x2 h0 = u32x2{pack2(v0[0], v0[1]), pack2(v0[2], v0[3])}, h1 = u32x2{pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
+        lo[0][t][g] = u32x2{pack2(v0[0] - bf_lo(h0.x), v0[1] - bf_hi(h0.x)), pack2(v0[2] - bf_lo(h0.y), v0[3] - bf_hi(h0.y))};
+        lo[1][t][g] = u32x2{pack2(v1[0] - bf_lo(h1.x), v1[1] - bf_hi(h1.x)), pack2(v1[2] - bf_lo(h1.y), v1[3] - bf_hi(h1.y))};
+        *reinterpret_cast<u32x2*>(strip + l31 * PS + 2 * (32 * t + 8 * g + 4 * h)) = h0;
+        *reinterpret_cast<u32x2*>(strip + (32 + l31) * PS + 2 * (32 * t + 8 * g + 4 * h)) = h1;
+      }
+    f32x16 p[2][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      if (pl == 1) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const u32x2 x = xv[s][t][g];
-              const float X[4] = {bf_lo(x.x), bf_hi(x.x), bf_lo(x.y), bf_hi(x.y)};
-              float v[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = rok[s] ? (q == 0 ? acc1[s][t][4 * g + j] * X[j] : acc1[s][t][4 * g + j]) : 0.f;
-              u32x2 o = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
-              if (pl == 1) o = u32x2{pack2(v[0] - bf_lo(o.x), v[1] - bf_hi(o.x)), pack2(v[2] - bf_lo(o.y), v[3] - bf_hi(o.y))};
-              *reinterpret_cast<u32x2*>(strip + (32 * s + l31) * PS + 2 * (32 * t + 8 * g + 4 * h)) = o;
-            }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int s = 0; s < RT; ++s) {
-            const char* yp = strip + (32 * s + l31) * PS + 64 * t + 16 * h;
-            p[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(yp), as_frag(idf[0]), p[t], 0, 0, 0);
-            p[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(yp + 32), as_frag(idf[1]), p[t], 0, 0, 0);
-          }
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2*>(strip + (32 * q + l31) * PS + 2 * (32 * t + 8 * g + 4 * h)) = lo[q][t][g];
       }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const char* yp = strip + (32 * q + l31) * PS + 64 * t + 16 * h;
+          p[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(yp), as_frag(idf[0]), pl == 0 ? splat16(0.f) : p[q][t], 0, 0, 0);
+          p[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(yp + 32), as_frag(idf[1]), p[q][t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         float c = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) c += p[t][i];
+        for (int i = 0; i < 16; ++i) c += p[q][t][i];
         c += __shfl_xor(c, 32, 64);
         if (h == 0) atomicAdd((q == 0 ? S.dgamma : S.dbeta) + 64 * w + 32 * t + l31, c);
       }
-    }
   }
   st2.prefetch(S.WoT, w * (16 * 2), lane);                        // (in front of the barrier: the column sums above need the registers)
+  // the first sub-tile's attention operands start now and land under the dO product: queries (the wave's 64 features of 32 rows, 8
+  // chunks of 16 bytes per row), the sample's keys (-> LDS, for the transposing reads) and its values as A fragments straight from L2
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+  u32x4 qreg[4], kreg[2]; u32x2 vfr[2][2][2];
+  auto load_q = [&](int row0, int nr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      qreg[i] = *reinterpret_cast<const u32x4*>(a.Q16 + ((size_t)row0 + max(0, min(c >> 3, nr - 1))) * 256 + 64 * w + 8 * (c & 7));
+    }
+  };
+  auto load_kv = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = lane + 64 * i, j = c >> 3;
+      kreg[i] = *reinterpret_cast<const u32x4*>(a.KV16 + ((size_t)b * Nk + min(j, Nk - 1)) * 512 + 64 * w + 8 * (c & 7));
+      if (j >= Nk) kreg[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    // value row j = lane & 15, features 16 ss + 4 h .. + 3 and + 8 .. of head t: the k order of the dO accumulator's registers
+    const int j = l31 & 15;
+    const us16* vp = a.KV16 + ((size_t)b * Nk + min(j, Nk - 1)) * 512 + 256 + 64 * w + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        vfr[t][ss][0] = *reinterpret_cast<const u32x2*>(vp + 32 * t + 16 * ss);
+        vfr[t][ss][1] = *reinterpret_cast<const u32x2*>(vp + 32 * t + 16 * ss + 8);
+        if (j >= Nk) { vfr[t][ss][0] = u32x2{0u, 0u}; vfr[t][ss][1] = u32x2{0u, 0u}; }
+      }
+  };
+  load_q(sub[0].row0, sub[0].nr);
+  load_kv(sub[0].b);
   __syncthreads();                                                // dU tile complete
   stamp(a.stamps, 3);
   // ---- dO = dU . Wo (lane = row, registers = the features of heads 2 w, 2 w + 1)
@@ -254,39 +312,30 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
     if (rr < nr_s) store16_wt(S.dU16 + ((size_t)row0_s + rr) * 256 + 8 * k, *reinterpret_cast<const u32x4*>(bufdU + r * PR + 16 * k));
   }
   __syncthreads();                                                // the dU tile's space becomes per-wave scratch
-  // ---- RG->KG attention backward, one sub-tile at a time, out of this wave's own LDS (no block barriers from here on)
+  stamp(a.stamps, 5);
+  // ---- RG->KG attention backward, one sub-tile at a time, out of this wave's own LDS (no block barriers from here on); the two heads
+  // of a sub-tile share nothing but read-only tiles (their own dS / Pd images), so their chains overlap
   char* Qs = strip; char* dOs = strip + 32 * PS;
   char* wscr = smem + CfgB::DU + w * CfgB::WSCR;
-  char* Ks = wscr + CfgB::W_KS; char* Vs = wscr + CfgB::W_VS; char* imS = wscr + CfgB::W_IMG; char* imP = imS + 1024;
-  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+  char* Ks = wscr + CfgB::W_KS;
 #pragma unroll
   for (int s = 0; s < RT; ++s) {
     if (sub[s].nr == 0) break;
     const size_t rowg0 = (size_t)sub[s].row0;
-    {
-      u32x4 qreg[4], kreg[2], vreg[2];
+    if (s == 0 || sub[s].b != sub[0].b) {                         // (wave-uniform) a new sample's keys
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {                               // queries: the wave's 64 features of 32 rows (8 chunks of 16 bytes per row)
-        const int c = lane + 64 * i;
-        qreg[i] = *reinterpret_cast<const u32x4*>(a.Q16 + (rowg0 + min(c >> 3, sub[s].nr - 1)) * 256 + 64 * w + 8 * (c & 7));
-      }
-      if (s == 0 || sub[s].b != sub[0].b) {                       // (wave-uniform) the sample's keys | values, rows Nk .. 15 cleared
+      for (int i = 0; i < 2; ++i) { const int c = lane + 64 * i; *reinterpret_cast<u32x4*>(Ks + (c >> 3) * PS + 16 * (c & 7)) = kreg[i]; }
+    }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int c = lane + 64 * i, j = c >> 3;
-          const us16* kp = a.KV16 + ((size_t)sub[s].b * Nk + min(j, Nk - 1)) * 512 + 64 * w + 8 * (c & 7);
-          kreg[i] = *reinterpret_cast<const u32x4*>(kp); vreg[i] = *reinterpret_cast<const u32x4*>(kp + 256);
-          if (j >= Nk) { kreg[i] = u32x4{0u, 0u, 0u, 0u}; vreg[i] = kreg[i]; }
-        }
+    for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; *reinterpret_cast<u32x4*>(Qs + (c >> 3) * PS + 16 * (c & 7)) = qreg[i]; }
+    u32x2 vf[2][2][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int c = lane + 64 * i;
-          *reinterpret_cast<u32x4*>(Ks + (c >> 3) * PS + 16 * (c & 7)) = kreg[i];
-          *reinterpret_cast<u32x4*>(Vs + (c >> 3) * PS + 16 * (c & 7)) = vreg[i];
-        }
-      }
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; *reinterpret_cast<u32x4*>(Qs + (c >> 3) * PS + 16 * (c & 7)) = qreg[i]; }
+      for (int ss = 0; ss < 2; ++ss) { vf[t][ss][0] = vfr[t][ss][0]; vf[t][ss][1] = vfr[t][ss][1]; }
+    if (s + 1 < RT && sub[RT - 1].nr > 0) {                       // the next sub-tile's operands, under this one's attention
+      load_q(sub[RT - 1].row0, sub[RT - 1].nr);
+      if (sub[RT - 1].b != sub[0].b) load_kv(sub[RT - 1].b);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -297,6 +346,7 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int head = 2 * w + t;
+      char* imS = wscr + CfgB::W_IMG + 2048 * t; char* imP = imS + 1024;
       // scores and probabilities, exactly as bwd1_kernel recomputes them
       f32x16 Sc = splat16(0.f);
 #pragma unroll
@@ -310,15 +360,11 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
       const uint32_t ibase = ((uint32_t)(rowg0 + l31) * 8u + (uint32_t)head) * (uint32_t)Nk;
 #pragma unroll
       for (int i = 0; i < 8; ++i) mm[i] = DROP ? drop_mult(a.drop, SITE_ATTN_RG2KG, ibase + (uint32_t)acc_row(i, h)) : 1.0f;
-      // dPd^T[j][row] = V_h[j] . dO_h[row]: the dO accumulator is the B operand (k order of its registers), so the A fragment takes
-      // features 16 ss + 4 h .. + 3 and 16 ss + 8 + 4 h .. + 3 of value row j
+      // dPd^T[j][row] = V_h[j] . dO_h[row]: the dO accumulator is the B operand (k order of its registers)
       f32x16 dP = splat16(0.f);
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const char* vp = Vs + (l31 & 15) * PS + 2 * (32 * t + 16 * ss + 4 * h);
-        const u32x2 v0 = *reinterpret_cast<const u32x2*>(vp), v1 = *reinterpret_cast<const u32x2*>(vp + 16);
-        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(u32x4{v0.x, v0.y, v1.x, v1.y}), as_frag(pack8(acc2[s][t], ss)), dP, 0, 0, 0);
-      }
+      for (int ss = 0; ss < 2; ++ss)
+        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(u32x4{vf[t][ss][0].x, vf[t][ss][0].y, vf[t][ss][1].x, vf[t][ss][1].y}), as_frag(pack8(acc2[s][t], ss)), dP, 0, 0, 0);
       float ds[8], pd[8], delta = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { ds[i] = dP[i] * mm[i]; delta = fmaf(pr[i], ds[i], delta); pd[i] = pr[i] * mm[i]; }
@@ -389,8 +435,7 @@ int launch_wide2_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
   if (rc != 0) return rc;
   const double rows = (double)a.rows_rg;
   const int prof = gemm_prof_open(stream, 2.0 * rows * (512.0 * 256.0 + 256.0 * 256.0) + 10.0 * rows * a.Nk * 256.0, PROF_BWD1);
-  Bwd1Args k = a;
-  k.stamps = nullptr;                                                        // (the developer timeline of bwd1_kernel has another layout)
+  const Bwd1Args& k = a;
   const int rc2 = a.drop.p > 0.f ? bwd1w_launch<8, true>(k, stream) : bwd1w_launch<8, false>(k, stream);
   gemm_prof_close(prof, stream);
   return rc2;

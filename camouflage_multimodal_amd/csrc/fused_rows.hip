@@ -1520,7 +1520,7 @@ int launch_fused_bwd1(Bwd1Args& a, int variant, hipStream_t stream, int kg_only)
   for (int i = 0; i < a.nzero; ++i)
     if (!a.zero_ptr[i] || !al16(a.zero_ptr[i]) || (a.zero_bytes[i] & 15)) return (int)hipErrorInvalidValue;
   Bwd1Args k = a;                                                    // (the kernel decodes a block's role from rg_tiles_max)
-  if (kg_only) k.rg_tiles_max = 0;
+  if (kg_only) { k.rg_tiles_max = 0; k.stamps = nullptr; }           // (the timeline region belongs to the RG rows' launch then)
   const dim3 grid(k.B + k.rg_tiles_max + k.writer_blocks + k.nzero);
   // executed FLOPs per row: dY (512 -> 256), dO (256 -> 256); RG rows: the RG->KG attention backward (5 products of Nk x 256)
   const double rows = (kg_only ? 0.0 : (double)a.rows_rg) + (double)a.B * a.Nk;

@@ -899,8 +899,10 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   a1.nzero = t_nzero_bwd1;
   for (int i = 0; i < t_nzero_bwd1; ++i) { a1.zero_ptr[i] = t_zero_bwd1_ptr[i]; a1.zero_bytes[i] = t_zero_bwd1_bytes[i]; }
   t_nzero_bwd1 = 0;
-  // the RG rows of the first half on 64-row half-blocks (bwd_wide2.hip) by size -- the threshold of the 64-row training forward
-  const bool bwd1w = g_opt_wide2_bwd != 0 && (g_opt_wide2_bwd > 0 || (g_opt_fused_rt < 0 && T >= 57344));
+  // the RG rows of the first half on 64-row half-blocks (bwd_wide2.hip) from 16 384 packed rows (training step, ms without / with:
+  // B = 24 0.209 / 0.217, B = 32 0.2395 / 0.237, B = 48 0.307 / 0.301, B = 64 0.355 / 0.349, B = 128 0.632 / 0.615, B = 256 1.007 / 0.944,
+  // B = 1024 3.215 / 2.815) -- behind either forward: the saved set is the same
+  const bool bwd1w = g_opt_wide2_bwd != 0 && (g_opt_wide2_bwd > 0 || (g_opt_fused_rt < 0 && T >= 16384));
   if (bwd1w) CK(launch_wide2_bwd1(a1, g_opt_fused_variant, st), "fused backward, first half (64-row half-blocks)");
   else       CK(launch_fused_bwd1(a1, g_opt_fused_variant, st), "fused backward, first half");
   Bwd2Args a2; std::memset(&a2, 0, sizeof(a2));

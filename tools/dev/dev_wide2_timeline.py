@@ -88,3 +88,23 @@ print("   the 8 blocks that started last: index", bi[late].tolist(), "XCD", x[la
 order = np.argsort(bi)
 ds = np.diff(start[order]) / 100
 print(f"   start-time gaps between consecutive block indices: median {np.median(ds):.3f} us, p99 {np.percentile(ds, 99):.2f}, max {ds.max():.2f}")
+
+# ---- the backward's first half on 64-row half-blocks (bwd_wide2.hip): region 2 of the stamp buffer, the same [block][wave][slot] layout
+if train:
+    rawb = buf.cpu().numpy().reshape(5, NB // 16, 8, 16).astype(np.float64)[2]
+    sb = rawb[:grid, :4, :]
+    actb = (sb[:, 0, 0] > 0) & (sb[:, 0, 12] > 0)
+    if actb.any():
+        sb = sb[actb]
+        bnames = {1: "tables + dH tile in LDS (2 barriers)", 2: "dH16 rows out + dY MFMAs (K = 512)", 3: "LayerNorm backward + column-sum MFMAs (2 barriers)",
+                  4: "dO MFMAs (K = 256) (barrier)", 5: "dU16 rows out (barrier)", 12: "RG->KG attention backward, 2 sub-tiles"}
+        tzb = sb[:, :, 0].min(); endb = sb[:, :, 12].max(axis=1); startb = sb[:, :, 0].min(axis=1)
+        print(f"--- bwd1w: {actb.sum()} blocks, span {(endb.max() - tzb) / 100:.2f} us; block time median {np.median(endb - startb) / 100:.2f} max {(endb - startb).max() / 100:.2f}")
+        prev = 0
+        for slot in sorted(bnames):
+            d = (sb[:, :, slot] - sb[:, :, prev]) / 100
+            rel = (sb[:, :, slot] - sb[:, :, 0].min(axis=1, keepdims=True)) / 100
+            print(f"   {slot:2d} {bnames[slot]:52s} wave-median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} | reached at median {np.median(rel):6.2f}")
+            prev = slot
+        pts = np.linspace(tzb, endb.max(), 12)[1:-1]
+        print("   running blocks over the span:", [int(((startb <= p) & (endb > p)).sum()) for p in pts])
