@@ -114,6 +114,7 @@ struct Bwd2Args {
   const int* off; const int* tile_off; const int4* tile_desc;
   int B, Nk, rg_tiles_max, rows_rg; float qscale; DropCfg drop; unsigned long long* stamps;
   int param_space;                             // 1: no dR / dG products (bwd2p_kernel): the caller takes the projections' weight gradients in parameter space
+  int split_finish;                            // (param_space only) 1: no arrival protocol -- the KG rows' dQ2 sums become bf16 in a second, B-block launch
 };
 int launch_fused_bwd2(Bwd2Args& a, int variant, hipStream_t stream);
 size_t fused_bwd2_lds();

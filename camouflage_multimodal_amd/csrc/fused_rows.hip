@@ -1367,6 +1367,9 @@ __global__ __launch_bounds__(256, 2) void bwd2p_kernel(const Bwd2Args a) {
   copy_out<6>(bufT, PQ, 512, a.dQKV16 + 256, 768, rowg0, nrows);     // the weight-gradient operand's dK2 | dV2 columns (dQ: the first half's)
   stamp(a.stamps, 2);
   }
+  // large batches: no arrival protocol (a drain of the tile's stores, a ticket round trip and three barriers per 32-row tile: a quarter
+  // of a tile block's life) -- bwd2_finish_kernel converts the dQ2 sums behind this launch
+  if (a.split_finish) return;
   // ---- arrival: the last block of the sample (its RG tiles and its early block) finishes the KG rows' product.  What it reads from the other
   // tiles are the dQ2 sums, fp32 atomics that execute at the memory side (no L2 line to write back), so a tile only has
   // to have its atomics acknowledged (vmcnt) before its ticket; everything else it reads is the previous launch's.
@@ -1395,6 +1398,18 @@ __global__ __launch_bounds__(256, 2) void bwd2p_kernel(const Bwd2Args a) {
   __syncthreads();
   copy_out<5>(bufT, PQ, 0, a.dQKVkg16, 768, krow0, Nk);
   stamp(a.stamps, 3);
+}
+
+// dQ2 of every sample's Nk rows: fp32 sums (complete: the previous launch's atomics) -> columns 0 .. 255 of the KG rows' weight-gradient
+// operand (bf16) -- what the last-arriving tile block of bwd2p_kernel does when the arrival protocol is on.  One block per sample.
+__global__ __launch_bounds__(256) void bwd2_finish_kernel(const Bwd2Args a) {
+  const size_t krow0 = (size_t)blockIdx.x * a.Nk;
+  for (int c = threadIdx.x; c < a.Nk * 32; c += 256) {
+    const int j = c >> 5, ch = c & 31;
+    const float* src = a.dQ2acc + (krow0 + j) * 256 + 8 * ch;
+    const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+    *reinterpret_cast<u32x4*>(a.dQKVkg16 + (krow0 + j) * 768 + 8 * ch) = u32x4{pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w)};
+  }
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1549,8 +1564,10 @@ int launch_fused_bwd2(Bwd2Args& a, int variant, hipStream_t stream) {
   // attention backward (5 products of Nk x 256)
   const double rows = (double)a.rows_rg + (double)a.B * a.Nk;
   const int prof = gemm_prof_open(stream, (a.param_space ? 0.0 : 2.0 * rows * 768.0 * 256.0) + 10.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BWD2);
+  if (!a.param_space) a.split_finish = 0;
   if (a.param_space) hipLaunchKernelGGL((bwd2p_kernel<12, false>), dim3(a.B + a.rg_tiles_max), dim3(256), X_LDS, stream, a);
   else               hipLaunchKernelGGL((bwd2_kernel<12, false>), dim3(a.B + a.rg_tiles_max), dim3(256), X_LDS, stream, a);
+  if (a.split_finish) hipLaunchKernelGGL(bwd2_finish_kernel, dim3(a.B), dim3(256), 0, stream, a);
   gemm_prof_close(prof, stream);
   return (int)hipGetLastError();
 }

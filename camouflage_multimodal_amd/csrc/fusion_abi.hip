@@ -913,6 +913,7 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   a2.B = B; a2.Nk = Nk; a2.rows_rg = T; a2.rg_tiles_max = T / 32 + B; a2.qscale = a1.qscale; a2.drop = drop;
   a2.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)3 * g_dbg_stamp_blocks * 8 : nullptr;
   a2.param_space = param_space ? 1 : 0;
+  a2.split_finish = (param_space && bwd1w) ? 1 : 0;        // (by the size rule of the wide first half: the extra launch costs ~2 us)
   CK(launch_fused_bwd2(a2, g_opt_fused_variant, st), "fused backward, second half");
   // every node-level weight gradient: dW += dy^T . x over the rows of a stream (bf16 operands the fused kernels wrote)
   if (!param_space) {
