@@ -26,18 +26,25 @@ namespace {
 
 constexpr int PH = 1040;     // row pitch (bytes) of the [rows][512] bf16 dH tile (65 x 16 bytes: 8 consecutive rows on 8 distinct 16-byte slots)
 
+// NT = feature tiles (= attention heads) per wave: 2 -> blocks of 4 waves (the forward's shape), 1 -> blocks of 8 waves on the same 64
+// rows and the same LDS: four waves per SIMD instead of two.  The kernel is latency-bound at two (PMC at B = 1024: vector issue 15 %,
+// MFMA 9 % of a wave's cycles, 46 % waiting for an instruction to issue), so the product build takes NT = 1.
+template <int NT>
 struct CfgB {
+  static constexpr int NWB = 8 / NT, NTHB = 64 * NWB;
+  static constexpr int PSW = 64 * NT + 16;                       // row pitch (bytes) of a per-wave strip [rows][32 NT features]
   static constexpr int GT = 0;                                   // [RT][512] bf16: d(mean H) / n * dropout scale of each sub-tile's sample
-  static constexpr int CST = GT + RT * 1024;                     // floats: ln_g [256] | d(mean Z) / n of sub-tile 0 [256] | of sub-tile 1 [256]
-  static constexpr int RED = CST + 3 * 1024;                     // LayerNorm gradient partials {sum g, sum g xhat} per (wave, row)
-  static constexpr int DU = RED + NW * ROWS * 8;                 // dU tile [ROWS][256] bf16 (pitch PR); then per-wave attention scratch (WSCR each)
-  static constexpr int ST = DU + ROWS * PR;                      // per-wave strips [ROWS][64] (pitch PS): column-sum planes; then queries | dO
-  static constexpr int STRIP = ROWS * PS;
-  static constexpr int LDS = ST + NW * STRIP;
-  static constexpr int WSCR = ROWS * PR / NW;                    // 8448 bytes: keys [16][64] (pitch PS) | dS, Pd images [32][16] of each of the wave's two heads
-  static constexpr int W_KS = 0, W_IMG = 16 * PS;
-  static_assert(ROWS * PH <= ROWS * PR + NW * STRIP, "the dH tile aliases [dU tile | strips]");
-  static_assert(W_IMG + 4096 <= WSCR, "per-wave attention scratch");
+  static constexpr int RED = 0;                                  // LayerNorm gradient partials {sum g, sum g xhat} per (wave, row): over the table (dead by then)
+  static constexpr int CST = 4096;                               // floats: ln_g [256] | d(mean Z) / n of sub-tile 0 [256] | of sub-tile 1 [256]
+  static constexpr int DU = CST + 3 * 1024;                      // dU tile [ROWS][256] bf16 (pitch PR); then per-wave attention scratch (WSCR each)
+  static constexpr int ST = DU + ROWS * PR;                      // per-wave strips [ROWS][32 NT] (pitch PSW): column-sum planes; then queries | dO
+  static constexpr int STRIP = ROWS * PSW;
+  static constexpr int LDS = ST + NWB * STRIP;
+  static constexpr int WSCR = ROWS * PR / NWB;                   // keys [16][32 NT] (pitch PSW) | dS, Pd images [32][16] of each of the wave's heads
+  static constexpr int W_KS = 0, W_IMG = 16 * PSW;
+  static_assert(RT * 1024 <= 4096 && NWB * ROWS * 8 <= 4096, "table / partials in front of the constants");
+  static_assert(ROWS * PH <= ROWS * PR + NWB * STRIP, "the dH tile aliases [dU tile | strips]");
+  static_assert(W_IMG + NT * 2048 <= WSCR, "per-wave attention scratch");
   static_assert(LDS <= 81920, "two blocks per CU");
 };
 
@@ -56,18 +63,21 @@ __device__ __forceinline__ void rg_softmax(const f32x16& Sc, int h, int Nk, floa
   for (int i = 0; i < 8; ++i) p[i] *= inv;
 }
 
-template <int DEPTH, bool DROP>
-__global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
+template <int DEPTH, bool DROP, int NT>
+__global__ __launch_bounds__(CfgB<NT>::NTHB, CfgB<NT>::NWB / 2) void bwd1w_kernel(const Bwd1Args a) {      // (HIP: threads per block, min WAVES PER SIMD -- two blocks per CU)
+  using C = CfgB<NT>;
+  constexpr int NWB = C::NWB, NTHB = C::NTHB, PSW = C::PSW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Bwd1Stream& S = a.s[0];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5, Nk = a.Nk;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  us16* gtab = reinterpret_cast<us16*>(smem + CfgB::GT);
-  float* cst = reinterpret_cast<float*>(smem + CfgB::CST);
-  float* red = reinterpret_cast<float*>(smem + CfgB::RED);
-  char* tileH = smem + CfgB::DU;                                  // dH tile (first product), aliasing [dU tile | strips]
-  char* bufdU = smem + CfgB::DU;
-  char* strip = smem + CfgB::ST + w * CfgB::STRIP;
+  const int ft0 = NT * w;                                         // this wave's first 32-feature tile (= its first head) of the 256-wide layers
+  us16* gtab = reinterpret_cast<us16*>(smem + C::GT);
+  float* cst = reinterpret_cast<float*>(smem + C::CST);
+  float* red = reinterpret_cast<float*>(smem + C::RED);
+  char* tileH = smem + C::DU;                                     // dH tile (first product), aliasing [dU tile | strips]
+  char* bufdU = smem + C::DU;
+  char* strip = smem + C::ST + w * C::STRIP;
   const int g0 = (int)blockIdx.x * RT;
   Sub sub[RT];
 #pragma unroll
@@ -80,48 +90,64 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
   }
   if (sub[0].nr == 0) return;                                     // (tiles are dense from 0: the whole group is past the end)
   stamp(a.stamps, 0);
-  Stage<RT, 2, 32, 2, DEPTH> st1;
-  st1.prefetch(S.W1T, w * (32 * 2), lane);
+  // weight fragments: the shadows' 4-wave layout -- wave w4 = tile >> 1 owns fragments (k step, tile & 1) at w4 (2 KS) + 2 ks + (tile & 1)
+  Stage<RT, NT, 32, 2, DEPTH> st1;
+  st1.prefetch(S.W1T, (ft0 >> 1) * (32 * 2) + (ft0 & 1), lane);
   // ---- per-sample tables: the FFN gradient row as bf16 (what a set mask bit selects), d(mean Z) / n, gamma
   {
     const float gsc = a.drop.scale;
 #pragma unroll
-    for (int it = 0; it < RT * 2; ++it) {
-      const int s = it >> 1, f = tid + NTH * (it & 1);
+    for (int it = 0; it < RT * 512 / NTHB; ++it) {
+      const int s = (NTHB * it) >> 9, f = (tid + NTHB * it) & 511;
       gtab[512 * s + f] = f2bf(S.dHm[(size_t)sub[s].b * S.ld_dHm + f] * (sub[s].inv_n * gsc));
     }
-    cst[tid] = S.ln_g[tid];
+    if (tid < 256) {
+      cst[tid] = S.ln_g[tid];
 #pragma unroll
-    for (int s = 0; s < RT; ++s) cst[256 + 256 * s + tid] = S.dcomb[(size_t)sub[s].b * S.ld_dcomb + tid] * sub[s].inv_n;
+      for (int s = 0; s < RT; ++s) cst[256 + 256 * s + tid] = S.dcomb[(size_t)sub[s].b * S.ld_dcomb + tid] * sub[s].inv_n;
+    }
   }
-  // this thread's share of the mask: row tid >> 2 of the block (wave w: rows 16 w .. + 15, all in sub-tile w >> 1), words 4 q .. + 3
-  const int hs_row0 = w < 2 ? sub[0].row0 : sub[1].row0, hs_nr = w < 2 ? sub[0].nr : sub[1].nr;
-  const int hr = tid >> 2, hq = tid & 3, hrr = hr & 31;
-  u32x4 mwq = u32x4{0u, 0u, 0u, 0u};
-  if (hrr < hs_nr) mwq = *reinterpret_cast<const u32x4*>(S.mask + ((size_t)hs_row0 + hrr) * 16 + 4 * hq);
+  // this thread's share of the mask: WPT words of one row (a wave's threads cover rows of ONE sub-tile)
+  constexpr int WPT = 1024 / NTHB, TPR = 16 / WPT;                // words per thread (4 or 2), threads per row
+  const bool hs1 = w * (64 / TPR) >= 32;                          // (wave-uniform) this wave's rows are sub-tile 1's
+  const int hs_row0 = hs1 ? sub[1].row0 : sub[0].row0, hs_nr = hs1 ? sub[1].nr : sub[0].nr;
+  const int hr = tid / TPR, hq = tid % TPR, hrr = hr & 31;
+  uint32_t mw[WPT];
+#pragma unroll
+  for (int j = 0; j < WPT; ++j) mw[j] = 0u;
+  if (hrr < hs_nr) {
+    const uint32_t* mp = S.mask + ((size_t)hs_row0 + hrr) * 16 + WPT * hq;
+    if constexpr (WPT == 4) { const u32x4 v = *reinterpret_cast<const u32x4*>(mp); mw[0] = v.x; mw[1] = v.y; mw[2] = v.z; mw[3] = v.w; }
+    else                    { const u32x2 v = *reinterpret_cast<const u32x2*>(mp); mw[0] = v.x; mw[1] = v.y; }
+  }
   // this lane's rows of the two sub-tiles (clamped into the tile), their saved normalised LayerNorm inputs and 1 / std
-  bool rok[RT]; u32x2 xv[RT][2][4]; float rstd[RT];
+  // The normalised inputs arrive as 16-byte chunks, a wave's 32 NT features of 64 rows in 4 NT coalesced instructions (one 8-byte piece
+  // per lane, row and feature group touches 32 cache lines per instruction: the kernel is bound by the vector memory pipeline -- PMC at
+  // B = 1024: TA busy 76 % -- and those loads were a sixth of its line traffic); they pass through the wave's own strip once the dH
+  // tile is dead and come back in the accumulators' layout (lane = row).
+  constexpr int CPR = 4 * NT;                                     // 16-byte chunks of this wave's features per row
+  bool rok[RT]; u32x2 xv[RT][NT][4]; float rstd[RT]; u32x4 xch[RT][2 * NT];
 #pragma unroll
   for (int s = 0; s < RT; ++s) {
     rok[s] = l31 < sub[s].nr;
     const size_t vrow = (size_t)sub[s].row0 + max(0, min(l31, sub[s].nr - 1));
-    const us16* xp = S.XH16 + vrow * 256 + 64 * w + 4 * h;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) xv[s][t][g] = *reinterpret_cast<const u32x2*>(xp + 32 * t + 8 * g);
+    for (int i = 0; i < 2 * NT; ++i) {
+      const int c = lane + 64 * i;
+      xch[s][i] = *reinterpret_cast<const u32x4*>(S.XH16 + ((size_t)sub[s].row0 + max(0, min(c / CPR, sub[s].nr - 1))) * 256 + 32 * ft0 + 8 * (c % CPR));
+    }
     rstd[s] = S.rstd[vrow];
   }
   __syncthreads();                                                // tables complete
   // ---- dH tile: feature pair (2 d, 2 d + 1) of a 16-byte chunk <- the table's pair where the mask bits are set
   {
-    const char* gt = reinterpret_cast<const char*>(gtab) + 1024 * (w >> 1) + 256 * hq;
-    char* dst = tileH + hr * PH + 256 * hq;
+    const char* gt = reinterpret_cast<const char*>(gtab) + (hs1 ? 1024 : 0) + 64 * WPT * hq;
+    char* dst = tileH + hr * PH + 64 * WPT * hq;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < WPT; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const uint32_t bits = mwq[j] >> (8 * i);
+        const uint32_t bits = mw[j] >> (8 * i);
         const u32x4 gv = *reinterpret_cast<const u32x4*>(gt + 64 * j + 16 * i);
         u32x4 fr;
 #pragma unroll
@@ -136,16 +162,29 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
   stamp(a.stamps, 1);
   // dH16: whole rows as 16-byte stores (a wave writes one 1 KB row per instruction)
 #pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int r = w + 4 * it, rr = r & 31, nr_s = it < 8 ? sub[0].nr : sub[1].nr, row0_s = it < 8 ? sub[0].row0 : sub[1].row0;      // (scalar selects: no indexed sub[])
+  for (int it = 0; it < ROWS / NWB; ++it) {
+    const int r = w + NWB * it, rr = r & 31;
+    const bool s1 = it >= 32 / NWB;                                // (scalar selects: no indexed sub[])
+    const int nr_s = s1 ? sub[1].nr : sub[0].nr, row0_s = s1 ? sub[1].row0 : sub[0].row0;
     if (rr < nr_s) *reinterpret_cast<u32x4*>(S.dH16 + ((size_t)row0_s + rr) * 512 + 8 * lane) = *reinterpret_cast<const u32x4*>(tileH + r * PH + 16 * lane);
   }
-  // ---- dY = d(mean Z) / n + dH . W1 (lane = row, registers = features 64 w + 32 t + acc_row)
-  f32x16 acc1[RT][2];
+  // ---- dY = d(mean Z) / n + dH . W1 (lane = row, registers = features 32 (ft0 + t) + acc_row)
+  f32x16 acc1[RT][NT];
   st1.template run_fi<true>([&](int s, int ks) { return *reinterpret_cast<const bf16x8*>(tileH + (32 * s + l31) * PH + 16 * h + 32 * ks); },
-                            [&](int s, int t) { return feature_vec(cst + 256 + 256 * s + 32 * (2 * w + t), h); }, acc1);
+                            [&](int s, int t) { return feature_vec(cst + 256 + 256 * s + 32 * (ft0 + t), h); }, acc1);
   stamp(a.stamps, 2);
-  Stage<RT, 2, 16, 2, DEPTH> st2;
+  Stage<RT, NT, 16, 2, DEPTH> st2;
+  __syncthreads();                                                // every wave is done with the dH tile (the strips lie inside it)
+#pragma unroll
+  for (int s = 0; s < RT; ++s)
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) { const int c = lane + 64 * i; *reinterpret_cast<u32x4*>(strip + (32 * s + c / CPR) * PSW + 16 * (c % CPR)) = xch[s][i]; }
+#pragma unroll
+  for (int s = 0; s < RT; ++s)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xv[s][t][g] = *reinterpret_cast<const u32x2*>(strip + (32 * s + l31) * PSW + 2 * (32 * t + 8 * g + 4 * h));
   // ---- LayerNorm backward: g = dy gamma; du = (g - mean(g) - xhat mean(g xhat)) / std; dgamma += dy xhat, dbeta += dy
   // rows past a sub-tile's end: dy and xhat cleared once (then g, both row sums and du are exactly 0 there and the column sums skip
   // them); full sub-tiles -- the common case -- carry no masks at all
@@ -153,7 +192,7 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
 #pragma unroll
     for (int s = 0; s < RT; ++s)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc1[s][t][i] = rok[s] ? acc1[s][t][i] : 0.f;
 #pragma unroll
@@ -164,10 +203,10 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
   for (int s = 0; s < RT; ++s) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(cst + 32 * (2 * w + t) + 8 * g + 4 * h);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(cst + 32 * (ft0 + t) + 8 * g + 4 * h);
         const u32x2 x = xv[s][t][g];
         const float X[4] = {bf_lo(x.x), bf_hi(x.x), bf_lo(x.y), bf_hi(x.y)};
 #pragma unroll
@@ -176,21 +215,21 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
     s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
     if (h == 0) *reinterpret_cast<float2*>(red + 2 * (w * ROWS + 32 * s + l31)) = make_float2(s1, s2);
   }
-  __syncthreads();                                                // partials complete; every wave is done with the dH tile
+  __syncthreads();                                                // partials complete
 #pragma unroll
   for (int s = 0; s < RT; ++s) {
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < NW; ++ww) {
+    for (int ww = 0; ww < NWB; ++ww) {
       const float2 p = *reinterpret_cast<const float2*>(red + 2 * (ww * ROWS + 32 * s + l31));
       m1 += p.x; m2 += p.y;
     }
     const float nm1 = -m1 * (1.0f / 256.0f), nm2 = -m2 * (1.0f / 256.0f);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int c0 = 32 * (2 * w + t) + 8 * g + 4 * h;
+        const int c0 = 32 * (ft0 + t) + 8 * g + 4 * h;
         const f32x4 gm = *reinterpret_cast<const f32x4*>(cst + c0);
         const u32x2 x = xv[s][t][g];
         const float X[4] = {bf_lo(x.x), bf_hi(x.x), bf_lo(x.y), bf_hi(x.y)};
@@ -200,7 +239,7 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
         *reinterpret_cast<u32x2*>(bufdU + (32 * s + l31) * PR + 2 * c0) = u32x2{pack2(du[0], du[1]), pack2(du[2], du[3])};
       }
   }
-  // column sums over the block's rows of dy xhat (dgamma) and dy (dbeta), this wave's 64 features.  The two sub-tiles' values of one
+  // column sums over the block's rows of dy xhat (dgamma) and dy (dbeta), this wave's features.  The two sub-tiles' values of one
   // (row slot, feature) are added in the lane first; the sums go through the wave's strip as bf16 hi planes (dy xhat: strip rows
   // 0 .. 31, dy: rows 32 .. 63), then lo planes (exact to 2^-17), and come back as MFMAs against the identity: lane = feature,
   // registers = row slots -- an fp32 tile in LDS summed by one thread per column costs 64 KB for these rows
@@ -213,9 +252,9 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
       idf[kk] = u32x4{j == 0 ? one_lo : (j == 1 ? one_hi : 0u), j == 2 ? one_lo : (j == 3 ? one_hi : 0u),
                       j == 4 ? one_lo : (j == 5 ? one_hi : 0u), j == 6 ? one_lo : (j == 7 ? one_hi : 0u)};
     }
-    u32x2 lo[2][2][4];
+    u32x2 lo[2][NT][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const u32x2 x0 = xv[0][t][g], x1 = xv[1][t][g];
@@ -229,25 +268,25 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
         const u32x2 h0 = u32x2{pack2(v0[0], v0[1]), pack2(v0[2], v0[3])}, h1 = u32x2{pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
         lo[0][t][g] = u32x2{pack2(v0[0] - bf_lo(h0.x), v0[1] - bf_hi(h0.x)), pack2(v0[2] - bf_lo(h0.y), v0[3] - bf_hi(h0.y))};
         lo[1][t][g] = u32x2{pack2(v1[0] - bf_lo(h1.x), v1[1] - bf_hi(h1.x)), pack2(v1[2] - bf_lo(h1.y), v1[3] - bf_hi(h1.y))};
-        *reinterpret_cast<u32x2*>(strip + l31 * PS + 2 * (32 * t + 8 * g + 4 * h)) = h0;
-        *reinterpret_cast<u32x2*>(strip + (32 + l31) * PS + 2 * (32 * t + 8 * g + 4 * h)) = h1;
+        *reinterpret_cast<u32x2*>(strip + l31 * PSW + 2 * (32 * t + 8 * g + 4 * h)) = h0;
+        *reinterpret_cast<u32x2*>(strip + (32 + l31) * PSW + 2 * (32 * t + 8 * g + 4 * h)) = h1;
       }
-    f32x16 p[2][2];
+    f32x16 p[2][NT];
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
       if (pl == 1) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2*>(strip + (32 * q + l31) * PS + 2 * (32 * t + 8 * g + 4 * h)) = lo[q][t][g];
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2*>(strip + (32 * q + l31) * PSW + 2 * (32 * t + 8 * g + 4 * h)) = lo[q][t][g];
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const char* yp = strip + (32 * q + l31) * PS + 64 * t + 16 * h;
+        for (int t = 0; t < NT; ++t) {
+          const char* yp = strip + (32 * q + l31) * PSW + 64 * t + 16 * h;
           p[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(yp), as_frag(idf[0]), pl == 0 ? splat16(0.f) : p[q][t], 0, 0, 0);
           p[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(yp + 32), as_frag(idf[1]), p[q][t], 0, 0, 0);
         }
@@ -255,38 +294,38 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         float c = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) c += p[q][t][i];
         c += __shfl_xor(c, 32, 64);
-        if (h == 0) atomicAdd((q == 0 ? S.dgamma : S.dbeta) + 64 * w + 32 * t + l31, c);
+        if (h == 0) atomicAdd((q == 0 ? S.dgamma : S.dbeta) + 32 * (ft0 + t) + l31, c);
       }
   }
-  st2.prefetch(S.WoT, w * (16 * 2), lane);                        // (in front of the barrier: the column sums above need the registers)
-  // the first sub-tile's attention operands start now and land under the dO product: queries (the wave's 64 features of 32 rows, 8
-  // chunks of 16 bytes per row), the sample's keys (-> LDS, for the transposing reads) and its values as A fragments straight from L2
+  st2.prefetch(S.WoT, (ft0 >> 1) * (16 * 2) + (ft0 & 1), lane);  // (in front of the barrier: the column sums above need the registers)
+  // the first sub-tile's attention operands start now and land under the dO product: queries (the wave's 32 NT features of 32 rows,
+  // 4 NT chunks of 16 bytes per row), the sample's keys (-> LDS, for the transposing reads) and its values as A fragments straight from L2
   const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
-  u32x4 qreg[4], kreg[2]; u32x2 vfr[2][2][2];
+  u32x4 qreg[2 * NT], kreg[NT]; u32x2 vfr[NT][2][2];
   auto load_q = [&](int row0, int nr) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2 * NT; ++i) {
       const int c = lane + 64 * i;
-      qreg[i] = *reinterpret_cast<const u32x4*>(a.Q16 + ((size_t)row0 + max(0, min(c >> 3, nr - 1))) * 256 + 64 * w + 8 * (c & 7));
+      qreg[i] = *reinterpret_cast<const u32x4*>(a.Q16 + ((size_t)row0 + max(0, min(c / CPR, nr - 1))) * 256 + 32 * ft0 + 8 * (c % CPR));
     }
   };
   auto load_kv = [&](int b) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = lane + 64 * i, j = c >> 3;
-      kreg[i] = *reinterpret_cast<const u32x4*>(a.KV16 + ((size_t)b * Nk + min(j, Nk - 1)) * 512 + 64 * w + 8 * (c & 7));
+    for (int i = 0; i < NT; ++i) {
+      const int c = lane + 64 * i, j = c / CPR;
+      kreg[i] = *reinterpret_cast<const u32x4*>(a.KV16 + ((size_t)b * Nk + min(j, Nk - 1)) * 512 + 32 * ft0 + 8 * (c % CPR));
       if (j >= Nk) kreg[i] = u32x4{0u, 0u, 0u, 0u};
     }
     // value row j = lane & 15, features 16 ss + 4 h .. + 3 and + 8 .. of head t: the k order of the dO accumulator's registers
     const int j = l31 & 15;
-    const us16* vp = a.KV16 + ((size_t)b * Nk + min(j, Nk - 1)) * 512 + 256 + 64 * w + 4 * h;
+    const us16* vp = a.KV16 + ((size_t)b * Nk + min(j, Nk - 1)) * 512 + 256 + 32 * ft0 + 4 * h;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
         vfr[t][ss][0] = *reinterpret_cast<const u32x2*>(vp + 32 * t + 16 * ss);
@@ -294,43 +333,47 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
         if (j >= Nk) { vfr[t][ss][0] = u32x2{0u, 0u}; vfr[t][ss][1] = u32x2{0u, 0u}; }
       }
   };
-  load_q(sub[0].row0, sub[0].nr);
-  load_kv(sub[0].b);
+  if constexpr (NT == 2) { load_q(sub[0].row0, sub[0].nr); load_kv(sub[0].b); }     // (8 waves: behind the dO product -- 128 registers)
   __syncthreads();                                                // dU tile complete
   stamp(a.stamps, 3);
-  // ---- dO = dU . Wo (lane = row, registers = the features of heads 2 w, 2 w + 1)
-  f32x16 acc2[RT][2];
+  // ---- dO = dU . Wo (lane = row, registers = the features of this wave's heads)
+  f32x16 acc2[RT][NT];
   {
-    const f32x16 init[2] = {splat16(0.f), splat16(0.f)};
+    f32x16 init[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) init[t] = splat16(0.f);
     st2.template run<true>(bufdU + l31 * PR + 16 * h, 32 * PR, init, acc2);
   }
+  if constexpr (NT == 1) { load_q(sub[0].row0, sub[0].nr); load_kv(sub[0].b); }
   __syncthreads();                                                // every wave is done reading the dU tile
   stamp(a.stamps, 4);
 #pragma unroll 4
-  for (int it = 0; it < 8; ++it) {                                // dU16: the tile's rows as 16-byte stores (behind the block's last weight stream)
-    const int r = (tid >> 5) + 8 * it, rr = r & 31, k = tid & 31, nr_s = it < 4 ? sub[0].nr : sub[1].nr, row0_s = it < 4 ? sub[0].row0 : sub[1].row0;
+  for (int it = 0; it < ROWS * 32 / NTHB; ++it) {                 // dU16: the tile's rows as 16-byte stores (behind the block's last weight stream)
+    const int r = (tid >> 5) + (NTHB / 32) * it, rr = r & 31, k = tid & 31;
+    const bool s1 = it >= ROWS * 16 / NTHB;
+    const int nr_s = s1 ? sub[1].nr : sub[0].nr, row0_s = s1 ? sub[1].row0 : sub[0].row0;
     if (rr < nr_s) store16_wt(S.dU16 + ((size_t)row0_s + rr) * 256 + 8 * k, *reinterpret_cast<const u32x4*>(bufdU + r * PR + 16 * k));
   }
   __syncthreads();                                                // the dU tile's space becomes per-wave scratch
   stamp(a.stamps, 5);
-  // ---- RG->KG attention backward, one sub-tile at a time, out of this wave's own LDS (no block barriers from here on); the two heads
-  // of a sub-tile share nothing but read-only tiles (their own dS / Pd images), so their chains overlap
-  char* Qs = strip; char* dOs = strip + 32 * PS;
-  char* wscr = smem + CfgB::DU + w * CfgB::WSCR;
-  char* Ks = wscr + CfgB::W_KS;
+  // ---- RG->KG attention backward, one sub-tile at a time, out of this wave's own LDS (no block barriers from here on); the heads
+  // of a wave share nothing but read-only tiles (their own dS / Pd images), so their chains overlap
+  char* Qs = strip; char* dOs = strip + 32 * PSW;
+  char* wscr = smem + C::DU + w * C::WSCR;
+  char* Ks = wscr + C::W_KS;
 #pragma unroll
   for (int s = 0; s < RT; ++s) {
     if (sub[s].nr == 0) break;
     const size_t rowg0 = (size_t)sub[s].row0;
     if (s == 0 || sub[s].b != sub[0].b) {                         // (wave-uniform) a new sample's keys
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { const int c = lane + 64 * i; *reinterpret_cast<u32x4*>(Ks + (c >> 3) * PS + 16 * (c & 7)) = kreg[i]; }
+      for (int i = 0; i < NT; ++i) { const int c = lane + 64 * i; *reinterpret_cast<u32x4*>(Ks + (c / CPR) * PSW + 16 * (c % CPR)) = kreg[i]; }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; *reinterpret_cast<u32x4*>(Qs + (c >> 3) * PS + 16 * (c & 7)) = qreg[i]; }
-    u32x2 vf[2][2][2];
+    for (int i = 0; i < 2 * NT; ++i) { const int c = lane + 64 * i; *reinterpret_cast<u32x4*>(Qs + (c / CPR) * PSW + 16 * (c % CPR)) = qreg[i]; }
+    u32x2 vf[NT][2][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) { vf[t][ss][0] = vfr[t][ss][0]; vf[t][ss][1] = vfr[t][ss][1]; }
     if (s + 1 < RT && sub[RT - 1].nr > 0) {                       // the next sub-tile's operands, under this one's attention
@@ -338,21 +381,21 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
       if (sub[RT - 1].b != sub[0].b) load_kv(sub[RT - 1].b);
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g)                                  // dO strip (bf16): read back transposed for dV
-        *reinterpret_cast<u32x2*>(dOs + l31 * PS + 2 * (32 * t + 8 * g + 4 * h)) =
+        *reinterpret_cast<u32x2*>(dOs + l31 * PSW + 2 * (32 * t + 8 * g + 4 * h)) =
             rok[s] ? u32x2{pack2(acc2[s][t][4 * g], acc2[s][t][4 * g + 1]), pack2(acc2[s][t][4 * g + 2], acc2[s][t][4 * g + 3])} : u32x2{0u, 0u};
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int head = 2 * w + t;
-      char* imS = wscr + CfgB::W_IMG + 2048 * t; char* imP = imS + 1024;
+    for (int t = 0; t < NT; ++t) {
+      const int head = ft0 + t;
+      char* imS = wscr + C::W_IMG + 2048 * t; char* imP = imS + 1024;
       // scores and probabilities, exactly as bwd1_kernel recomputes them
       f32x16 Sc = splat16(0.f);
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (l31 & 15) * PS + 2 * (32 * t + 16 * ss + 8 * h));
-        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + l31 * PS + 2 * (32 * t + 16 * ss + 8 * h));
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (l31 & 15) * PSW + 2 * (32 * t + 16 * ss + 8 * h));
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + l31 * PSW + 2 * (32 * t + 16 * ss + 8 * h));
         Sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, Sc, 0, 0, 0);
       }
       float pr[8], mm[8];
@@ -366,6 +409,7 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
       for (int ss = 0; ss < 2; ++ss)
         dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(u32x4{vf[t][ss][0].x, vf[t][ss][0].y, vf[t][ss][1].x, vf[t][ss][1].y}), as_frag(pack8(acc2[s][t], ss)), dP, 0, 0, 0);
       float ds[8], pd[8], delta = 0.f;
+      f32x16 dq;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { ds[i] = dP[i] * mm[i]; delta = fmaf(pr[i], ds[i], delta); pd[i] = pr[i] * mm[i]; }
       delta += __shfl_xor(delta, 32, 64);
@@ -374,15 +418,9 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
       const u32x4 dsf = u32x4{pack2(ds[0], ds[1]), pack2(ds[2], ds[3]), pack2(ds[4], ds[5]), pack2(ds[6], ds[7])};
       const u32x4 pdf = u32x4{pack2(pd[0], pd[1]), pack2(pd[2], pd[3]), pack2(pd[4], pd[5]), pack2(pd[6], pd[7])};
       {   // dQ^T = scale * K_h^T . dS^T: lane = row
-        const char* kp = Ks + (4 * h + q4) * PS + 2 * (32 * t + 16 * g1 + 4 * p4);
-        const bf16x8 kt = join(lds_tr16(kp), lds_tr16(kp + 8 * PS));
-        const f32x16 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, as_frag(dsf), splat16(0.f), 0, 0, 0);
-        if (rok[s]) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<u32x2*>(a.dQKV16 + (rowg0 + l31) * 768 + 32 * head + 8 * g + 4 * h) =
-                u32x2{pack2(dq[4 * g] * a.qscale, dq[4 * g + 1] * a.qscale), pack2(dq[4 * g + 2] * a.qscale, dq[4 * g + 3] * a.qscale)};
-        }
+        const char* kp = Ks + (4 * h + q4) * PSW + 2 * (32 * t + 16 * g1 + 4 * p4);
+        const bf16x8 kt = join(lds_tr16(kp), lds_tr16(kp + 8 * PSW));
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, as_frag(dsf), splat16(0.f), 0, 0, 0);
       }
       // dS / Pd images [row][16 keys] (bf16): keys 4 h .. + 3 at byte 8 h, keys 8 + 4 h .. at byte 16 + 8 h
       *reinterpret_cast<u32x2*>(imS + l31 * 32 + 8 * h) = u32x2{dsf.x, dsf.y};
@@ -397,10 +435,21 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
         const bf16x8 sA = join(lds_tr16(imS + r0 * 32 + 8 * p4), lds_tr16(imS + (r0 + 4) * 32 + 8 * p4));
         const bf16x8 pA = join(lds_tr16(imP + r0 * 32 + 8 * p4), lds_tr16(imP + (r0 + 4) * 32 + 8 * p4));
         const int co = 2 * (32 * t + 16 * g1 + 4 * p4);
-        const bf16x8 qB = join(lds_tr16(Qs + r0 * PS + co), lds_tr16(Qs + (r0 + 4) * PS + co));
-        const bf16x8 oB = join(lds_tr16(dOs + r0 * PS + co), lds_tr16(dOs + (r0 + 4) * PS + co));
+        const bf16x8 qB = join(lds_tr16(Qs + r0 * PSW + co), lds_tr16(Qs + (r0 + 4) * PSW + co));
+        const bf16x8 oB = join(lds_tr16(dOs + r0 * PSW + co), lds_tr16(dOs + (r0 + 4) * PSW + co));
         dK = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sA, qB, dK, 0, 0, 0);
         dV = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA, oB, dV, 0, 0, 0);
+      }
+      // dQ rows (bf16, 64 bytes per row and head) leave through the head's image space, dead now, as 16-byte pieces: four lanes per row
+      // -- 8-byte pieces straight from the accumulators touch 64 cache lines per store instruction
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<u32x2*>(imS + l31 * 64 + 2 * (8 * g + 4 * h)) =
+            u32x2{pack2(dq[4 * g] * a.qscale, dq[4 * g + 1] * a.qscale), pack2(dq[4 * g + 2] * a.qscale, dq[4 * g + 3] * a.qscale)};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = lane + 64 * i, r = c >> 2;
+        if (r < sub[s].nr) *reinterpret_cast<u32x4*>(a.dQKV16 + (rowg0 + r) * 768 + 32 * head + 8 * (c & 3)) = *reinterpret_cast<const u32x4*>(imS + r * 64 + 16 * (c & 3));
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -416,14 +465,14 @@ __global__ __launch_bounds__(NTH, 2) void bwd1w_kernel(const Bwd1Args a) {
   stamp(a.stamps, 12);
 }
 
-template <int DEPTH, bool DROP>
+template <int DEPTH, bool DROP, int NT>
 int bwd1w_launch(const Bwd1Args& a, hipStream_t stream) {
   static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd1w_kernel<DEPTH, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, CfgB::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd1w_kernel<DEPTH, DROP, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, CfgB<NT>::LDS);
     return true;
   }();
   (void)attr;
-  hipLaunchKernelGGL((bwd1w_kernel<DEPTH, DROP>), dim3((a.rg_tiles_max + RT - 1) / RT), dim3(NTH), CfgB::LDS, stream, a);
+  hipLaunchKernelGGL((bwd1w_kernel<DEPTH, DROP, NT>), dim3((a.rg_tiles_max + RT - 1) / RT), dim3(CfgB<NT>::NTHB), CfgB<NT>::LDS, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -436,7 +485,9 @@ int launch_wide2_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
   const double rows = (double)a.rows_rg;
   const int prof = gemm_prof_open(stream, 2.0 * rows * (512.0 * 256.0 + 256.0 * 256.0) + 10.0 * rows * a.Nk * 256.0, PROF_BWD1);
   const Bwd1Args& k = a;
-  const int rc2 = a.drop.p > 0.f ? bwd1w_launch<8, true>(k, stream) : bwd1w_launch<8, false>(k, stream);
+  // (k.exp == 4: developer A/B, the 4-wave shape)
+  const int rc2 = k.exp == 4 ? (a.drop.p > 0.f ? bwd1w_launch<8, true, 2>(k, stream) : bwd1w_launch<8, false, 2>(k, stream))
+                             : (a.drop.p > 0.f ? bwd1w_launch<6, true, 1>(k, stream) : bwd1w_launch<6, false, 1>(k, stream));
   gemm_prof_close(prof, stream);
   return rc2;
 }

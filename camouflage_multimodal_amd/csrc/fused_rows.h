@@ -90,6 +90,7 @@ struct Bwd1Args {
   const int* off; const int* tile_off; const float* inv_nr; const int4* tile_desc;
   const int* row_sample;                       // RG row -> sample (the batch descriptor's table)
   int B, Nk, rg_tiles_max, rows_rg; float qscale; DropCfg drop; unsigned long long* stamps;
+  int exp;                                     // developer A/B (bwd_wide2.hip: weight fragments in flight); product calls pass 0
   int writer_blocks, writer_first_row;         // (filled by the launcher) dH16 writer blocks and the first row of [RG rows | KG rows] they cover
   // clears for the weight-gradient launch (pad rows of its operands) when no shadow launch did them: one extra block each
   void* zero_ptr[FUSED_BWD1_MAXZ]; unsigned zero_bytes[FUSED_BWD1_MAXZ]; int nzero;

@@ -909,7 +909,8 @@ int launch_wide2_rgfwd(const FrontStream& f, const us16* Wf, const float* bf, fl
     if (b.exp == 8) wide2_launch<8, true, false, false>(g, grid, stream); else if (b.exp == 16) wide2_launch<16, true, false, false>(g, grid, stream);
     else wide2_launch<12, true, false, false>(g, grid, stream);
   } else if (save) {
-    if (drop) wide2_launch<6, false, true, true>(g, grid, stream); else wide2_launch<6, false, false, true>(g, grid, stream);
+    if (b.exp == 8) { if (drop) wide2_launch<8, false, true, true>(g, grid, stream); else wide2_launch<8, false, false, true>(g, grid, stream); }
+    else if (drop) wide2_launch<6, false, true, true>(g, grid, stream); else wide2_launch<6, false, false, true>(g, grid, stream);
   } else {
     wide2_launch<8, false, true, false>(g, grid, stream);         // (an inference call in training mode: dropout, nothing saved)
   }

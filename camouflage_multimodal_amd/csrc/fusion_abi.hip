@@ -896,7 +896,7 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   a1.off = rg_offsets; a1.tile_off = bd.tile_off; a1.tile_desc = bd.tile_desc; a1.inv_nr = bd.inv_nr; a1.row_sample = bd.row_sample;
   a1.B = B; a1.Nk = Nk; a1.rows_rg = T; a1.rg_tiles_max = T / 32 + B; a1.qscale = 1.0f / sqrtf(32.0f); a1.drop = drop;
   a1.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)2 * g_dbg_stamp_blocks * 8 : nullptr;
-  a1.nzero = t_nzero_bwd1;
+  a1.nzero = t_nzero_bwd1; a1.exp = g_opt_exp;
   for (int i = 0; i < t_nzero_bwd1; ++i) { a1.zero_ptr[i] = t_zero_bwd1_ptr[i]; a1.zero_bytes[i] = t_zero_bwd1_bytes[i]; }
   t_nzero_bwd1 = 0;
   // the RG rows of the first half on 64-row half-blocks (bwd_wide2.hip) from 16 384 packed rows (training step, ms without / with:
