@@ -278,7 +278,7 @@ def main():
         ev_us = sorted(a_.elapsed_time(b_) * 1e3 for a_, b_ in pairs)[len(pairs) // 2]
         peak = PEAK_TFLOPS[args.precision]
         names = ["grouped GEMM (gemm16_kernel / gemm16_tnbig_kernel: weight gradients in the fused schedule)", "front_kernel / front8_kernel (fused forward: projection + in-projections)",
-                 "back_kernel (fused forward: attention + out-projection + LayerNorm + FFN; rgfwd_kernel = the whole RG forward in inference calls at T >= 13 312)", "bwd1_kernel (fused backward, first half)",
+                 "back_kernel (fused forward: attention + out-projection + LayerNorm + FFN; inference calls from 10 240 packed rows run rgfwd2_kernel + kgchain_kernel instead: roofline_forward)", "bwd1_kernel (fused backward, first half)",
                  "bwd2_kernel (fused backward, second half)", "per-sample tail (tail_fused_kernel: one launch at B <= 16, groups of 16 up to B = 48; gemm_skinny_kernel + heads_loss_kernel above; tailw_fwd_kernel in wide inference calls)",
                  "optimizer (sumsq_kernel, adamw_shadow_kernel: AdamW that also leaves the next step's bf16 weight shadows)", "shadow_kernel (bf16 weight shadows + clears: only on steps whose shadows the optimizer did not leave)", "attention kernels (unfused schedules)", "other"]
         table = []

@@ -45,7 +45,9 @@ def main():
         per_step += per_launch * lps
     res = {"steps_profiled": {"fetch_pass": steps_f, "write_pass": steps_w}, "kernels": kernels,
            "all_kernels_hbm_bytes_per_step": round(per_step),
-           "correction": "FETCH_SIZE doubled (gfx950 counts 128-B read requests at 64 B); WRITE_SIZE as reported"}
+           "correction": "FETCH_SIZE doubled (gfx950 counts 128-B read requests at 64 B); WRITE_SIZE as reported",
+           "source": {"per_kernel_records": "profiles/%s_pmc_bench/FETCH_SIZE_per_kernel.csv, WRITE_SIZE_per_kernel.csv" % (re.search(r"(r\d+)_pmc_bench", fetch_dir).group(1) if re.search(r"(r\d+)_pmc_bench", fetch_dir) else "rNN"),
+                      "fetch_pass": fetch_dir, "write_pass": write_dir, "command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-extras --no-cpu-baseline (tools/dev/dev_final_run.sh)"}}
     json.dump(res, open("profiles/pmc_traffic.json", "w"), indent=1)
     print(json.dumps(res, indent=1))
 
