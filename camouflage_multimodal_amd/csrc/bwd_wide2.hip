@@ -476,6 +476,160 @@ int bwd1w_launch(const Bwd1Args& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ backward, second half (parameter-space form)
+// bwd2p_kernel of fused_rows.hip for the RG rows of large batches: the KG->RG attention backward of a block's 64 rows -- probabilities
+// recomputed from the saved softmax {max, sum}; dK2 | dV2 per row into columns 256 .. 767 of dQKV16, the sample's dQ2 by fp32 atomics.
+// There is no weight stream here, only rows in and rows out (2 KB per row): a wave is one head and keeps everything of its head in its
+// own 8.7 KB of LDS -- key and value slices [32 rows][32 features] loaded as 16-byte pieces (4 lanes per row), the sample's 16
+// queries and d(attention output) rows, the dS image -- so the block has NO barrier, and the next sub-tile's slices are in flight
+// while this one computes.  The dK2 / dV2 rows leave through the dead key / value slices as 16-byte pieces.  (bwd2p_kernel: 8 waves
+// on 32 rows between three barriers, a 49 KB tile for 1 KB rows, 73 % of its wave cycles waiting.)
+struct CfgC {
+  static constexpr int PW = 80;                                  // row pitch (bytes) of a [rows][32 features] bf16 slice
+  static constexpr int KS = 0, VS = 32 * PW, Q2S = 2 * 32 * PW, DO2S = Q2S + 16 * PW, IMG = DO2S + 16 * PW, TAB = IMG + 1024, WAVE = TAB + 192;
+  static constexpr int LDS = 8 * WAVE;
+  static_assert(LDS <= 81920, "two blocks per CU");
+};
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 4) void bwd2w_kernel(const Bwd2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PW = CfgC::PW;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5, Nk = a.Nk;
+  const int head = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* ws = smem + head * CfgC::WAVE;
+  char* Ks = ws + CfgC::KS; char* Vs = ws + CfgC::VS; char* Q2s = ws + CfgC::Q2S; char* dO2s = ws + CfgC::DO2S; char* im = ws + CfgC::IMG;
+  float* tab = reinterpret_cast<float*>(ws + CfgC::TAB);          // max [16] | 1 / sum [16] | row-dot [16] of this head's queries
+  const int g0 = (int)blockIdx.x * RT;
+  Sub sub[RT];
+#pragma unroll
+  for (int s = 0; s < RT; ++s) {
+    int4 td = make_int4(-1, 0, 0, 0);
+    if (g0 + s < a.rg_tiles_max) td = a.tile_desc[g0 + s];
+    const int tb = __builtin_amdgcn_readfirstlane(td.x);
+    sub[s].b = tb < 0 ? 0 : tb; sub[s].row0 = tb < 0 ? 0 : __builtin_amdgcn_readfirstlane(td.y); sub[s].nr = tb < 0 ? 0 : __builtin_amdgcn_readfirstlane(td.z);
+    sub[s].inv_n = 0.f;
+  }
+  if (sub[0].nr == 0) return;
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+  u32x4 kreg[2], vreg[2], q2reg, o2reg; float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+  auto load_kv = [&](int row0, int nr) {                          // this head's key | value slices of 32 rows: 4 lanes per row
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = lane + 64 * i;
+      const us16* p = a.KV2_16 + ((size_t)row0 + max(0, min(c >> 2, nr - 1))) * 512 + 32 * head + 8 * (c & 3);
+      kreg[i] = *reinterpret_cast<const u32x4*>(p); vreg[i] = *reinterpret_cast<const u32x4*>(p + 256);
+    }
+  };
+  auto load_sample = [&](int b) {                                 // the sample's Nk queries (pre-scaled) and d(attention output) rows, this head; its softmax tables
+    const int j = lane >> 2;
+    const size_t r = (size_t)b * Nk + min(j, Nk - 1);
+    q2reg = *reinterpret_cast<const u32x4*>(a.Q2_16 + r * 256 + 32 * head + 8 * (lane & 3));
+    o2reg = *reinterpret_cast<const u32x4*>(a.dO2_16 + r * 256 + 32 * head + 8 * (lane & 3));
+    if (j >= Nk) { q2reg = u32x4{0u, 0u, 0u, 0u}; o2reg = q2reg; }
+    if (lane < 16) {
+      const size_t o = (size_t)b * 128 + head * 16 + lane;        // [b][head][16]
+      const bool ok = lane < Nk;
+      t0 = ok ? a.lse2[2 * o] : 0.f; t1 = ok ? 1.0f / a.lse2[2 * o + 1] : 0.f; t2 = ok ? a.delta2[o] : 0.f;
+    }
+  };
+  load_kv(sub[0].row0, sub[0].nr);
+  load_sample(sub[0].b);
+  f32x16 dq2 = splat16(0.f);
+#pragma unroll
+  for (int s = 0; s < RT; ++s) {
+    if (sub[s].nr == 0) break;
+    const size_t rowg0 = (size_t)sub[s].row0;
+    const bool rok = l31 < sub[s].nr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = lane + 64 * i;
+      *reinterpret_cast<u32x4*>(Ks + (c >> 2) * PW + 16 * (c & 3)) = kreg[i];
+      *reinterpret_cast<u32x4*>(Vs + (c >> 2) * PW + 16 * (c & 3)) = vreg[i];
+    }
+    if (s == 0 || sub[s].b != sub[0].b) {                         // (wave-uniform) a new sample
+      *reinterpret_cast<u32x4*>(Q2s + (lane >> 2) * PW + 16 * (lane & 3)) = q2reg;
+      *reinterpret_cast<u32x4*>(dO2s + (lane >> 2) * PW + 16 * (lane & 3)) = o2reg;
+      if (lane < 16) { tab[lane] = t0; tab[16 + lane] = t1; tab[32 + lane] = t2; }
+    }
+    const bool more = s + 1 < RT && sub[RT - 1].nr > 0;
+    if (more) {                                                   // the next sub-tile's slices, under this one's products
+      load_kv(sub[RT - 1].row0, sub[RT - 1].nr);
+      if (sub[RT - 1].b != sub[0].b) load_sample(sub[RT - 1].b);
+    }
+    // scores of the Nk queries against this lane's row, and dP = dO2 . V2^T  ([query j][row]: lane = row, registers = queries)
+    f32x16 S2 = splat16(0.f), dP = splat16(0.f);
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const int qo = (l31 & 15) * PW + 2 * (16 * ss + 8 * h), ro = l31 * PW + 2 * (16 * ss + 8 * h);
+      S2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Q2s + qo), *reinterpret_cast<const bf16x8*>(Ks + ro), S2, 0, 0, 0);
+      dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(dO2s + qo), *reinterpret_cast<const bf16x8*>(Vs + ro), dP, 0, 0, 0);
+    }
+    float ds[8], pd[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = acc_row(i, h);
+      const float p = (j < Nk && rok) ? __expf(S2[i] - tab[j]) * tab[16 + j] : 0.f;
+      const float mm = DROP ? drop_mult(a.drop, SITE_ATTN_KG2RG, ((uint32_t)(rowg0 + l31) * 8u + (uint32_t)head) * (uint32_t)Nk + (uint32_t)j) : 1.0f;
+      ds[i] = p * (dP[i] * mm - tab[32 + j]);
+      pd[i] = p * mm;
+    }
+    const u32x4 dsf = u32x4{pack2(ds[0], ds[1]), pack2(ds[2], ds[3]), pack2(ds[4], ds[5]), pack2(ds[6], ds[7])};
+    const u32x4 pdf = u32x4{pack2(pd[0], pd[1]), pack2(pd[2], pd[3]), pack2(pd[4], pd[5]), pack2(pd[6], pd[7])};
+    // dS image [row][16 queries] (bf16): queries 4 h .. + 3 at byte 8 h, queries 8 + 4 h .. at byte 16 + 8 h
+    *reinterpret_cast<u32x2*>(im + l31 * 32 + 8 * h) = u32x2{dsf.x, dsf.y};
+    *reinterpret_cast<u32x2*>(im + l31 * 32 + 16 + 8 * h) = u32x2{dsf.z, dsf.w};
+    // dQ2_h[j][f] += scale * sum_rows dS2[j][row] K2[row][f]  (lane = f, registers = j): image and key slice read transposed
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const int r0 = 16 * ss + 8 * h + q4;
+      const bf16x8 sA = join(lds_tr16(im + r0 * 32 + 8 * p4), lds_tr16(im + (r0 + 4) * 32 + 8 * p4));
+      const int co = 2 * (16 * g1 + 4 * p4);
+      const bf16x8 kB = join(lds_tr16(Ks + r0 * PW + co), lds_tr16(Ks + (r0 + 4) * PW + co));
+      dq2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sA, kB, dq2, 0, 0, 0);
+    }
+    // dV2^T = dO2_h^T . P2d,  dK2^T = Q2_h^T . dS2: lane = row, registers = the head's 32 features
+    const int tro = (4 * h + q4) * PW + 2 * (16 * g1 + 4 * p4);
+    const f32x16 dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join(lds_tr16(dO2s + tro), lds_tr16(dO2s + tro + 8 * PW)), as_frag(pdf), splat16(0.f), 0, 0, 0);
+    const f32x16 dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join(lds_tr16(Q2s + tro), lds_tr16(Q2s + tro + 8 * PW)), as_frag(dsf), splat16(0.f), 0, 0, 0);
+    // the rows leave through the key / value slices (dead now: the wave's own LDS traffic, program order) as 16-byte pieces
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<u32x2*>(Ks + l31 * PW + 2 * (8 * g + 4 * h)) = u32x2{pack2(dk[4 * g], dk[4 * g + 1]), pack2(dk[4 * g + 2], dk[4 * g + 3])};
+      *reinterpret_cast<u32x2*>(Vs + l31 * PW + 2 * (8 * g + 4 * h)) = u32x2{pack2(dv[4 * g], dv[4 * g + 1]), pack2(dv[4 * g + 2], dv[4 * g + 3])};
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = lane + 64 * i, r = c >> 2;
+      if (r < sub[s].nr) {
+        us16* dst = a.dQKV16 + (rowg0 + r) * 768 + 256 + 32 * head + 8 * (c & 3);
+        store16_wt(dst, *reinterpret_cast<const u32x4*>(Ks + r * PW + 16 * (c & 3)));
+        store16_wt(dst + 256, *reinterpret_cast<const u32x4*>(Vs + r * PW + 16 * (c & 3)));
+      }
+    }
+    if (!more || sub[RT - 1].b != sub[s].b) {                     // (wave-uniform) the sample's last sub-tile of this block: one set of atomics
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = acc_row(i, h);
+        if (j < Nk) atomicAdd(a.dQ2acc + ((size_t)sub[s].b * Nk + j) * 256 + 32 * head + l31, dq2[i] * a.qscale);
+      }
+      dq2 = splat16(0.f);
+    }
+  }
+}
+
+// behind it, one block per sample: the KG rows' weight-gradient operand [dQ2 | dK | dV] (bf16) from the fp32 sums of both halves -- what
+// bwd2p_kernel's early blocks and last-arriving tile blocks do
+__global__ __launch_bounds__(256) void bwd2w_finish_kernel(const Bwd2Args a) {
+  const size_t krow0 = (size_t)blockIdx.x * a.Nk;
+  for (int c = threadIdx.x; c < a.Nk * 96; c += 256) {
+    const int j = c / 96, ch = c % 96;                            // chunk of 8 values: 0 .. 31 dQ2, 32 .. 95 dK | dV
+    const float* src = ch < 32 ? a.dQ2acc + (krow0 + j) * 256 + 8 * ch : a.dKV + (krow0 + j) * 512 + 8 * (ch - 32);
+    const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+    *reinterpret_cast<u32x4*>(a.dQKVkg16 + (krow0 + j) * 768 + 8 * ch) = u32x4{pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w)};
+  }
+}
+
 }  // namespace
 
 // The RG rows of the backward's first half on 64-row half-blocks; the KG rows (and the KG stream's dH16) through bwd1_kernel.
@@ -490,4 +644,25 @@ int launch_wide2_bwd1(Bwd1Args& a, int variant, hipStream_t stream) {
                              : (a.drop.p > 0.f ? bwd1w_launch<6, true, 1>(k, stream) : bwd1w_launch<6, false, 1>(k, stream));
   gemm_prof_close(prof, stream);
   return rc2;
+}
+
+// The second half (parameter-space form: no dR / dG products) with the RG rows on 64-row blocks, wave = head, no barriers.
+int launch_wide2_bwd2(Bwd2Args& a, hipStream_t stream) {
+  if (!a.param_space) return (int)hipErrorInvalidValue;
+  if (a.B < 1 || a.Nk < 1 || a.Nk > 16 || a.rg_tiles_max < 1 || !a.Q2_16 || !a.dO2_16 || !a.lse2 || !a.delta2 || !a.KV2_16 || !a.dQKV16 || !a.dQ2acc || !a.dKV ||
+      !a.dQKVkg16 || !a.tile_desc)
+    return (int)hipErrorInvalidValue;
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd2w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CfgC::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd2w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CfgC::LDS);
+    return true;
+  }();
+  (void)attr;
+  const int prof = gemm_prof_open(stream, 10.0 * (double)a.rows_rg * a.Nk * 256.0, PROF_BWD2);
+  const dim3 grid((a.rg_tiles_max + RT - 1) / RT);
+  if (a.drop.p > 0.f) hipLaunchKernelGGL(bwd2w_kernel<true>, grid, dim3(512), CfgC::LDS, stream, a);
+  else                hipLaunchKernelGGL(bwd2w_kernel<false>, grid, dim3(512), CfgC::LDS, stream, a);
+  hipLaunchKernelGGL(bwd2w_finish_kernel, dim3(a.B), dim3(256), 0, stream, a);
+  gemm_prof_close(prof, stream);
+  return (int)hipGetLastError();
 }

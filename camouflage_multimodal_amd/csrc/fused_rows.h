@@ -118,6 +118,8 @@ struct Bwd2Args {
   int split_finish;                            // (param_space only) 1: no arrival protocol -- the KG rows' dQ2 sums become bf16 in a second, B-block launch
 };
 int launch_fused_bwd2(Bwd2Args& a, int variant, hipStream_t stream);
+// param_space calls of large batches: the RG rows on 64-row blocks, wave = head, no barriers (bwd_wide2.hip); same outputs
+int launch_wide2_bwd2(Bwd2Args& a, hipStream_t stream);
 size_t fused_bwd2_lds();
 
 #define FUSED_PART_FLOATS 544

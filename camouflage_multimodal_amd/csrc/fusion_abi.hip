@@ -914,7 +914,9 @@ int backward_nodes17(const camo_dims_t& d, const float* const* P, float* const* 
   a2.stamps = g_dbg_stamps ? g_dbg_stamps + (size_t)3 * g_dbg_stamp_blocks * 8 : nullptr;
   a2.param_space = param_space ? 1 : 0;
   a2.split_finish = (param_space && bwd1w) ? 1 : 0;        // (by the size rule of the wide first half: the extra launch costs ~2 us)
-  CK(launch_fused_bwd2(a2, g_opt_fused_variant, st), "fused backward, second half");
+  // (wide2_bwd == 2: developer A/B, bwd2p_kernel + bwd2_finish_kernel behind the wide first half)
+  if (a2.split_finish && g_opt_wide2_bwd != 2) CK(launch_wide2_bwd2(a2, st), "fused backward, second half (64-row blocks)");
+  else CK(launch_fused_bwd2(a2, g_opt_fused_variant, st), "fused backward, second half");
   // every node-level weight gradient: dW += dy^T . x over the rows of a stream (bf16 operands the fused kernels wrote)
   if (!param_space) {
     GB16 g(drop, st);

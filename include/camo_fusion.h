@@ -60,7 +60,8 @@ enum { CAMO_PREC_F32 = 0,  /* f32-input MFMA: bit-faithful fp32 FMA chains      
  *   tail17   -1 the per-sample tail runs as one launch where the fused schedule does (B <= 16; groups up to 48), 0 never
  *   fused_rt -1 wide row tiles by size, 0 never, 1 / 2 / 4 that many 32-row tiles per 8-wave block (csrc/fused_wide.hip)
  *   wide2    -1 the 64-row half-block forward by size (csrc/fused_wide2.hip), 0 never, 1 whenever the shape allows
- *   wide2_bwd  -1 the backward's first half of the RG rows on 64-row half-blocks by size (csrc/bwd_wide2.hip), 0 never, 1 always
+ *   wide2_bwd  -1 the backward's node-level halves of the RG rows on 64-row blocks by size (csrc/bwd_wide2.hip), 0 never, 1 always,
+ *            2 always, with the 32-row second half behind the 64-row first half
  *   fused_one, wide_front_rt, tailw, tailw_bwd, param_space, tn_big, fused_variant, back_lead, tn_balance, tn_kcap, tn_exp, exp: developer A/Bs
  *   fused_save  1 makes inference calls of the fused schedule also write the tensors a backward would read (names for
  *            camo_debug_ws_offset: R16 G16 Q16 Q2_16 KV16 KV2_16 O16 O2_16 Y16 Y2_16 XH16 XH2_16 rstd1 rstd2 mask1 mask2 lse2 X16
