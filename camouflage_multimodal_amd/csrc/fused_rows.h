@@ -138,9 +138,10 @@ int launch_wide_back(BackArgs& a, int rt, int max_nr, hipStream_t stream);
 int wide_max_rows(int rt);
 
 // ---- second wide design (fused_wide2.hip): the RG rows' whole forward in one launch on 64-row half-blocks of 4 waves, two
-// independent blocks per CU; inference calls only (nothing saved, no dropout).  Same arguments as launch_wide_rgfwd.
-// Wf / bf: the folded in-projection [q | k2 | v2] = x Wf^T + bf (Wf = [Wq1; Wk2; Wv2] Wrg as a [768 x 128] shadow, bf [768] fp32), built by
-// launch_fold_rg whenever the parameters changed; f.W1 / f.bq / f.bkv (the unfolded in-projection) are not read.
+// independent blocks per CU, + the KG rows' launch behind it.  Same arguments as launch_wide_rgfwd.  Inference calls (b.save == 0, no
+// dropout) read the folded in-projection [q | k2 | v2] = x Wf^T + bf (Wf = [Wq1; Wk2; Wv2] Wrg as a [768 x 128] shadow, bf [768] fp32,
+// built by launch_fold_rg whenever the parameters changed) and not f.W1 / f.bq / f.bkv; saving / dropout calls read the unfolded
+// weights and write the backward's saved set (Wf / bf unused).
 int launch_fold_rg(const float* Wq, const float* Wkv, const float* bq, const float* bkv, const float* Wrg, const float* brg, us16* Wf, float* bf, hipStream_t stream);
 // save_r16 (saving calls): 0 when the backward takes the projections' weight gradients in parameter space (nothing reads R16 then)
 int launch_wide2_rgfwd(const FrontStream& f, const us16* Wf, const float* bf, float qscale, BackArgs& b, int max_nr, int save_r16, hipStream_t stream);

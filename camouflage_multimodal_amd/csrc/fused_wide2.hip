@@ -1,9 +1,10 @@
 // The RG rows' whole forward in ONE launch, second design (gfx950): 64-row half-blocks of 4 waves, two independent blocks per CU.
 // Contract and argument blocks: fused_rows.h (FrontStream, BackArgs: the same weight shadows, tile table, partial / ticket
-// protocol of the KG->RG attention and pooled-sum outputs as rgfwd_kernel of fused_wide.hip, which this replaces for inference
-// calls); the KG rows' projections (Q2_16, KV16) come from the front kernel's KG launch as before.
+// layout of the KG->RG attention and pooled-sum outputs as rgfwd_kernel of fused_wide.hip, which this replaces by size: inference calls
+// from 10 240 packed rows, saving / dropout calls from 57 344); the KG rows' projections (Q2_16, KV16) come from the front kernel's KG
+// launch as before, their chain (combine, out-projection, LayerNorm, FFN) runs as kgchain_kernel behind the RG launch.
 //
-// Why a second design (DESIGN.md 5c, VERDICT r3 item 1).  rgfwd_kernel<4> runs one block of 8 waves per CU on 128 rows: the two
+// Why a second design (DESIGN.md 5c, 5d).  rgfwd_kernel<4> runs one block of 8 waves per CU on 128 rows: the two
 // waves of a SIMD execute the same program between the same barriers, so they reach their MFMA passes together and their
 // epilogues together -- matrix time and vector time ADD (25 % MFMA issue), and the vector work itself was 9 instructions per
 // MFMA (the MFMA gap hides 5-6).  Here

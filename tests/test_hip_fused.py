@@ -315,6 +315,15 @@ def test_fused_training_step_shape_envelope_64row_forward(nrs, nk, pseed, fused_
     _training_step_shape_envelope(nrs, nk, pseed, fused_opts, wide2=1)
 
 
+@pytest.mark.parametrize("nrs,nk,pseed", [([1], 1, 6), ([5, 700, 32], 16, 6), ([33, 31, 1, 2, 530, 96], 13, 7), ([1500, 17], 7, 6),
+                                          ([128] * 3 + [127, 129, 256, 64, 192], 13, 6), ([64] * 17, 13, 6)])
+def test_fused_training_step_shape_envelope_64row_backward_parameter_space(nrs, nk, pseed, fused_opts):
+    """The same envelope on the schedule large batches run: 64-row forward, both backward halves on 64-row blocks (bwd1w_kernel, bwd2w_kernel
+    + bwd2w_finish_kernel) and the projections' weight gradients in parameter space -- forced here at shapes that by size would not take
+    it: one-node samples, Nk = 1 / 7 / 16, samples ending on tile boundaries, two samples in one 64-row block."""
+    _training_step_shape_envelope(nrs, nk, pseed, fused_opts, wide2=2)
+
+
 def _training_step_shape_envelope(nrs, nk, pseed, fused_opts, wide2):
     """Envelope of the fused BACKWARD (and of the one-launch tail where B <= 16): one-node samples, Nk = 1 / 7 / 16, samples
     that end exactly on a 32-, 64- or 128-row boundary, B = 17 (multi-launch tail behind fused node kernels), a 1500-node sample,
@@ -324,7 +333,9 @@ def _training_step_shape_envelope(nrs, nk, pseed, fused_opts, wide2):
     seed 6 the six-sample case has head units whose pre-activation sits within bf16 noise of zero in three samples: against
     the reference-exact f32 oracle one such ReLU flip moves instance_head.0.bias by 18 % (tools/dev/dev_relu_flip.py); the bf16-operand
     oracle rounds what the kernels round and lands on the same side.  The f32 oracle still bounds the logits (north_star: 1e-3)."""
-    fused_opts("wide2", wide2); fused_opts("wide2_bwd", wide2)      # (1: forward AND the backward's first half on 64-row half-blocks)
+    fused_opts("wide2", min(wide2, 1)); fused_opts("wide2_bwd", min(wide2, 1))      # (1: forward AND the backward's first half on 64-row half-blocks)
+    if wide2 == 2:
+        fused_opts("param_space", 1)                                # (2: ... and the parameter-space second half)
     cfg = OP.full_cfg()
     m = make_model(cfg, pseed, "bf16").train()
     eng = m._engine
